@@ -1,0 +1,175 @@
+/* openscene_amd.h -- C ABI of libopenscene_amd.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for ONE hot path of pengsongyou/openscene: hash voxelisation,
+ * coordinate / kernel maps, sparse 3-D convolution (fwd, dgrad, wgrad), batch-norm
+ * (+ReLU +residual), and the per-point feature x CLIP-text query.  Every entry
+ * point names the reference interface it replaces (paths relative to the
+ * reference tree; [ME] = NVIDIA/MinkowskiEngine v0.5.4, the un-vendored
+ * dependency that holds the reference's arithmetic -- SURVEY.md appendix C).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch), unless the
+ *     parameter is documented as "host";
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*),
+ *     except the few that return a count to the host (documented);
+ *   - return value: 0 = OK, negative = error (OSN_E_*); text via osn_last_error()
+ *     (thread-local); no C++ exception crosses the boundary;
+ *   - the library allocates nothing: scratch comes in through `ws` arguments
+ *     whose size the matching *_ws_bytes() helper reports;
+ *   - callable from any host thread (autograd's backward thread included); no
+ *     global mutable state.
+ *   - feature matrices are row-major float32 [rows, channels]; coordinates are
+ *     int32 rows (batch, x, y, z) exactly as the reference builds them
+ *     (dataset/feature_loader.py:178-179,204-205).
+ *   - a kernel map is a dense k-major neighbour table nbr[K, n_out] of int32,
+ *     nbr[k, o] = input row found at coord[o] + offset_k, or -1.
+ */
+#ifndef OPENSCENE_AMD_H
+#define OPENSCENE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSN_OK 0
+#define OSN_E_ARG (-1)     /* bad argument (null pointer, size, alignment, range) */
+#define OSN_E_HIP (-2)     /* a HIP runtime call or kernel launch failed          */
+#define OSN_E_WS (-3)      /* workspace too small                                  */
+#define OSN_E_RANGE (-4)   /* coordinate outside the packable range                */
+
+typedef void* osn_stream_t; /* hipStream_t */
+
+/* ---- library ------------------------------------------------------------- */
+int osn_version(void);                 /* ABI version, bumped on any signature change */
+const char* osn_last_error(void);      /* message of this thread's last failing call   */
+int osn_device_ok(void);               /* 1 if the current HIP device is gfx950        */
+
+/* ---- coordinate maps ----------------------------------------------------- *
+ * Replaces [ME] CoordinateManager.insert_and_map / stride (called implicitly by
+ *   SparseTensor(features, coordinates)   run/distill.py:316-317, run/evaluate.py:284
+ *   stride-2 convolutions                 models/mink_unet.py:52-53,59-60,66-67,73-74).
+ * The hash table is open addressing over a 64-bit packed key
+ * (b<<48 | (x+2^15)<<32 | (y+2^15)<<16 | (z+2^15)); capacity = power of two.    */
+int64_t osn_hash_capacity(int64_t n);                                  /* host helper */
+size_t osn_coords_unique_ws_bytes(int64_t n);                          /* host helper */
+
+/* Quantise rows to multiples of `stride` (floor; stride 1 = as is), de-duplicate.
+ * out_coords4[u] = u-th distinct row in FIRST-OCCURRENCE order, inverse[i] = u,
+ * first[u] = lowest input row of u.  On return the table (keys, vals) maps a packed
+ * key to u and is what osn_kmap_build() probes.  *n_unique_host is written on the
+ * HOST; the call synchronises `stream` once to deliver it.                      */
+int osn_coords_unique(const int32_t* coords4, int64_t n, int stride,
+                      uint64_t* table_keys, int32_t* table_vals, int64_t cap,
+                      int32_t* out_coords4, int32_t* inverse, int32_t* first,
+                      int64_t* n_unique_host, void* ws, size_t ws_bytes, osn_stream_t stream);
+
+/* Replaces [ME] CoordinateManager.kernel_map (HYPER_CUBE region).  Offsets
+ * enumerate with x fastest; odd ksize centred, even ksize spans [0,ksize); all
+ * multiplied by `offset_scale` (= dilation * tensor stride of the INPUT map).  */
+int osn_kmap_build(const uint64_t* in_table_keys, const int32_t* in_table_vals, int64_t cap,
+                   const int32_t* out_coords4, int64_t n_out, int ksize, int offset_scale,
+                   int32_t* nbr, osn_stream_t stream);
+
+/* tbl[k, i] = o  <=>  nbr[k, o] = i : the map of the transposed operator
+ * ([ME] MinkowskiConvolutionTranspose, models/mink_unet.py:77-78,84-85,91-92,98-99,
+ * and the input-gradient of every strided convolution).                          */
+int osn_kmap_transpose(const int32_t* nbr, int64_t n_out, int K, int64_t n_in, int32_t* tbl,
+                       osn_stream_t stream);
+
+/* counts[k] = #valid entries of nbr[k, :]  (int64 [K], device).                  */
+int osn_kmap_count(const int32_t* nbr, int64_t n_out, int K, int64_t* counts, osn_stream_t stream);
+
+/* ---- sparse convolution -------------------------------------------------- *
+ * Replaces [ME] MinkowskiConvolution / MinkowskiConvolutionTranspose forward and
+ * backward (constructed at models/mink_unet.py:47-113, models/resnet_base.py:92-97).
+ *   out[o, :] = sum_k in[nbr[k, o], :] @ W[k]        W: [K, cin, cout] float32
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain).
+ * out_rows (nullable): out row of tile slot j is out_rows[j] instead of j.       */
+size_t osn_spconv_fwd_ws_bytes(int64_t n_out, int K, int cin, int cout);
+int osn_spconv_fwd(const float* in, const float* W, const int32_t* nbr, const int32_t* out_rows,
+                   float* out, int64_t n_out, int K, int cin, int cout,
+                   void* ws, size_t ws_bytes, osn_stream_t stream);
+
+/* Wt[k] = W[flip ? K-1-k : k]^T   ([K, cout, cin]).  The input gradient is
+ * osn_spconv_fwd(gout, Wt, table, ...) with table = nbr and flip = 1 for a
+ * stride-1 odd kernel (the map is its own mirror), or the transposed table and
+ * flip = 0 otherwise.                                                             */
+int osn_weight_transpose(const float* W, int K, int cin, int cout, int flip, float* Wt,
+                         osn_stream_t stream);
+
+/* gW[k] = sum_{o : nbr[k,o] >= 0} in[nbr[k,o], :]^T (x) gout[o, :]   ([K, cin, cout]).
+ * Deterministic: fixed split of the row range, partial sums reduced in order.    */
+size_t osn_spconv_wgrad_ws_bytes(int64_t n_out, int K, int cin, int cout);
+int osn_spconv_wgrad(const float* in, const float* gout, const int32_t* nbr, float* gW,
+                     int64_t n_out, int K, int cin, int cout,
+                     void* ws, size_t ws_bytes, osn_stream_t stream);
+
+/* ---- batch norm (+ReLU, +residual) -------------------------------------- *
+ * Replaces [ME] MinkowskiBatchNorm (= torch.nn.BatchNorm1d on .F), MinkowskiReLU
+ * and the BasicBlock residual add (models/mink_unet.py:50-114, resnet_base.py:98).
+ * Training statistics: biased variance for normalisation, unbiased for the
+ * running estimate, momentum as torch.                                            */
+size_t osn_bn_ws_bytes(int64_t n, int c);
+/* mean[c], var[c] (biased) of x; if running_mean/var non-null update them in place:
+ * r = (1-momentum) r + momentum * stat  (var unbiased).                           */
+int osn_bn_stats(const float* x, int64_t n, int c, float* mean, float* var,
+                 float* running_mean, float* running_var, float momentum,
+                 void* ws, size_t ws_bytes, osn_stream_t stream);
+/* y = act( (x - mean) * rsqrt(var + eps) * gamma + beta  [+ residual] ),  act = ReLU if relu */
+int osn_bn_apply(const float* x, const float* mean, const float* var, const float* gamma,
+                 const float* beta, float eps, const float* residual, int relu, float* y,
+                 int64_t n, int c, osn_stream_t stream);
+/* Backward of osn_bn_apply.  g = relu ? gy * (y > 0) : gy.
+ * training != 0 (batch statistics were used):
+ *   gx = gamma * invstd * (g - mean_rows(g) - xhat * mean_rows(g * xhat))
+ * training == 0 (running statistics): gx = gamma * invstd * g.
+ * ggamma = sum_rows(g * xhat), gbeta = sum_rows(g); gres (nullable) = g.          */
+int osn_bn_backward(const float* x, const float* y, const float* gy, const float* mean,
+                    const float* var, const float* gamma, float eps, int relu, int training,
+                    float* gx, float* gres, float* ggamma, float* gbeta,
+                    int64_t n, int c, void* ws, size_t ws_bytes, osn_stream_t stream);
+
+/* ---- open-vocabulary query ---------------------------------------------- *
+ * Replaces run/evaluate.py:290-292 (and run/distill.py:423-425):
+ *   pred = feats[inds_reverse].half() @ text.t();  label = argmax(pred, 1)
+ * X float32 [n_rows_x, d]; gather (nullable) int64 [n]; text fp16 [c, d];
+ * scores (nullable) fp16 [n, c]; argmax int64 [n].  fp16 MFMA, fp32 accumulate,
+ * one rounding to fp16; argmax over the rounded scores, lowest index on ties.    */
+int osn_cosine_query(const float* X, const int64_t* gather, const void* text_f16,
+                     void* scores_f16, int64_t* argmax, int64_t n, int d, int c,
+                     osn_stream_t stream);
+/* run/evaluate.py:302-324 (ensemble): per point normalise both feature sources
+ * (x / (|x| + 1e-5)), take the source whose best fp16 score is larger (fusion wins
+ * only if strictly larger), re-score the selected UN-normalised fp16 features.
+ * Each source has its own (nullable) gather: the reference gathers the distilled
+ * voxel features with inds_reverse while the fused features are already per point.
+ * sel (nullable) uint8 [n] = 1 where the fusion feature was selected.            */
+size_t osn_query_ensemble_ws_bytes(int64_t n);
+int osn_query_ensemble(const float* X_distill, const int64_t* gather_distill,
+                       const float* X_fusion, const int64_t* gather_fusion,
+                       const void* text_f16, void* scores_f16, int64_t* argmax, uint8_t* sel,
+                       int64_t n, int d, int c, void* ws, size_t ws_bytes, osn_stream_t stream);
+
+/* ---- hash voxelisation --------------------------------------------------- *
+ * Replaces Voxelizer.voxelize (dataset/voxelizer.py:117-129) +
+ * sparse_quantize / fnv_hash_vec (dataset/voxelization_utils.py:9-22,112-132):
+ *   grid = floor([xyz,1] @ T^T[:, :3]); grid -= min(grid); key = FNV64(grid)
+ *   inds = first occurrence per distinct key in ascending key order,
+ *   inverse[p] = rank of key(p).
+ * xyz float64 [n,3] device; T12 = first three rows of the 4x4 transform, HOST,
+ * row-major (12 doubles).  Outputs: grid_out float64 [n,3] (integral, shifted),
+ * inds int64 [<=n], inverse int64 [n]; *n_vox_host on the HOST (one stream sync). */
+size_t osn_voxelize_ws_bytes(int64_t n);
+int osn_voxelize_fnv(const double* xyz, int64_t n, const double* T12_host,
+                     double* grid_out, int64_t* inds, int64_t* inverse, int64_t* n_vox_host,
+                     void* ws, size_t ws_bytes, osn_stream_t stream);
+/* fnv_hash_vec alone (dataset/voxelization_utils.py:9-22): keys[i] of integral rows. */
+int osn_fnv_hash(const double* grid, int64_t n, int ncol, uint64_t* keys, osn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENSCENE_AMD_H */

@@ -1,0 +1,262 @@
+// Batch-norm statistics, fused normalise(+residual)(+ReLU), and backward on
+// gfx950.  Pure streaming work (HBM-bound): 16-byte loads, lanes along the
+// channel axis, fp64 accumulators, deterministic two-stage column reductions
+// (per-block partials -> ordered final sum; no floating-point atomics).
+//
+// Function parity with torch.nn.BatchNorm1d as wrapped by MinkowskiBatchNorm,
+// MinkowskiReLU and the BasicBlock residual add.
+#include "common.h"
+
+namespace osn {
+
+constexpr int CR_COLS = 64;    // columns per block (16 lanes x float4)
+constexpr int CR_RL = 16;      // row lanes per block
+constexpr int CR_MAX_BLOCKS = 512;
+
+struct ColReducePlan {
+    int n_rb;            // row blocks
+    int n_cg;            // column groups
+    int rows_per_block;
+};
+
+static ColReducePlan plan_colreduce(int64_t n, int c) {
+    ColReducePlan p;
+    p.n_cg = int(cdiv(c, CR_COLS));
+    int64_t rb = cdiv(n, 4 * CR_RL);
+    if (rb > CR_MAX_BLOCKS) rb = CR_MAX_BLOCKS;
+    if (rb < 1) rb = 1;
+    p.rows_per_block = int(cdiv(cdiv(n, rb), CR_RL) * CR_RL);
+    p.n_rb = int(cdiv(n, p.rows_per_block));
+    if (p.n_rb < 1) p.n_rb = 1;
+    return p;
+}
+
+// MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat), g = relu ? gy*(y>0) : gy
+template <int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ gy, const float* __restrict__ mean,
+                                                         const float* __restrict__ var, float eps, int relu, int64_t n,
+                                                         int c, int rows_per_block, double* __restrict__ partial) {
+    __shared__ double red[2][CR_RL][CR_COLS];
+    const int tid = threadIdx.x;
+    const int cl = tid & 15, rl = tid >> 4;
+    const int col = blockIdx.y * CR_COLS + cl * 4;
+    const bool on = col < c;
+    const int64_t r0 = int64_t(blockIdx.x) * rows_per_block;
+    const int64_t r1 = min(n, r0 + rows_per_block);
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    float4 mu = make_float4(0, 0, 0, 0), is = make_float4(0, 0, 0, 0);
+    if (MODE == 1 && on) {
+        mu = *reinterpret_cast<const float4*>(mean + col);
+        const float4 v = *reinterpret_cast<const float4*>(var + col);
+        is = make_float4(1.f / sqrtf(v.x + eps), 1.f / sqrtf(v.y + eps), 1.f / sqrtf(v.z + eps), 1.f / sqrtf(v.w + eps));
+    }
+    if (on) {
+        for (int64_t r = r0 + rl; r < r1; r += CR_RL) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * c + col);
+            if (MODE == 0) {
+                s1[0] += xv.x; s1[1] += xv.y; s1[2] += xv.z; s1[3] += xv.w;
+                s2[0] += double(xv.x) * xv.x; s2[1] += double(xv.y) * xv.y;
+                s2[2] += double(xv.z) * xv.z; s2[3] += double(xv.w) * xv.w;
+            } else {
+                float4 g = *reinterpret_cast<const float4*>(gy + r * c + col);
+                if (relu) {
+                    const float4 yv = *reinterpret_cast<const float4*>(y + r * c + col);
+                    g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+                    g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+                }
+                s1[0] += g.x; s1[1] += g.y; s1[2] += g.z; s1[3] += g.w;
+                s2[0] += double(g.x) * ((xv.x - mu.x) * is.x); s2[1] += double(g.y) * ((xv.y - mu.y) * is.y);
+                s2[2] += double(g.z) * ((xv.z - mu.z) * is.z); s2[3] += double(g.w) * ((xv.w - mu.w) * is.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][rl][cl * 4 + j] = s1[j];
+        red[1][rl][cl * 4 + j] = s2[j];
+    }
+    __syncthreads();
+    if (tid < 2 * CR_COLS) {
+        const int which = tid / CR_COLS, cc = tid % CR_COLS;
+        double s = 0;
+#pragma unroll
+        for (int r = 0; r < CR_RL; ++r) s += red[which][r][cc];
+        const int gc = blockIdx.y * CR_COLS + cc;
+        if (gc < c) partial[(int64_t(blockIdx.x) * 2 + which) * c + gc] = s;
+    }
+}
+
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int n_rb, int64_t n, int c,
+                                         float* __restrict__ mean, float* __restrict__ var,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                         float momentum) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= c) return;
+    double s1 = 0, s2 = 0;
+    for (int b = 0; b < n_rb; ++b) {
+        s1 += partial[(int64_t(b) * 2 + 0) * c + j];
+        s2 += partial[(int64_t(b) * 2 + 1) * c + j];
+    }
+    const double m = s1 / double(n);
+    double v = s2 / double(n) - m * m;
+    if (v < 0) v = 0;
+    mean[j] = float(m);
+    var[j] = float(v);
+    if (running_mean) running_mean[j] = (1.f - momentum) * running_mean[j] + momentum * float(m);
+    if (running_var) {
+        const double unb = n > 1 ? v * double(n) / double(n - 1) : v;
+        running_var[j] = (1.f - momentum) * running_var[j] + momentum * float(unb);
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int n_rb, int c,
+                                       float* __restrict__ sum_g, float* __restrict__ sum_gx) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= c) return;
+    double s1 = 0, s2 = 0;
+    for (int b = 0; b < n_rb; ++b) {
+        s1 += partial[(int64_t(b) * 2 + 0) * c + j];
+        s2 += partial[(int64_t(b) * 2 + 1) * c + j];
+    }
+    sum_g[j] = float(s1);
+    sum_gx[j] = float(s2);
+}
+
+__device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ var, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps,
+                                                       const float* __restrict__ residual, int relu,
+                                                       float* __restrict__ y, int64_t total4, int c4) {
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total4; e += int64_t(gridDim.x) * blockDim.x) {
+        const int col = int(e % c4) * 4;
+        const float4 xv = ld4(x + e * 4), mu = ld4(mean + col), vv = ld4(var + col), ga = ld4(gamma + col),
+                     be = ld4(beta + col);
+        float4 o;
+        o.x = (xv.x - mu.x) * (1.f / sqrtf(vv.x + eps)) * ga.x + be.x;
+        o.y = (xv.y - mu.y) * (1.f / sqrtf(vv.y + eps)) * ga.y + be.y;
+        o.z = (xv.z - mu.z) * (1.f / sqrtf(vv.z + eps)) * ga.z + be.z;
+        o.w = (xv.w - mu.w) * (1.f / sqrtf(vv.w + eps)) * ga.w + be.w;
+        if (residual) {
+            const float4 rv = ld4(residual + e * 4);
+            o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+        }
+        if (relu) {
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(y + e * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ gy, const float* __restrict__ mean,
+                                                           const float* __restrict__ var, const float* __restrict__ gamma,
+                                                           float eps, int relu, int training,
+                                                           const float* __restrict__ sum_g,
+                                                           const float* __restrict__ sum_gx, float inv_n,
+                                                           float* __restrict__ gx, float* __restrict__ gres,
+                                                           int64_t total4, int c4) {
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total4; e += int64_t(gridDim.x) * blockDim.x) {
+        const int col = int(e % c4) * 4;
+        float4 g = ld4(gy + e * 4);
+        if (relu) {
+            const float4 yv = ld4(y + e * 4);
+            g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+            g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+        }
+        if (gres) *reinterpret_cast<float4*>(gres + e * 4) = g;
+        const float4 vv = ld4(var + col), ga = ld4(gamma + col);
+        const float4 is = make_float4(1.f / sqrtf(vv.x + eps), 1.f / sqrtf(vv.y + eps), 1.f / sqrtf(vv.z + eps),
+                                      1.f / sqrtf(vv.w + eps));
+        float4 o;
+        if (training) {
+            const float4 xv = ld4(x + e * 4), mu = ld4(mean + col), sg = ld4(sum_g + col), sx = ld4(sum_gx + col);
+            o.x = ga.x * is.x * (g.x - sg.x * inv_n - (xv.x - mu.x) * is.x * sx.x * inv_n);
+            o.y = ga.y * is.y * (g.y - sg.y * inv_n - (xv.y - mu.y) * is.y * sx.y * inv_n);
+            o.z = ga.z * is.z * (g.z - sg.z * inv_n - (xv.z - mu.z) * is.z * sx.z * inv_n);
+            o.w = ga.w * is.w * (g.w - sg.w * inv_n - (xv.w - mu.w) * is.w * sx.w * inv_n);
+        } else {
+            o.x = ga.x * is.x * g.x; o.y = ga.y * is.y * g.y; o.z = ga.z * is.z * g.z; o.w = ga.w * is.w * g.w;
+        }
+        *reinterpret_cast<float4*>(gx + e * 4) = o;
+    }
+}
+
+static int ew_grid(int64_t total4) {
+    int64_t g = cdiv(total4, 256);
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return int(g);
+}
+
+}  // namespace osn
+
+using namespace osn;
+
+extern "C" size_t osn_bn_ws_bytes(int64_t n, int c) {
+    (void)n;
+    return size_t(CR_MAX_BLOCKS) * 2 * size_t(c) * 8 + 256;
+}
+
+extern "C" int osn_bn_stats(const float* x, int64_t n, int c, float* mean, float* var, float* running_mean,
+                            float* running_var, float momentum, void* ws, size_t ws_bytes, osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n >= 1 && c >= 4 && (c & 3) == 0, OSN_E_ARG, "osn_bn_stats: need n >= 1 and c %% 4 == 0 (n=%lld c=%d)", (long long)n, c);
+    OSN_REQUIRE(x && mean && var && aligned16(x), OSN_E_ARG, "osn_bn_stats: null or unaligned pointer");
+    ColReducePlan p = plan_colreduce(n, c);
+    const size_t need = size_t(p.n_rb) * 2 * size_t(c) * 8;
+    OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_bn_stats: workspace %zu < %zu", ws_bytes, need);
+    double* partial = static_cast<double*>(ws);
+    hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(p.n_rb, p.n_cg), dim3(256), 0, st, x, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, 0, n, c,
+                       p.rows_per_block, partial);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, partial, p.n_rb, n, c, mean, var,
+                       running_mean, running_var, momentum);
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}
+
+extern "C" int osn_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                            float eps, const float* residual, int relu, float* y, int64_t n, int c,
+                            osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n >= 0 && c >= 4 && (c & 3) == 0, OSN_E_ARG, "osn_bn_apply: need c %% 4 == 0 (c=%d)", c);
+    if (n == 0) return OSN_OK;
+    OSN_REQUIRE(x && mean && var && gamma && beta && y, OSN_E_ARG, "osn_bn_apply: null pointer");
+    OSN_REQUIRE(aligned16(x) && aligned16(y) && aligned16(mean) && aligned16(var) && aligned16(gamma) && aligned16(beta) &&
+                    (!residual || aligned16(residual)),
+                OSN_E_ARG, "osn_bn_apply: pointers must be 16-byte aligned");
+    const int64_t total4 = n * (c / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, mean, var, gamma, beta, eps,
+                       residual, relu, y, total4, c / 4);
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}
+
+extern "C" int osn_bn_backward(const float* x, const float* y, const float* gy, const float* mean, const float* var,
+                               const float* gamma, float eps, int relu, int training, float* gx, float* gres,
+                               float* ggamma, float* gbeta, int64_t n, int c, void* ws, size_t ws_bytes,
+                               osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n >= 1 && c >= 4 && (c & 3) == 0, OSN_E_ARG, "osn_bn_backward: need n >= 1 and c %% 4 == 0");
+    OSN_REQUIRE(x && gy && mean && var && gamma && gx && ggamma && gbeta && (!relu || y), OSN_E_ARG,
+                "osn_bn_backward: null pointer");
+    OSN_REQUIRE(aligned16(x) && aligned16(gy) && aligned16(gx) && aligned16(mean) && aligned16(var) && aligned16(gamma) &&
+                    aligned16(ggamma) && aligned16(gbeta) && (!y || aligned16(y)) && (!gres || aligned16(gres)),
+                OSN_E_ARG, "osn_bn_backward: pointers must be 16-byte aligned");
+    ColReducePlan p = plan_colreduce(n, c);
+    const size_t need = size_t(p.n_rb) * 2 * size_t(c) * 8;
+    OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_bn_backward: workspace %zu < %zu", ws_bytes, need);
+    double* partial = static_cast<double*>(ws);
+    hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(p.n_rb, p.n_cg), dim3(256), 0, st, x, y, gy, mean, var, eps, relu, n,
+                       c, p.rows_per_block, partial);
+    // ggamma = sum g*xhat, gbeta = sum g  (also the two column sums the apply pass needs)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, partial, p.n_rb, c, gbeta, ggamma);
+    const int64_t total4 = n * (c / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, y, gy, mean, var, gamma, eps,
+                       relu, training, gbeta, ggamma, 1.f / float(n), gx, gres, total4, c / 4);
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}

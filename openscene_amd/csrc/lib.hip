@@ -1,0 +1,26 @@
+// Library-level entry points: version, error text, device check.
+#include "common.h"
+#include <string.h>
+
+namespace osn {
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace osn
+
+extern "C" int osn_version(void) { return 1; }
+
+extern "C" const char* osn_last_error(void) { return osn::g_err; }
+
+extern "C" int osn_device_ok(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}

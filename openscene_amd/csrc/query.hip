@@ -1,0 +1,236 @@
+// Open-vocabulary query on gfx950: fused gather + fp32->fp16 cast + fp16 MFMA
+// GEMM against the CLIP text matrix + fp16 rounding + row argmax.
+//
+// Replaces run/evaluate.py:290-292 / 302-324 and run/distill.py:423-425:
+//   pred = feats[inds_reverse].half() @ text_features.t();  torch.max(pred, 1)[1]
+//
+// HBM-bound on reading X once through the gather; the text
+// matrix (<= 246 KB) stays L2-resident.  MFMA is used because this IS a dense
+// contraction: v_mfma_f32_32x32x16_f16, A = 32 point rows x 16 k, B = text rows
+// (text is [C, D] row-major = the K-contiguous B operand, no transpose needed).
+#include "common.h"
+
+namespace osn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+constexpr int Q_BM = 128;   // points per workgroup (4 waves x 32)
+constexpr int Q_DK = 64;    // feature chunk
+constexpr int Q_LD = Q_DK + 8;  // padded LDS row (144 B: 16-B aligned, conflict-free ds_read_b128)
+
+// sources: point p reads row g0[p] of X0 (or p if g0 null); if sel && sel[p], row g1[p] of X1.
+template <int CT>
+__global__ __launch_bounds__(256) void query_kernel(const float* __restrict__ X0, const int64_t* __restrict__ g0,
+                                                    const float* __restrict__ X1, const int64_t* __restrict__ g1,
+                                                    const uint8_t* __restrict__ sel, const float* __restrict__ rowdiv,
+                                                    const _Float16* __restrict__ T, _Float16* __restrict__ scores,
+                                                    int64_t* __restrict__ argmax, float* __restrict__ rowmax,
+                                                    int64_t n, int d, int c) {
+    __shared__ __attribute__((aligned(16))) _Float16 Xs[Q_BM][Q_LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Ts[CT * 32][Q_LD];
+    __shared__ const float* rowptr[Q_BM];
+    __shared__ float rowden[Q_BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row0 = int64_t(blockIdx.x) * Q_BM;
+
+    if (tid < Q_BM) {
+        const int64_t p = row0 + tid;
+        const float* ptr = nullptr;
+        float den = 1.f;
+        if (p < n) {
+            if (sel && sel[p]) ptr = X1 + (g1 ? g1[p] : p) * int64_t(d);
+            else ptr = X0 + (g0 ? g0[p] : p) * int64_t(d);
+            if (rowdiv) den = rowdiv[p];
+        }
+        rowptr[tid] = ptr;
+        rowden[tid] = den;
+    }
+    __syncthreads();
+
+    float bestv[16];
+    int besti[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { bestv[r] = -INFINITY; besti[r] = 0x7fffffff; }
+
+    for (int cg0 = 0; cg0 < c; cg0 += 32 * CT) {
+        f32x16 acc[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+        for (int d0 = 0; d0 < d; d0 += Q_DK) {
+            {   // X chunk: 128 rows x 64 floats -> fp16
+                const int q = tid & 15, r = tid >> 4;
+#pragma unroll
+                for (int ps = 0; ps < Q_BM / 16; ++ps) {
+                    const int row = ps * 16 + r;
+                    const float* src = rowptr[row];
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (src && d0 + q * 4 < d) v = *reinterpret_cast<const float4*>(src + d0 + q * 4);
+                    if (rowdiv) {
+                        const float den = rowden[row];
+                        v.x /= den; v.y /= den; v.z /= den; v.w /= den;
+                    }
+                    half4 h;
+                    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+                    *reinterpret_cast<half4*>(&Xs[row][q * 4]) = h;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {  // T chunk: CT*32 text rows x 64 halfs
+                const int f = tid + 256 * j;
+                const int trow = f >> 3, ch = f & 7;
+                const int col = cg0 + trow;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (col < c && d0 + ch * 8 < d)
+                    v = *reinterpret_cast<const uint4*>(T + int64_t(col) * d + d0 + ch * 8);
+                *reinterpret_cast<uint4*>(&Ts[trow][ch * 8]) = v;
+            }
+            __syncthreads();
+            const int arow = wave * 32 + (lane & 31);
+            const int kh = 8 * (lane >> 5);
+#pragma unroll
+            for (int ks = 0; ks < Q_DK / 16; ++ks) {
+                const half8 a = *reinterpret_cast<const half8*>(&Xs[arow][ks * 16 + kh]);
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    const half8 b = *reinterpret_cast<const half8*>(&Ts[t * 32 + (lane & 31)][ks * 16 + kh]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- group epilogue: round to fp16, optional store, running argmax
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int col = cg0 + t * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const _Float16 hv = (_Float16)acc[t][r];
+                const float v = (float)hv;
+                if (col < c) {
+                    if (scores && row < n) scores[row * c + col] = hv;
+                    if (v > bestv[r] || (v == bestv[r] && col < besti[r])) { bestv[r] = v; besti[r] = col; }
+                }
+            }
+        }
+    }
+    // ---- reduce over the 32 lanes that hold one row's columns
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = bestv[r];
+        int i = besti[r];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+            const float ov = __shfl_xor(v, m, 64);
+            const int oi = __shfl_xor(i, m, 64);
+            if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+        }
+        if ((lane & 31) == 0) {
+            const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < n) {
+                if (argmax) argmax[row] = (i == 0x7fffffff) ? 0 : i;
+                if (rowmax) rowmax[row] = v;
+            }
+        }
+    }
+}
+
+// den[p] = ||X[g[p]]||_2 + eps   (one wave per point)
+__global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ X, const int64_t* __restrict__ g,
+                                                       int64_t n, int d, float eps, float* __restrict__ den) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (p >= n) return;
+    const float* src = X + (g ? g[p] : p) * int64_t(d);
+    float s = 0.f;
+    for (int j = lane * 4; j < d; j += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(src + j);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) den[p] = sqrtf(s) + eps;
+}
+
+__global__ void ensemble_select_kernel(const float* __restrict__ max_d, const float* __restrict__ max_f, int64_t n,
+                                       uint8_t* __restrict__ sel) {
+    const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p < n) sel[p] = max_d[p] < max_f[p] ? 1 : 0;
+}
+
+static int launch_query(hipStream_t st, const float* X0, const int64_t* g0, const float* X1, const int64_t* g1,
+                        const uint8_t* sel, const float* rowdiv, const _Float16* T, _Float16* scores, int64_t* argmax,
+                        float* rowmax, int64_t n, int d, int c) {
+    const dim3 grid(cdiv(n, Q_BM)), block(256);
+    const int ct = int(cdiv(c, 32));
+    if (ct <= 1)
+        hipLaunchKernelGGL((query_kernel<1>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
+    else if (ct <= 2)
+        hipLaunchKernelGGL((query_kernel<2>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
+    else if (ct <= 3)
+        hipLaunchKernelGGL((query_kernel<3>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
+    else
+        hipLaunchKernelGGL((query_kernel<5>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}
+
+}  // namespace osn
+
+using namespace osn;
+
+extern "C" int osn_cosine_query(const float* X, const int64_t* gather, const void* text_f16, void* scores_f16,
+                                int64_t* argmax, int64_t n, int d, int c, osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n >= 0 && d >= 8 && (d & 7) == 0 && c >= 1, OSN_E_ARG,
+                "osn_cosine_query: need d %% 8 == 0 and c >= 1 (d=%d c=%d)", d, c);
+    if (n == 0) return OSN_OK;
+    OSN_REQUIRE(X && text_f16 && (argmax || scores_f16), OSN_E_ARG, "osn_cosine_query: null pointer");
+    OSN_REQUIRE(aligned16(X) && aligned16(text_f16), OSN_E_ARG, "osn_cosine_query: X and text must be 16-byte aligned");
+    return launch_query(st, X, gather, nullptr, nullptr, nullptr, nullptr, static_cast<const _Float16*>(text_f16),
+                        static_cast<_Float16*>(scores_f16), argmax, nullptr, n, d, c);
+}
+
+extern "C" size_t osn_query_ensemble_ws_bytes(int64_t n) {
+    const size_t m = size_t(n > 0 ? n : 1);
+    return 4 * align_up(m * 4, 256) + align_up(m, 256);
+}
+
+extern "C" int osn_query_ensemble(const float* X_distill, const int64_t* gather_distill, const float* X_fusion,
+                                  const int64_t* gather_fusion, const void* text_f16, void* scores_f16,
+                                  int64_t* argmax, uint8_t* sel_out, int64_t n, int d, int c, void* ws, size_t ws_bytes,
+                                  osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n >= 0 && d >= 8 && (d & 7) == 0 && c >= 1, OSN_E_ARG, "osn_query_ensemble: need d %% 8 == 0 and c >= 1");
+    if (n == 0) return OSN_OK;
+    OSN_REQUIRE(X_distill && X_fusion && text_f16 && (argmax || scores_f16), OSN_E_ARG, "osn_query_ensemble: null pointer");
+    OSN_REQUIRE(aligned16(X_distill) && aligned16(X_fusion) && aligned16(text_f16), OSN_E_ARG,
+                "osn_query_ensemble: feature and text pointers must be 16-byte aligned");
+    OSN_REQUIRE(ws && ws_bytes >= osn_query_ensemble_ws_bytes(n), OSN_E_WS, "osn_query_ensemble: workspace too small");
+    char* p = static_cast<char*>(ws);
+    const size_t fsz = align_up(size_t(n) * 4, 256);
+    float* den_d = reinterpret_cast<float*>(p);
+    float* den_f = reinterpret_cast<float*>(p + fsz);
+    float* max_d = reinterpret_cast<float*>(p + 2 * fsz);
+    float* max_f = reinterpret_cast<float*>(p + 3 * fsz);
+    uint8_t* sel = sel_out ? sel_out : reinterpret_cast<uint8_t*>(p + 4 * fsz);
+    const _Float16* T = static_cast<const _Float16*>(text_f16);
+    const dim3 ngrid(cdiv(n, 4)), block(256);
+    hipLaunchKernelGGL(row_norm_kernel, ngrid, block, 0, st, X_distill, gather_distill, n, d, 1e-5f, den_d);
+    hipLaunchKernelGGL(row_norm_kernel, ngrid, block, 0, st, X_fusion, gather_fusion, n, d, 1e-5f, den_f);
+    OSN_LAUNCH_CHECK();
+    int rc = launch_query(st, X_distill, gather_distill, nullptr, nullptr, nullptr, den_d, T, nullptr, nullptr, max_d, n, d, c);
+    if (rc) return rc;
+    rc = launch_query(st, X_fusion, gather_fusion, nullptr, nullptr, nullptr, den_f, T, nullptr, nullptr, max_f, n, d, c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ensemble_select_kernel, dim3(cdiv(n, 256)), block, 0, st, max_d, max_f, n, sel);
+    OSN_LAUNCH_CHECK();
+    return launch_query(st, X_distill, gather_distill, X_fusion, gather_fusion, sel, nullptr, T,
+                        static_cast<_Float16*>(scores_f16), argmax, nullptr, n, d, c);
+}

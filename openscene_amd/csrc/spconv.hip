@@ -1,0 +1,485 @@
+// Sparse 3-D convolution on gfx950: forward / input-gradient (one kernel) and
+// weight-gradient, fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32.
+//
+// Function parity (not a port) with MinkowskiEngine's convolution kernels
+// (SURVEY.md section 2.1, appendix C item 5):  out[o] = sum_k in[nbr[k,o]] @ W[k].
+//
+// Design (MI355X-first):
+//   * output-stationary implicit GEMM over the dense k-major neighbour table:
+//     a workgroup owns BM output rows x BN output channels and walks the K
+//     kernel offsets; per offset it gathers the BM input rows (16-byte loads,
+//     one 128-byte row segment per 8 lanes) into LDS, stages W[k] once for all
+//     four waves, and accumulates in registers -> no atomics, no scatter, one
+//     coalesced store per output row, bitwise reproducible;
+//   * an offset none of the tile's rows uses is skipped (block-uniform vote);
+//   * 64-wide waves: each wave owns 32 rows x (32*TN) channels of accumulators
+//     in the 32x32x2 f32 MFMA layout; LDS A tile padded to an odd stride so the
+//     32-row column reads are conflict-free;
+//   * small maps (deep U-Net levels) use narrower row tiles and split the offset
+//     loop across workgroups (deterministic partial buffers + ordered reduce) so
+//     the launch still covers the 256 CUs.
+#include "common.h"
+
+namespace osn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int WM, int WN, int TN, int BK>
+__global__ __launch_bounds__(256) void spconv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ W,
+                                                         const int32_t* __restrict__ nbr,
+                                                         const int32_t* __restrict__ out_rows,
+                                                         float* __restrict__ out, int n_out, int K, int cin, int cout,
+                                                         int k_per_split, int to_partial) {
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * TN * WN;
+    __shared__ float As[BM][BK + 1];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][BN];
+    __shared__ int rowidx[BM];
+    __shared__ int wflag[2][4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int row0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int k_begin = blockIdx.z * k_per_split;
+    const int k_end = min(K, k_begin + k_per_split);
+    const bool a_vec = (cin & 3) == 0;
+    const bool b_vec = (cout & 3) == 0;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int k = k_begin; k < k_end; ++k) {
+        int idx = -1;
+        if (tid < BM) {
+            const int r = row0 + tid;
+            if (r < n_out) idx = nbr ? nbr[int64_t(k) * n_out + r] : r;
+            rowidx[tid] = idx;
+        }
+        // block-uniform vote (double-buffered flags: a wave is never more than one
+        // barrier ahead of the slowest one); the barrier also publishes rowidx
+        const int wave_any = __any(idx >= 0);
+        if (lane == 0) wflag[k & 1][wave] = wave_any;
+        __syncthreads();
+        if (!(wflag[k & 1][0] | wflag[k & 1][1] | wflag[k & 1][2] | wflag[k & 1][3])) continue;
+
+        for (int c0 = 0; c0 < cin; c0 += BK) {
+            // ---- gather the A tile: BM rows x BK input channels
+            if (BK == 32 && a_vec) {
+                const int sub = tid & 7, r = tid >> 3;
+#pragma unroll
+                for (int p = 0; p < BM / 32; ++p) {
+                    const int row = p * 32 + r;
+                    const int i = rowidx[row];
+                    const int c = c0 + sub * 4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (i >= 0 && c < cin) v = *reinterpret_cast<const float4*>(in + int64_t(i) * cin + c);
+                    As[row][sub * 4 + 0] = v.x;
+                    As[row][sub * 4 + 1] = v.y;
+                    As[row][sub * 4 + 2] = v.z;
+                    As[row][sub * 4 + 3] = v.w;
+                }
+            } else {
+                for (int e = tid; e < BM * BK; e += 256) {
+                    const int row = e / BK, cc = e % BK;
+                    const int i = rowidx[row];
+                    const int c = c0 + cc;
+                    As[row][cc] = (i >= 0 && c < cin) ? in[int64_t(i) * cin + c] : 0.f;
+                }
+            }
+            // ---- stage the B tile: W[k][c0:c0+BK][n0:n0+BN]
+            if (b_vec) {
+                constexpr int V = BN / 4;  // float4 per row
+                for (int f = tid; f < BK * V; f += 256) {
+                    const int r = f / V, c4 = f % V;
+                    const int c = c0 + r, n = n0 + c4 * 4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c < cin && n < cout)
+                        v = *reinterpret_cast<const float4*>(W + (int64_t(k) * cin + c) * cout + n);
+                    *reinterpret_cast<float4*>(&Bs[r][c4 * 4]) = v;
+                }
+            } else {
+                for (int e = tid; e < BK * BN; e += 256) {
+                    const int r = e / BN, cc = e % BN;
+                    const int c = c0 + r, n = n0 + cc;
+                    Bs[r][cc] = (c < cin && n < cout) ? W[(int64_t(k) * cin + c) * cout + n] : 0.f;
+                }
+            }
+            __syncthreads();
+            // ---- MFMA: lane l feeds A[row = l&31][kk + (l>>5)], B[kk + (l>>5)][col = l&31]
+            const int arow = wm * 32 + (lane & 31);
+            const int kh = lane >> 5;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a = As[arow][kk + kh];
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    const float b = Bs[kk + kh][(wn * TN + t) * 32 + (lane & 31)];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* dst = out;
+    if (to_partial) dst = out + int64_t(blockIdx.z) * n_out * cout;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int col = n0 + (wn * TN + t) * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < n_out && col < cout) {
+                const int orow = (!to_partial && out_rows) ? out_rows[row] : row;
+                dst[int64_t(orow) * cout + col] = acc[t][r];
+            }
+        }
+    }
+}
+
+__global__ void reduce_partial_rows_kernel(const float* __restrict__ partial, int S, int64_t n_out, int cout,
+                                           const int32_t* __restrict__ out_rows, float* __restrict__ out) {
+    const int64_t total = n_out * cout;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < S; ++z) s += partial[int64_t(z) * total + e];
+        if (out_rows) {
+            const int64_t r = e / cout, c = e % cout;
+            out[int64_t(out_rows[r]) * cout + c] = s;
+        } else {
+            out[e] = s;
+        }
+    }
+}
+
+__global__ void weight_transpose_kernel(const float* __restrict__ W, int K, int cin, int cout, int flip,
+                                        float* __restrict__ Wt) {
+    const int64_t total = int64_t(K) * cin * cout;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        // e indexes Wt [K][cout][cin]
+        const int ci = int(e % cin);
+        const int co = int((e / cin) % cout);
+        const int k = int(e / (int64_t(cin) * cout));
+        const int ks = flip ? K - 1 - k : k;
+        Wt[e] = W[(int64_t(ks) * cin + ci) * cout + co];
+    }
+}
+
+// ------------------------------------------------------------- weight grad ----
+// Block tile: 64 input channels x 128 output channels of gW[k]; wave w owns output
+// channel tile w and both 32-row input-channel tiles.  Reduction over the valid
+// (in,out) pairs of offset k inside the block's row range, compacted in LDS in a
+// deterministic (ballot/prefix) order, staged 16 pairs at a time.
+constexpr int WG_CI = 64, WG_CO = 128, WG_RB = 16, WG_SUB = 1024;
+
+__global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+                                                           const int32_t* __restrict__ nbr, float* __restrict__ dst,
+                                                           int n_out, int K, int cin, int cout, int rows_per_split,
+                                                           int n_co_blocks) {
+    __shared__ __attribute__((aligned(16))) float As[WG_RB][WG_CI];
+    __shared__ __attribute__((aligned(16))) float Gs[WG_RB][WG_CO];
+    __shared__ int list_o[WG_SUB];
+    __shared__ int list_i[WG_SUB];
+    __shared__ int wcnt[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci0 = (blockIdx.x / n_co_blocks) * WG_CI;
+    const int co0 = (blockIdx.x % n_co_blocks) * WG_CO;
+    const int k = blockIdx.z;
+    const int r_begin = blockIdx.y * rows_per_split;
+    const int r_end = min(n_out, r_begin + rows_per_split);
+    const bool a_vec = (cin & 3) == 0, g_vec = (cout & 3) == 0;
+    const bool tile_on[2] = {ci0 < cin, ci0 + 32 < cin};
+    const bool wave_on = co0 + wave * 32 < cout;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int base = r_begin; base < r_end; base += WG_SUB) {
+        // ---- compact the valid pairs of rows [base, base + WG_SUB)
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < WG_SUB / 256; ++j) {
+            const int o = base + j * 256 + tid;
+            int i = -1;
+            if (o < r_end) i = nbr ? nbr[int64_t(k) * n_out + o] : o;
+            const bool valid = i >= 0;
+            const unsigned long long m = __ballot(valid);
+            if (lane == 0) wcnt[wave] = __popcll(m);
+            __syncthreads();
+            int woff = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int c = wcnt[w];
+                if (w < wave) woff += c;
+                tot += c;
+            }
+            if (valid) {
+                const int pos = cnt + woff + __popcll(m & ((1ull << lane) - 1ull));
+                list_o[pos] = o;
+                list_i[pos] = i;
+            }
+            cnt += tot;
+            __syncthreads();
+        }
+        // ---- reduce the compacted pairs, WG_RB at a time
+        for (int p0 = 0; p0 < cnt; p0 += WG_RB) {
+            {   // A: in[list_i[p0+j]][ci0 : ci0+64)   -- 16 rows x 16 float4 = one per thread
+                const int j = tid >> 4, c4 = tid & 15;
+                const int p = p0 + j;
+                const int c = ci0 + c4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < cnt) {
+                    const float* src = in + int64_t(list_i[p]) * cin + c;
+                    if (a_vec) {
+                        if (c < cin) v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (c + 0 < cin) v.x = src[0];
+                        if (c + 1 < cin) v.y = src[1];
+                        if (c + 2 < cin) v.z = src[2];
+                        if (c + 3 < cin) v.w = src[3];
+                    }
+                }
+                *reinterpret_cast<float4*>(&As[j][c4 * 4]) = v;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // G: gout[list_o[p0+j]][co0 : co0+128)  -- 16 rows x 32 float4
+                const int f = tid + h * 256;
+                const int j = f >> 5, c4 = f & 31;
+                const int p = p0 + j;
+                const int c = co0 + c4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < cnt) {
+                    const float* src = gout + int64_t(list_o[p]) * cout + c;
+                    if (g_vec) {
+                        if (c < cout) v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (c + 0 < cout) v.x = src[0];
+                        if (c + 1 < cout) v.y = src[1];
+                        if (c + 2 < cout) v.z = src[2];
+                        if (c + 3 < cout) v.w = src[3];
+                    }
+                }
+                *reinterpret_cast<float4*>(&Gs[j][c4 * 4]) = v;
+            }
+            __syncthreads();
+            if (wave_on) {
+                const int kh = lane >> 5;
+#pragma unroll
+                for (int kk = 0; kk < WG_RB; kk += 2) {
+                    const float b = Gs[kk + kh][wave * 32 + (lane & 31)];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        if (tile_on[t]) {
+                            const float a = As[kk + kh][t * 32 + (lane & 31)];
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- store: dst[(split, k)][ci][co]
+    float* d = dst + (int64_t(blockIdx.y) * K + k) * cin * cout;
+    if (wave_on) {
+        const int co = co0 + wave * 32 + (lane & 31);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (ci < cin && co < cout) d[int64_t(ci) * cout + co] = acc[t][r];
+            }
+        }
+    }
+}
+
+__global__ void reduce_partial_flat_kernel(const float* __restrict__ partial, int S, int64_t total,
+                                           float* __restrict__ out) {
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < S; ++z) s += partial[int64_t(z) * total + e];
+        out[e] = s;
+    }
+}
+
+// ------------------------------------------------------------ host planning ----
+struct FwdPlan {
+    int cfg;      // 0: BM128 (4,1,TN) ; 1: BM64 (2,2,TN) ; 2: BM32 (1,4,1)
+    int tn;
+    int bm, bn;
+    int gx, gy, S, kps;
+};
+
+static FwdPlan plan_fwd(int64_t n_out, int K, int cin, int cout) {
+    FwdPlan p;
+    const int ct = int(cdiv(cout, 32));
+    if (n_out >= 32768 || ct == 1) {
+        p.cfg = 0; p.tn = ct >= 4 ? 4 : ct; p.bm = 128; p.bn = 32 * p.tn;
+    } else if (n_out >= 4096 || ct == 2) {
+        p.cfg = 1; p.tn = ct >= 3 ? 2 : 1; p.bm = 64; p.bn = 64 * p.tn;
+    } else {
+        p.cfg = 2; p.tn = 1; p.bm = 32; p.bn = 128;
+    }
+    p.gx = int(cdiv(n_out, p.bm));
+    p.gy = int(cdiv(cout, p.bn));
+    const int64_t blocks = int64_t(p.gx) * p.gy;
+    int S = 1;
+    if (K > 1 && blocks < 384) {
+        S = int(cdiv(768, blocks));
+        if (S > 16) S = 16;
+        if (S > K) S = K;
+    }
+    p.kps = int(cdiv(K, S));
+    p.S = int(cdiv(K, p.kps));
+    return p;
+}
+
+struct WgradPlan {
+    int n_ci, n_co, S, rps;
+};
+
+static WgradPlan plan_wgrad(int64_t n_out, int K, int cin, int cout) {
+    WgradPlan p;
+    p.n_ci = int(cdiv(cin, WG_CI));
+    p.n_co = int(cdiv(cout, WG_CO));
+    const int64_t base = int64_t(K) * p.n_ci * p.n_co;
+    int64_t S = cdiv(1024, base);
+    const int64_t smax = cdiv(n_out, 2 * WG_SUB);
+    if (S > smax) S = smax;
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    p.rps = int(cdiv(cdiv(n_out, S), WG_SUB) * WG_SUB);
+    p.S = int(cdiv(n_out, p.rps));
+    if (p.S < 1) p.S = 1;
+    return p;
+}
+
+}  // namespace osn
+
+using namespace osn;
+
+extern "C" size_t osn_spconv_fwd_ws_bytes(int64_t n_out, int K, int cin, int cout) {
+    if (n_out <= 0) return 0;
+    FwdPlan p = plan_fwd(n_out, K, cin, cout);
+    return p.S > 1 ? size_t(p.S) * size_t(n_out) * size_t(cout) * 4 : 0;
+}
+
+template <int WM, int WN, int TN, int BK>
+static void launch_fwd(const FwdPlan& p, hipStream_t st, const float* in, const float* W, const int32_t* nbr,
+                       const int32_t* out_rows, float* dst, int n_out, int K, int cin, int cout) {
+    hipLaunchKernelGGL((spconv_fwd_kernel<WM, WN, TN, BK>), dim3(p.gx, p.gy, p.S), dim3(256), 0, st, in, W, nbr,
+                       out_rows, dst, n_out, K, cin, cout, p.kps, p.S > 1 ? 1 : 0);
+}
+
+extern "C" int osn_spconv_fwd(const float* in, const float* W, const int32_t* nbr, const int32_t* out_rows, float* out,
+                              int64_t n_out, int K, int cin, int cout, void* ws, size_t ws_bytes,
+                              osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_spconv_fwd: n_out out of range");
+    OSN_REQUIRE(K >= 1 && cin >= 1 && cout >= 1, OSN_E_ARG, "osn_spconv_fwd: bad K/cin/cout (%d,%d,%d)", K, cin, cout);
+    if (n_out == 0) return OSN_OK;
+    OSN_REQUIRE(in && W && out, OSN_E_ARG, "osn_spconv_fwd: null pointer");
+    OSN_REQUIRE(nbr || K == 1, OSN_E_ARG, "osn_spconv_fwd: nbr may be null only for K == 1 (identity map)");
+    OSN_REQUIRE(aligned16(in) && aligned16(W) && aligned16(out), OSN_E_ARG, "osn_spconv_fwd: pointers must be 16-byte aligned");
+    FwdPlan p = plan_fwd(n_out, K, cin, cout);
+    float* dst = out;
+    if (p.S > 1) {
+        const size_t need = size_t(p.S) * size_t(n_out) * size_t(cout) * 4;
+        OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_spconv_fwd: workspace %zu < %zu", ws_bytes, need);
+        dst = static_cast<float*>(ws);
+    }
+    const int n = int(n_out);
+    if (cin <= 4) {
+        // stem convolution (3 -> 32): 4-wide channel chunks
+        switch (p.cfg * 10 + p.tn) {
+            case 1: launch_fwd<4, 1, 1, 4>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 2: launch_fwd<4, 1, 2, 4>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 3: launch_fwd<4, 1, 3, 4>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 4: launch_fwd<4, 1, 4, 4>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 11: launch_fwd<2, 2, 1, 4>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 12: launch_fwd<2, 2, 2, 4>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            default: launch_fwd<1, 4, 1, 4>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+        }
+    } else {
+        switch (p.cfg * 10 + p.tn) {
+            case 1: launch_fwd<4, 1, 1, 32>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 2: launch_fwd<4, 1, 2, 32>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 3: launch_fwd<4, 1, 3, 32>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 4: launch_fwd<4, 1, 4, 32>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 11: launch_fwd<2, 2, 1, 32>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 12: launch_fwd<2, 2, 2, 32>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            default: launch_fwd<1, 4, 1, 32>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+        }
+    }
+    OSN_LAUNCH_CHECK();
+    if (p.S > 1) {
+        const int64_t total = n_out * cout;
+        int g = int(cdiv(total, 256));
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(reduce_partial_rows_kernel, dim3(g), dim3(256), 0, st, dst, p.S, n_out, cout, out_rows, out);
+        OSN_LAUNCH_CHECK();
+    }
+    return OSN_OK;
+}
+
+extern "C" int osn_weight_transpose(const float* W, int K, int cin, int cout, int flip, float* Wt,
+                                    osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(W && Wt && K >= 1 && cin >= 1 && cout >= 1, OSN_E_ARG, "osn_weight_transpose: bad arguments");
+    const int64_t total = int64_t(K) * cin * cout;
+    int g = int(cdiv(total, 256));
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(weight_transpose_kernel, dim3(g), dim3(256), 0, st, W, K, cin, cout, flip, Wt);
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}
+
+extern "C" size_t osn_spconv_wgrad_ws_bytes(int64_t n_out, int K, int cin, int cout) {
+    if (n_out <= 0) return 0;
+    WgradPlan p = plan_wgrad(n_out, K, cin, cout);
+    return p.S > 1 ? size_t(p.S) * size_t(K) * size_t(cin) * size_t(cout) * 4 : 0;
+}
+
+extern "C" int osn_spconv_wgrad(const float* in, const float* gout, const int32_t* nbr, float* gW, int64_t n_out, int K,
+                                int cin, int cout, void* ws, size_t ws_bytes, osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_spconv_wgrad: n_out out of range");
+    OSN_REQUIRE(K >= 1 && cin >= 1 && cout >= 1 && gW, OSN_E_ARG, "osn_spconv_wgrad: bad arguments");
+    const int64_t wtotal = int64_t(K) * cin * cout;
+    if (n_out == 0) {
+        OSN_HIP(hipMemsetAsync(gW, 0, size_t(wtotal) * 4, st));
+        return OSN_OK;
+    }
+    OSN_REQUIRE(in && gout, OSN_E_ARG, "osn_spconv_wgrad: null pointer");
+    OSN_REQUIRE(nbr || K == 1, OSN_E_ARG, "osn_spconv_wgrad: nbr may be null only for K == 1");
+    OSN_REQUIRE(aligned16(in) && aligned16(gout) && aligned16(gW), OSN_E_ARG, "osn_spconv_wgrad: pointers must be 16-byte aligned");
+    WgradPlan p = plan_wgrad(n_out, K, cin, cout);
+    float* dst = gW;
+    if (p.S > 1) {
+        const size_t need = size_t(p.S) * size_t(wtotal) * 4;
+        OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_spconv_wgrad: workspace %zu < %zu", ws_bytes, need);
+        dst = static_cast<float*>(ws);
+    }
+    hipLaunchKernelGGL(spconv_wgrad_kernel, dim3(p.n_ci * p.n_co, p.S, K), dim3(256), 0, st, in, gout, nbr, dst,
+                       int(n_out), K, cin, cout, p.rps, p.n_co);
+    OSN_LAUNCH_CHECK();
+    if (p.S > 1) {
+        int g = int(cdiv(wtotal, 256));
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(reduce_partial_flat_kernel, dim3(g), dim3(256), 0, st, dst, p.S, wtotal, gW);
+        OSN_LAUNCH_CHECK();
+    }
+    return OSN_OK;
+}

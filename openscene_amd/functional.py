@@ -1,0 +1,82 @@
+"""Autograd glue: each Function's forward/backward is one or two C-ABI calls on
+the current HIP stream (backward runs on autograd's thread; the library is
+stateless so that is safe)."""
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+class SparseConvFunction(Function):
+    """out[o] = sum_k feats[nbr_fwd[k, o]] @ kernel[k]  ([ME] MinkowskiConvolutionFunction /
+    MinkowskiConvolutionTransposeFunction).  kernel: [K, cin, cout], or [cin, cout] when K == 1."""
+
+    @staticmethod
+    def forward(ctx, feats, kernel, nbr_fwd, nbr_bwd, flip, n_out):
+        ctx.save_for_backward(feats, kernel)
+        ctx.maps = (nbr_fwd, nbr_bwd, bool(flip))
+        ctx.n_in = feats.shape[0]
+        return ops.spconv_fwd(feats, kernel, nbr_fwd, n_out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        feats, kernel = ctx.saved_tensors
+        nbr_fwd, nbr_bwd, flip = ctx.maps
+        gout = gout.contiguous()
+        gin = gk = None
+        K = 1 if kernel.dim() == 2 else kernel.shape[0]
+        if ctx.needs_input_grad[0]:
+            wt = ops.weight_transpose(kernel, flip)
+            gin = ops.spconv_fwd(gout, wt, nbr_bwd, ctx.n_in)
+        if ctx.needs_input_grad[1]:
+            gk = ops.spconv_wgrad(feats, gout, nbr_fwd, K).reshape(kernel.shape)
+        return gin, gk, None, None, None, None
+
+
+class BatchNormActFunction(Function):
+    """y = act(BN(x) [+ residual]) in one pass over x; batch statistics in training
+    (running buffers updated in place like torch.nn.BatchNorm1d), running statistics in eval."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu):
+        x = x.contiguous()
+        if training:
+            mean, var = ops.bn_stats(x, running_mean, running_var, momentum)
+        else:
+            mean, var = running_mean, running_var
+        y = ops.bn_apply(x, mean, var, gamma, beta, eps, residual, relu)
+        ctx.save_for_backward(x, y if relu else None, mean, var, gamma)
+        ctx.cfg = (bool(training), float(eps), bool(relu), residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, mean, var, gamma = ctx.saved_tensors
+        training, eps, relu, has_res = ctx.cfg
+        want_gres = has_res and ctx.needs_input_grad[5]
+        gx, gres, ggamma, gbeta = ops.bn_backward(x, y, gy.contiguous(), mean, var, gamma, eps, relu, training,
+                                                  want_gres)
+        return gx, ggamma, gbeta, None, None, gres, None, None, None, None
+
+
+def sparse_conv(feats, kernel, maps, n_out):
+    nbr_fwd, nbr_bwd, flip = maps
+    return SparseConvFunction.apply(feats, kernel, nbr_fwd, nbr_bwd, flip, n_out)
+
+
+def batch_norm_act(x, bn, residual=None, relu=False):
+    """`bn` is a torch.nn.BatchNorm1d (the `.bn` of MinkowskiBatchNorm): same parameters,
+    buffers and train/eval semantics, computed by the HIP kernels."""
+    training = bn.training or (bn.running_mean is None)
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    if not training and rm is None:
+        raise RuntimeError("eval-mode batch norm needs running statistics")
+    gamma = bn.weight if bn.weight is not None else torch.ones(bn.num_features, device=x.device)
+    beta = bn.bias if bn.bias is not None else torch.zeros(bn.num_features, device=x.device)
+    return BatchNormActFunction.apply(x, gamma, beta, rm, rv, residual, training, momentum, bn.eps, relu)

@@ -1,0 +1,321 @@
+"""Tensor-level wrappers over the C ABI: allocate outputs / scratch with torch,
+pass raw device pointers and the current HIP stream.  No autograd here (see
+functional.py) and no CPU fallback."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+_vp = ctypes.c_void_p
+
+
+def _p(t):
+    return _vp(t.data_ptr()) if t is not None else None
+
+
+def _stream(dev):
+    return _vp(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _ws(nbytes, dev):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+
+
+def _prep(dev):
+    _lib.require_device(dev)
+    return _lib.load()
+
+
+class _Dev:
+    """Make `dev` the current HIP device for the duration of a call if it is not already."""
+
+    def __init__(self, dev):
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.ctx = None if idx == torch.cuda.current_device() else torch.cuda.device(idx)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------- coordinates
+class HashTable:
+    """Open-addressing table keys[cap] u64 / vals[cap] i32 living in HBM."""
+    __slots__ = ("keys", "vals", "cap")
+
+    def __init__(self, n, dev):
+        self.cap = int(_lib.load().osn_hash_capacity(int(n)))
+        self.keys = torch.empty(self.cap, dtype=torch.int64, device=dev)
+        self.vals = torch.empty(self.cap, dtype=torch.int32, device=dev)
+
+
+def coords_unique(coords4, stride=1):
+    """-> (unique coords [U,4] int32 in first-occurrence order, inverse [N] int32,
+    first [U] int32, HashTable mapping packed key -> unique row)."""
+    if coords4.dtype != torch.int32 or coords4.dim() != 2 or coords4.shape[1] != 4:
+        raise TypeError("coordinates must be int32 [N, 4] rows (batch, x, y, z)")
+    dev = coords4.device
+    lib = _prep(dev)
+    coords4 = coords4.contiguous()
+    n = coords4.shape[0]
+    table = HashTable(n, dev)
+    out = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
+    inverse = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    first = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    wsb = lib.osn_coords_unique_ws_bytes(n)
+    ws = _ws(wsb, dev)
+    nu = ctypes.c_int64(0)
+    with _Dev(dev):
+        check(lib.osn_coords_unique(_p(coords4), n, int(stride), _p(table.keys), _p(table.vals), table.cap,
+                                    _p(out), _p(inverse), _p(first), ctypes.byref(nu), _p(ws), ws.numel(),
+                                    _stream(dev)), "osn_coords_unique")
+    u = int(nu.value)
+    return out[:u], inverse[:n], first[:u], table
+
+
+def kmap_build(table, out_coords4, ksize, offset_scale):
+    dev = out_coords4.device
+    lib = _prep(dev)
+    out_coords4 = out_coords4.contiguous()
+    n_out = out_coords4.shape[0]
+    K = ksize ** 3
+    nbr = torch.empty((K, n_out), dtype=torch.int32, device=dev)
+    with _Dev(dev):
+        check(lib.osn_kmap_build(_p(table.keys), _p(table.vals), table.cap, _p(out_coords4), n_out, int(ksize),
+                                 int(offset_scale), _p(nbr), _stream(dev)), "osn_kmap_build")
+    return nbr
+
+
+def kmap_transpose(nbr, n_in):
+    dev = nbr.device
+    lib = _prep(dev)
+    K, n_out = nbr.shape
+    tbl = torch.empty((K, int(n_in)), dtype=torch.int32, device=dev)
+    with _Dev(dev):
+        check(lib.osn_kmap_transpose(_p(nbr), n_out, K, int(n_in), _p(tbl), _stream(dev)), "osn_kmap_transpose")
+    return tbl
+
+
+def kmap_count(nbr):
+    dev = nbr.device
+    lib = _prep(dev)
+    K, n_out = nbr.shape
+    counts = torch.empty(K, dtype=torch.int64, device=dev)
+    with _Dev(dev):
+        check(lib.osn_kmap_count(_p(nbr), n_out, K, _p(counts), _stream(dev)), "osn_kmap_count")
+    return counts
+
+
+# ----------------------------------------------------------------- convolution
+def _w3(weight):
+    return weight.unsqueeze(0) if weight.dim() == 2 else weight
+
+
+def spconv_fwd(feats, weight, nbr, n_out, out_rows=None):
+    """out[o] = sum_k feats[nbr[k,o]] @ weight[k].  nbr None <=> K == 1 identity map."""
+    dev = feats.device
+    lib = _prep(dev)
+    feats = _f32c(feats, "features")
+    w = _f32c(_w3(weight), "weight")
+    K, cin, cout = w.shape
+    if feats.shape[1] != cin:
+        raise ValueError("features have %d channels, kernel expects %d" % (feats.shape[1], cin))
+    if nbr is not None:
+        if nbr.dtype != torch.int32 or nbr.shape != (K, n_out):
+            raise ValueError("nbr must be int32 [%d, %d], got %s %s" % (K, n_out, nbr.dtype, tuple(nbr.shape)))
+        nbr = nbr.contiguous()
+    elif K != 1 or feats.shape[0] != n_out:
+        raise ValueError("nbr=None is the identity map and needs K == 1 and n_in == n_out")
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    wsb = lib.osn_spconv_fwd_ws_bytes(n_out, K, cin, cout)
+    ws = _ws(wsb, dev) if wsb else None
+    with _Dev(dev):
+        check(lib.osn_spconv_fwd(_p(feats), _p(w), _p(nbr), _p(out_rows), _p(out), n_out, K, cin, cout, _p(ws),
+                                 int(wsb), _stream(dev)), "osn_spconv_fwd")
+    return out
+
+
+def weight_transpose(weight, flip):
+    dev = weight.device
+    lib = _prep(dev)
+    w = _f32c(_w3(weight), "weight")
+    K, cin, cout = w.shape
+    wt = torch.empty((K, cout, cin), dtype=torch.float32, device=dev)
+    with _Dev(dev):
+        check(lib.osn_weight_transpose(_p(w), K, cin, cout, int(bool(flip)), _p(wt), _stream(dev)),
+              "osn_weight_transpose")
+    return wt
+
+
+def spconv_wgrad(feats, gout, nbr, K):
+    dev = feats.device
+    lib = _prep(dev)
+    feats = _f32c(feats, "features")
+    gout = _f32c(gout, "grad_output")
+    n_out, cout = gout.shape
+    cin = feats.shape[1]
+    if nbr is not None:
+        nbr = nbr.contiguous()
+        if nbr.shape != (K, n_out):
+            raise ValueError("nbr shape %s does not match (K=%d, n_out=%d)" % (tuple(nbr.shape), K, n_out))
+    gw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
+    wsb = lib.osn_spconv_wgrad_ws_bytes(n_out, K, cin, cout)
+    ws = _ws(wsb, dev) if wsb else None
+    with _Dev(dev):
+        check(lib.osn_spconv_wgrad(_p(feats), _p(gout), _p(nbr), _p(gw), n_out, K, cin, cout, _p(ws), int(wsb),
+                                   _stream(dev)), "osn_spconv_wgrad")
+    return gw
+
+
+# ------------------------------------------------------------------ batch norm
+def bn_stats(x, running_mean=None, running_var=None, momentum=0.1):
+    dev = x.device
+    lib = _prep(dev)
+    x = _f32c(x, "x")
+    n, c = x.shape
+    mean = torch.empty(c, dtype=torch.float32, device=dev)
+    var = torch.empty(c, dtype=torch.float32, device=dev)
+    wsb = lib.osn_bn_ws_bytes(n, c)
+    ws = _ws(wsb, dev)
+    with _Dev(dev):
+        check(lib.osn_bn_stats(_p(x), n, c, _p(mean), _p(var), _p(running_mean), _p(running_var), float(momentum),
+                               _p(ws), ws.numel(), _stream(dev)), "osn_bn_stats")
+    return mean, var
+
+
+def bn_apply(x, mean, var, gamma, beta, eps, residual=None, relu=False):
+    dev = x.device
+    lib = _prep(dev)
+    x = _f32c(x, "x")
+    n, c = x.shape
+    if residual is not None:
+        residual = _f32c(residual, "residual")
+        if residual.shape != x.shape:
+            raise ValueError("residual shape %s != %s" % (tuple(residual.shape), tuple(x.shape)))
+    y = torch.empty_like(x)
+    with _Dev(dev):
+        check(lib.osn_bn_apply(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), float(eps), _p(residual), int(bool(relu)),
+                               _p(y), n, c, _stream(dev)), "osn_bn_apply")
+    return y
+
+
+def bn_backward(x, y, gy, mean, var, gamma, eps, relu, training, want_gres):
+    dev = x.device
+    lib = _prep(dev)
+    gy = _f32c(gy, "grad_output")
+    n, c = x.shape
+    gx = torch.empty_like(x)
+    gres = torch.empty_like(x) if want_gres else None
+    ggamma = torch.empty(c, dtype=torch.float32, device=dev)
+    gbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    wsb = lib.osn_bn_ws_bytes(n, c)
+    ws = _ws(wsb, dev)
+    with _Dev(dev):
+        check(lib.osn_bn_backward(_p(x), _p(y), _p(gy), _p(mean), _p(var), _p(gamma), float(eps), int(bool(relu)),
+                                  int(bool(training)), _p(gx), _p(gres), _p(ggamma), _p(gbeta), n, c, _p(ws),
+                                  ws.numel(), _stream(dev)), "osn_bn_backward")
+    return gx, gres, ggamma, gbeta
+
+
+# ----------------------------------------------------------------------- query
+def cosine_query(feats, text_half, gather=None, want_scores=True):
+    """(scores fp16 [n, C] or None, argmax int64 [n]) of feats[gather].half() @ text.t()."""
+    dev = feats.device
+    lib = _prep(dev)
+    feats = _f32c(feats, "features")
+    if text_half.dtype != torch.float16:
+        raise TypeError("text features must be float16 (util/util.py:41-44 produces fp16)")
+    text_half = text_half.contiguous()
+    c, d = text_half.shape
+    if feats.shape[1] != d:
+        raise ValueError("feature dim %d != text dim %d" % (feats.shape[1], d))
+    if gather is not None:
+        if gather.dtype != torch.int64:
+            gather = gather.long()
+        gather = gather.contiguous()
+        n = gather.shape[0]
+    else:
+        n = feats.shape[0]
+    scores = torch.empty((n, c), dtype=torch.float16, device=dev) if want_scores else None
+    amax = torch.empty(n, dtype=torch.int64, device=dev)
+    with _Dev(dev):
+        check(lib.osn_cosine_query(_p(feats), _p(gather), _p(text_half), _p(scores), _p(amax), n, d, c, _stream(dev)),
+              "osn_cosine_query")
+    return scores, amax
+
+
+def query_ensemble(feat_distill, feat_fusion, text_half, gather_distill=None, gather_fusion=None, want_scores=True):
+    dev = feat_distill.device
+    lib = _prep(dev)
+    fd = _f32c(feat_distill, "distill features")
+    ff = _f32c(feat_fusion, "fusion features")
+    text_half = text_half.contiguous()
+    c, d = text_half.shape
+
+    def _g(g):
+        if g is None:
+            return None
+        return (g if g.dtype == torch.int64 else g.long()).contiguous()
+
+    gd, gf = _g(gather_distill), _g(gather_fusion)
+    n = gd.shape[0] if gd is not None else fd.shape[0]
+    nf = gf.shape[0] if gf is not None else ff.shape[0]
+    if n != nf:
+        raise ValueError("the two feature sources address %d vs %d points" % (n, nf))
+    scores = torch.empty((n, c), dtype=torch.float16, device=dev) if want_scores else None
+    amax = torch.empty(n, dtype=torch.int64, device=dev)
+    sel = torch.empty(n, dtype=torch.uint8, device=dev)
+    wsb = lib.osn_query_ensemble_ws_bytes(n)
+    ws = _ws(wsb, dev)
+    with _Dev(dev):
+        check(lib.osn_query_ensemble(_p(fd), _p(gd), _p(ff), _p(gf), _p(text_half), _p(scores), _p(amax), _p(sel), n,
+                                     d, c, _p(ws), ws.numel(), _stream(dev)), "osn_query_ensemble")
+    return scores, amax, sel.bool()
+
+
+# ------------------------------------------------------------------- voxelizer
+def voxelize_fnv(xyz, T):
+    """xyz float64 [N,3] (device), T 4x4 float64 (host, numpy or tensor) ->
+    (grid float64 [N,3] shifted integral coords, inds int64 [Nv], inverse int64 [N])."""
+    import numpy as np
+    dev = xyz.device
+    lib = _prep(dev)
+    if xyz.dtype != torch.float64:
+        raise TypeError("xyz must be float64 (the reference voxelises in float64)")
+    xyz = xyz.contiguous()
+    n = xyz.shape[0]
+    T = np.ascontiguousarray(np.asarray(T, dtype=np.float64))
+    t12 = (ctypes.c_double * 12)(*T[:3, :].reshape(-1).tolist())
+    grid = torch.empty((max(n, 1), 3), dtype=torch.float64, device=dev)
+    inds = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    inverse = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    with _Dev(dev):
+        wsb = lib.osn_voxelize_ws_bytes(n)
+        ws = _ws(wsb, dev)
+        nv = ctypes.c_int64(0)
+        check(lib.osn_voxelize_fnv(_p(xyz), n, t12, _p(grid), _p(inds), _p(inverse), ctypes.byref(nv), _p(ws),
+                                   ws.numel(), _stream(dev)), "osn_voxelize_fnv")
+    return grid[:n], inds[:int(nv.value)], inverse[:n]
+
+
+def fnv_hash(grid):
+    dev = grid.device
+    lib = _prep(dev)
+    grid = grid.to(torch.float64).contiguous()
+    n, ncol = grid.shape
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    with _Dev(dev):
+        check(lib.osn_fnv_hash(_p(grid), n, ncol, _p(keys), _stream(dev)), "osn_fnv_hash")
+    return keys

@@ -1,0 +1,176 @@
+"""SparseTensor and its per-tensor coordinate manager (GPU resident).
+
+Mirrors the slice of MinkowskiEngine's API the reference touches
+(``from MinkowskiEngine import SparseTensor`` -- run/distill.py:18,316-317;
+run/evaluate.py:18,284; models/mink_unet.py:116-174 use ``.F``, ``ME.cat``
+and ``+=``).  Semantics restated in SURVEY.md appendix C items 1-4:
+
+  * a new CoordinateManager per SparseTensor (maps are rebuilt every forward);
+  * unique coordinates keep the caller's row order;
+  * stride-2 convs create floor(c / 2s) * 2s coarse maps (cached);
+  * transposed convs land on the cached finer map, so decoder outputs are
+    row-aligned with encoder skips.
+"""
+import torch
+
+from . import ops
+
+
+class CoordinateManager:
+    """Caches, per tensor stride, the coordinate rows + hash table, and per
+    (in stride, out stride, kernel size, dilation) the k-major neighbour tables."""
+
+    def __init__(self, coordinates):
+        coords, inverse, first, table = ops.coords_unique(coordinates, 1)
+        self.n_input = coordinates.shape[0]
+        self.unique_index = None          # rows kept if the caller passed duplicates
+        self.inverse_mapping = None
+        if coords.shape[0] != coordinates.shape[0]:
+            self.unique_index = first.long()
+            self.inverse_mapping = inverse.long()
+        else:
+            coords = coordinates.contiguous()     # identical rows, caller's own storage order
+        self._coords = {1: coords}
+        self._tables = {1: table}
+        self._parent = {}
+        self._kmaps = {}
+        self.device = coordinates.device
+
+    # -- coordinate maps ----------------------------------------------------
+    def coords(self, stride):
+        if stride not in self._coords:
+            if stride < 2 or stride % 2:
+                raise ValueError("tensor stride %r was never created on this manager" % (stride,))
+            fine = self.coords(stride // 2)
+            c, parent, _first, table = ops.coords_unique(fine, stride)
+            self._coords[stride] = c
+            self._tables[stride] = table
+            self._parent[stride] = parent
+        return self._coords[stride]
+
+    def size(self, stride):
+        return self.coords(stride).shape[0]
+
+    def parent(self, stride):
+        """int32 [N_{stride/2}] : row of the stride-`stride` voxel containing each finer voxel."""
+        self.coords(stride)
+        return self._parent[stride]
+
+    def has(self, stride):
+        return stride in self._coords
+
+    # -- kernel maps ---------------------------------------------------------
+    def kmap(self, in_stride, out_stride, ksize, dilation=1):
+        """(nbr_fwd, nbr_bwd, flip).  nbr_fwd [K, N_out] feeds the forward conv;
+        the input gradient is a forward conv of grad_out over nbr_bwd with the
+        kernel transposed (and mirrored in k if flip)."""
+        key = (in_stride, out_stride, ksize, dilation)
+        hit = self._kmaps.get(key)
+        if hit is not None:
+            return hit
+        if ksize == 1 and in_stride == out_stride:
+            res = (None, None, False)
+        elif in_stride == out_stride:
+            self.coords(in_stride)
+            nbr = ops.kmap_build(self._tables[in_stride], self._coords[in_stride], ksize, dilation * in_stride)
+            if ksize % 2 == 1:
+                res = (nbr, nbr, True)            # the map of an odd stride-1 kernel is its own mirror
+            else:
+                res = (nbr, ops.kmap_transpose(nbr, self.size(in_stride)), False)
+        elif out_stride > in_stride:              # strided conv: fine -> coarse
+            out_c = self.coords(out_stride)
+            nbr = ops.kmap_build(self._tables[in_stride], out_c, ksize, dilation * in_stride)
+            res = (nbr, ops.kmap_transpose(nbr, self.size(in_stride)), False)
+        else:                                     # transposed conv: swap the fine -> coarse map
+            down_fwd, down_bwd, _ = self.kmap(out_stride, in_stride, ksize, dilation)
+            res = (down_bwd, down_fwd, False)
+        self._kmaps[key] = res
+        return res
+
+
+class SparseTensor:
+    """features float32 [N, C] + int32 coordinates [N, 4] (batch, x, y, z) on one device."""
+
+    def __init__(self, features, coordinates=None, tensor_stride=1, coordinate_manager=None, **unused):
+        if coordinate_manager is None:
+            if coordinates is None:
+                raise ValueError("SparseTensor needs coordinates or a coordinate_manager")
+            if coordinates.dtype != torch.int32:
+                coordinates = coordinates.int()
+            if coordinates.device != features.device:
+                raise ValueError("features on %s but coordinates on %s" % (features.device, coordinates.device))
+            if coordinates.shape[0] != features.shape[0]:
+                raise ValueError("%d feature rows vs %d coordinate rows" % (features.shape[0], coordinates.shape[0]))
+            coordinate_manager = CoordinateManager(coordinates)
+            if coordinate_manager.unique_index is not None:
+                features = features[coordinate_manager.unique_index]
+        self._F = features
+        self.tensor_stride = tensor_stride
+        self.coordinate_manager = coordinate_manager
+
+    # ME names
+    @property
+    def F(self):
+        return self._F
+
+    @property
+    def C(self):
+        return self.coordinate_manager.coords(self.tensor_stride)
+
+    features = F
+    coordinates = C
+
+    @property
+    def device(self):
+        return self._F.device
+
+    @property
+    def shape(self):
+        return self._F.shape
+
+    @property
+    def dtype(self):
+        return self._F.dtype
+
+    def size(self, *a):
+        return self._F.size(*a)
+
+    def __len__(self):
+        return self._F.shape[0]
+
+    def _like(self, feats):
+        return SparseTensor(feats, tensor_stride=self.tensor_stride, coordinate_manager=self.coordinate_manager)
+
+    def _same_map(self, other):
+        if other.coordinate_manager is not self.coordinate_manager or other.tensor_stride != self.tensor_stride:
+            raise ValueError("SparseTensors live on different coordinate maps")
+
+    def __add__(self, other):
+        if isinstance(other, SparseTensor):
+            self._same_map(other)
+            return self._like(self._F + other._F)
+        return self._like(self._F + other)
+
+    def __iadd__(self, other):
+        # the reference's residual `out += residual`; out-of-place on the feature
+        # matrix so autograd never sees an in-place edit of a saved tensor
+        if isinstance(other, SparseTensor):
+            self._same_map(other)
+            self._F = self._F + other._F
+        else:
+            self._F = self._F + other
+        return self
+
+    def __repr__(self):
+        return "SparseTensor(N=%d, C=%d, tensor_stride=%d, device=%s)" % (
+            self._F.shape[0], self._F.shape[1], self.tensor_stride, self._F.device)
+
+
+def cat(*tensors):
+    """ME.cat: column concat of tensors on the same coordinate map (models/mink_unet.py:147,155,163,171)."""
+    if len(tensors) == 1 and isinstance(tensors[0], (list, tuple)):
+        tensors = tuple(tensors[0])
+    first = tensors[0]
+    for t in tensors[1:]:
+        first._same_map(t)
+    return first._like(torch.cat([t.F for t in tensors], dim=1))

@@ -1,0 +1,163 @@
+"""TEST INFRASTRUCTURE: a CPU restatement of every op in ``openscene_amd.ops`` built on
+``oracle/`` + plain torch, with the same signatures and return conventions.
+
+Two uses, both inside tests/ only:
+  * the checker of the ``-m gpu`` parity tests (HIP op vs this, same inputs);
+  * ``install(monkeypatch)`` swaps it in for ``openscene_amd.ops`` so the HOST logic
+    (coordinate manager, autograd wiring, module tree, DDP) can be exercised without a
+    GPU.  The product package never imports this file and has no hook for it.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import coords as oc
+from oracle import query as oq
+from oracle import sparse_ops as so
+from oracle import voxelize as ov
+
+
+class HashTable:
+    def __init__(self, coords4):
+        self.coords4 = np.asarray(coords4)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def coords_unique(coords4, stride=1):
+    c = _np(coords4).astype(np.int32)
+    q = oc.floor_to_stride(c, stride) if stride > 1 else c
+    if q.shape[0] == 0:
+        z = torch.zeros(0, dtype=torch.int32)
+        return torch.zeros((0, 4), dtype=torch.int32), z, z.clone(), HashTable(q)
+    uniq, inv, first = oc.unique_first(q)
+    return (torch.from_numpy(uniq.astype(np.int32)), torch.from_numpy(inv.astype(np.int32)),
+            torch.from_numpy(first.astype(np.int32)), HashTable(uniq))
+
+
+def kmap_build(table, out_coords4, ksize, offset_scale):
+    # kernel_offsets(ksize, tensor_stride) scales by the tensor stride; dilation folded into offset_scale
+    off = oc.kernel_offsets(ksize, offset_scale)
+    return torch.from_numpy(oc.kernel_map(table.coords4, _np(out_coords4), off))
+
+
+def kmap_transpose(nbr, n_in):
+    return torch.from_numpy(oc.transpose_table(_np(nbr), int(n_in)))
+
+
+def kmap_count(nbr):
+    return (nbr >= 0).sum(1).long()
+
+
+def _w3(w):
+    return w.unsqueeze(0) if w.dim() == 2 else w
+
+
+def spconv_fwd(feats, weight, nbr, n_out, out_rows=None):
+    w = _w3(weight)
+    if nbr is None:
+        nbr = torch.arange(n_out, dtype=torch.int32)[None]
+    out = so.sparse_conv(feats, w, _np(nbr))
+    if out_rows is not None:
+        res = torch.zeros_like(out)
+        res[out_rows.long()] = out
+        out = res
+    return out
+
+
+def weight_transpose(weight, flip):
+    w = _w3(weight)
+    if flip:
+        w = torch.flip(w, dims=[0])
+    return w.transpose(1, 2).contiguous()
+
+
+def spconv_wgrad(feats, gout, nbr, K):
+    n_out = gout.shape[0]
+    if nbr is None:
+        nbr = torch.arange(n_out, dtype=torch.int32)[None]
+    nbr = nbr.long()
+    gw = feats.new_zeros((K, feats.shape[1], gout.shape[1]))
+    for k in range(K):
+        o = torch.nonzero(nbr[k] >= 0).reshape(-1)
+        if o.numel():
+            gw[k] = feats[nbr[k][o]].t() @ gout[o]
+    return gw
+
+
+def bn_stats(x, running_mean=None, running_var=None, momentum=0.1):
+    n = x.shape[0]
+    mean = x.mean(0)
+    var = x.var(0, unbiased=False)
+    with torch.no_grad():
+        if running_mean is not None:
+            running_mean.mul_(1 - momentum).add_(momentum * mean)
+        if running_var is not None:
+            unb = var * n / (n - 1) if n > 1 else var
+            running_var.mul_(1 - momentum).add_(momentum * unb)
+    return mean, var
+
+
+def bn_apply(x, mean, var, gamma, beta, eps, residual=None, relu=False):
+    y = (x - mean) * torch.rsqrt(var + eps) * gamma + beta
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+def bn_backward(x, y, gy, mean, var, gamma, eps, relu, training, want_gres):
+    g = gy * (y > 0).to(gy.dtype) if relu else gy
+    invstd = torch.rsqrt(var + eps)
+    xhat = (x - mean) * invstd
+    sg, sgx = g.sum(0), (g * xhat).sum(0)
+    n = x.shape[0]
+    if training:
+        gx = gamma * invstd * (g - sg / n - xhat * sgx / n)
+    else:
+        gx = gamma * invstd * g
+    return gx, (g.clone() if want_gres else None), sgx, sg
+
+
+def cosine_query(feats, text_half, gather=None, want_scores=True):
+    scores, amax = oq.query(feats, text_half, gather)
+    return (scores if want_scores else None), amax
+
+
+def query_ensemble(feat_distill, feat_fusion, text_half, gather_distill=None, gather_fusion=None, want_scores=True):
+    fd = feat_distill if gather_distill is None else feat_distill[gather_distill]
+    ff = feat_fusion if gather_fusion is None else feat_fusion[gather_fusion]
+    scores, amax, ens = oq.query_ensemble(fd, ff, text_half)
+    pf = oq.half_matmul((ff / (ff.norm(dim=-1, keepdim=True) + 1e-5)).half(), text_half)
+    pd = oq.half_matmul((fd / (fd.norm(dim=-1, keepdim=True) + 1e-5)).half(), text_half)
+    sel = pd.max(dim=-1)[0] < pf.max(dim=-1)[0]
+    return (scores if want_scores else None), amax, sel
+
+
+def voxelize_fnv(xyz, T):
+    T = np.asarray(T, dtype=np.float64)
+    x = _np(xyz)
+    homo = np.hstack((x, np.ones((x.shape[0], 1))))
+    grid = np.floor(homo @ T.T[:, :3])
+    grid = np.floor(grid - grid.min(0))
+    inds, inverse = ov.quantize_first_occurrence(grid)
+    return torch.from_numpy(grid), torch.from_numpy(inds), torch.from_numpy(inverse)
+
+
+def fnv_hash(grid):
+    return torch.from_numpy(ov.fnv_keys(_np(grid)).view(np.int64))
+
+
+_NAMES = ["HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_count", "spconv_fwd", "weight_transpose",
+          "spconv_wgrad", "bn_stats", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
+          "fnv_hash"]
+
+
+def install(monkeypatch):
+    """Swap the CPU restatement in for openscene_amd.ops (host-logic tests only)."""
+    import openscene_amd.ops as ops
+    import sys
+    me = sys.modules[__name__]
+    for n in _NAMES:
+        monkeypatch.setattr(ops, n, getattr(me, n))
