@@ -1,0 +1,125 @@
+"""HIP coordinate / kernel maps vs the oracle -- bit-exact (integer work)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import coords as oc
+from openscene_amd import synthetic as syn
+
+import cpu_backend
+
+pytestmark = pytest.mark.gpu
+
+S100K_LEVELS = [100999, 47618, 12868, 3052, 700]
+S100K_PAIRS27 = [535643, 439572, 134680, 34704, 8630]
+S100K_PAIRS125 = 1407639
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def random_cloud(seed, n, extent, batch=1, lo=0):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for b in range(batch):
+        g = np.unique(rng.integers(lo, lo + extent, (n, 3)), axis=0)
+        g = g[rng.permutation(g.shape[0])]
+        rows.append(np.concatenate([np.full((g.shape[0], 1), b), g], 1))
+    return np.concatenate(rows, 0).astype(np.int32)
+
+
+def s100k():
+    v = syn.shuffled(syn.grid_voxels(syn.room_points(0), 0.02), 0)
+    return syn.batch_coords([v])
+
+
+def test_unique_rows_keep_caller_order():
+    from openscene_amd import ops
+    c = random_cloud(0, 5000, 40, batch=2, lo=-7)
+    out, inv, first, table = ops.coords_unique(torch.from_numpy(c).to(dev()), 1)
+    assert out.shape[0] == c.shape[0]
+    assert np.array_equal(out.cpu().numpy(), c)
+    assert np.array_equal(inv.cpu().numpy(), np.arange(c.shape[0]))
+    assert np.array_equal(first.cpu().numpy(), np.arange(c.shape[0]))
+
+
+def test_duplicates_first_occurrence_order():
+    from openscene_amd import ops
+    rng = np.random.default_rng(1)
+    c = random_cloud(1, 3000, 12, batch=2)
+    c = c[rng.integers(0, c.shape[0], 9000)]                      # heavy duplication, random order
+    t = torch.from_numpy(c)
+    want = cpu_backend.coords_unique(t, 1)
+    got = ops.coords_unique(t.to(dev()), 1)
+    for w, g in zip(want[:3], got[:3]):
+        assert np.array_equal(w.numpy(), g.cpu().numpy())
+
+
+@pytest.mark.parametrize("case", ["random_neg", "room"])
+def test_stride_pyramid_and_kernel_maps(case):
+    from openscene_amd.sparse import CoordinateManager
+    if case == "random_neg":
+        c = random_cloud(2, 6000, 48, batch=2, lo=-20)
+    else:
+        c = syn.batch_coords([syn.shuffled(syn.grid_voxels(syn.room_points(1, n_pts=30000), 0.05), 1),
+                              syn.shuffled(syn.grid_voxels(syn.room_points(2, n_pts=20000), 0.05), 2)])
+    ref = oc.CoordinateManager(c)
+    cm = CoordinateManager(torch.from_numpy(c).to(dev()))
+    for s in (2, 4, 8, 16):
+        assert np.array_equal(cm.coords(s).cpu().numpy(), ref.level(s)), "coords stride %d" % s
+        assert np.array_equal(cm.parent(s).cpu().numpy(), ref.parent[s]), "parent stride %d" % s
+    for (si, so_, k) in [(1, 1, 3), (1, 1, 5), (2, 2, 3), (4, 4, 3), (8, 8, 3), (16, 16, 3),
+                         (1, 2, 2), (2, 4, 2), (4, 8, 2), (8, 16, 2), (2, 1, 2), (16, 8, 2)]:
+        fwd, bwd, flip = cm.kmap(si, so_, k)
+        want = ref.kmap(si, so_, k)
+        assert np.array_equal(fwd.cpu().numpy(), want), "kmap %s" % ((si, so_, k),)
+        # the table used for the input gradient is the transposed operator's map
+        want_t = oc.transpose_table(want, ref.level(si).shape[0])
+        got_t = bwd.cpu().numpy()[::-1] if flip else bwd.cpu().numpy()
+        assert np.array_equal(got_t, want_t), "transposed kmap %s" % ((si, so_, k),)
+    assert cm.kmap(1, 1, 1) == (None, None, False)
+
+
+def test_s100k_full_size_properties():
+    """Full BASELINE size: level sizes / pair counts of the canonical scene + structural properties."""
+    from openscene_amd import ops
+    from openscene_amd.sparse import CoordinateManager
+    c = s100k()
+    cm = CoordinateManager(torch.from_numpy(c).to(dev()))
+    sizes = [cm.size(s) for s in (1, 2, 4, 8, 16)]
+    assert sizes == S100K_LEVELS
+    for lvl, s in enumerate((1, 2, 4, 8, 16)):
+        nbr, _, _ = cm.kmap(s, s, 3)
+        cnt = ops.kmap_count(nbr).cpu().numpy()
+        assert int(cnt.sum()) == S100K_PAIRS27[lvl]
+        assert int(cnt[13]) == sizes[lvl]                              # centre offset: every voxel sees itself
+        assert np.array_equal(cnt, cnt[::-1])                          # (i,o) in map_k <=> (o,i) in map_{K-1-k}
+        t = ops.kmap_transpose(nbr, sizes[lvl])
+        assert torch.equal(t, torch.flip(nbr, dims=[0]))
+        assert torch.equal(nbr[13], torch.arange(sizes[lvl], dtype=torch.int32, device=nbr.device))
+    nbr5, _, _ = cm.kmap(1, 1, 5)
+    assert int(ops.kmap_count(nbr5).sum()) == S100K_PAIRS125
+    for s in (1, 2, 4, 8):                                             # k2s2: exactly one parent per fine voxel
+        down, up, _ = cm.kmap(s, 2 * s, 2)
+        assert int(ops.kmap_count(down).sum()) == cm.size(s)
+        assert torch.all((up >= 0).sum(0) == 1)
+        par = cm.parent(2 * s).long()
+        assert torch.equal(up.max(0)[0].long(), par)
+    # bit-exact against the oracle at full size for the two biggest tables
+    ref = oc.CoordinateManager(c)
+    assert np.array_equal(cm.kmap(1, 1, 3)[0].cpu().numpy(), ref.kmap(1, 1, 3))
+    assert np.array_equal(cm.coords(2).cpu().numpy(), ref.level(2))
+
+
+def test_determinism_and_empty_and_range():
+    from openscene_amd import ops, _lib
+    c = torch.from_numpy(random_cloud(3, 20000, 64, batch=3)).to(dev())
+    a = ops.coords_unique(c, 4)
+    b = ops.coords_unique(c, 4)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    e = ops.coords_unique(torch.zeros((0, 4), dtype=torch.int32, device=dev()), 1)
+    assert e[0].shape == (0, 4) and e[1].shape == (0,)
+    bad = torch.tensor([[0, 1, 2, 3], [0, 40000, 0, 0]], dtype=torch.int32, device=dev())
+    with pytest.raises(_lib.OpenSceneAmdError):
+        ops.coords_unique(bad, 1)

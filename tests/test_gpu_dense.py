@@ -1,0 +1,201 @@
+"""HIP batch-norm (+ReLU +residual), open-vocabulary query and voxeliser vs their
+oracles.  Tolerances are stated next to each check."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import query as oq
+from oracle import voxelize as ov
+
+import cpu_backend
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def rel(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+
+
+# ------------------------------------------------------------------ batch norm
+@pytest.mark.parametrize("n,c", [(1, 32), (7, 64), (700, 256), (3052, 128), (47618, 96), (100999, 32), (5000, 768)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
+def test_batchnorm_train_forward_backward(n, c, relu, res):
+    from openscene_amd import functional as F_
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, generator=g) * 2.5 + 0.7
+    r = torch.randn(n, c, generator=g) if res else None
+    gy = torch.randn(n, c, generator=g)
+    bn_ref = torch.nn.BatchNorm1d(c).double()
+    bn_ref.weight.data.uniform_(0.5, 1.5, generator=g)
+    bn_ref.bias.data.uniform_(-0.5, 0.5, generator=g)
+    bn = torch.nn.BatchNorm1d(c)
+    bn.load_state_dict({k: (v.float() if v.dtype.is_floating_point else v) for k, v in bn_ref.state_dict().items()})
+    bn = bn.to(dev())
+    if n == 1:
+        bn_ref.eval(); bn.eval()                     # torch refuses batch statistics of one row
+    x64 = x.double().requires_grad_(True)
+    r64 = r.double().requires_grad_(True) if res else None
+    y_ref = bn_ref(x64)
+    if res:
+        y_ref = y_ref + r64
+    if relu:
+        y_ref = torch.relu(y_ref)
+    y_ref.backward(gy.double())
+
+    xg = x.to(dev()).requires_grad_(True)
+    rg = r.to(dev()).requires_grad_(True) if res else None
+    y = F_.batch_norm_act(xg, bn, residual=rg, relu=relu)
+    y.backward(gy.to(dev()))
+    # fp32 elementwise math vs float64: 2e-5 relative to the tensor's max
+    assert rel(y, y_ref) < 2e-5
+    assert rel(xg.grad, x64.grad) < 5e-5
+    assert rel(bn.weight.grad, bn_ref.weight.grad) < 5e-5
+    assert rel(bn.bias.grad, bn_ref.bias.grad) < 5e-5
+    if res:
+        assert rel(rg.grad, r64.grad) < 1e-6
+    # running statistics: 1e-5 relative
+    assert rel(bn.running_mean, bn_ref.running_mean) < 1e-5
+    assert rel(bn.running_var, bn_ref.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked)
+
+
+def test_batchnorm_eval_mode():
+    from openscene_amd import functional as F_
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2000, 96, generator=g)
+    bn_ref = torch.nn.BatchNorm1d(96).double().eval()
+    bn_ref.running_mean.uniform_(-1, 1, generator=g)
+    bn_ref.running_var.uniform_(0.3, 2, generator=g)
+    bn = torch.nn.BatchNorm1d(96)
+    bn.load_state_dict({k: (v.float() if v.dtype.is_floating_point else v) for k, v in bn_ref.state_dict().items()})
+    bn = bn.to(dev()).eval()
+    x64 = x.double().requires_grad_(True)
+    y_ref = torch.relu(bn_ref(x64))
+    y_ref.sum().backward()
+    xg = x.to(dev()).requires_grad_(True)
+    y = F_.batch_norm_act(xg, bn, relu=True)
+    y.sum().backward()
+    assert rel(y, y_ref) < 2e-5 and rel(xg.grad, x64.grad) < 2e-5
+    assert torch.equal(bn.running_mean.cpu().double(), bn_ref.running_mean.float().double())
+
+
+# ----------------------------------------------------------------------- query
+def _query_inputs(n_vox, n_pts, d, c, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n_vox, d, generator=g)
+    x = x / x.norm(dim=1, keepdim=True) * (0.5 + 1.5 * torch.rand(n_vox, 1, generator=g))
+    t = torch.randn(c, d, generator=g)
+    t = (t / t.norm(dim=1, keepdim=True)).half()
+    gather = torch.randint(0, n_vox, (n_pts,), generator=g)
+    return x, t, gather
+
+
+@pytest.mark.parametrize("n_vox,n_pts,d,c", [(4000, 6001, 768, 20), (3000, 3000, 512, 21), (2500, 4000, 768, 160),
+                                             (1000, 1500, 768, 43), (700, 900, 512, 300), (130, 1, 768, 2)])
+def test_query_scores_and_argmax(n_vox, n_pts, d, c):
+    from openscene_amd import ops
+    x, t, gather = _query_inputs(n_vox, n_pts, d, c, n_vox + c)
+    ref_scores, ref_arg = oq.query(x, t, gather)
+    scores, arg = ops.cosine_query(x.to(dev()), t.to(dev()), gather.to(dev()))
+    scores, arg = scores.cpu(), arg.cpu()
+    # fp16 outputs of O(1) magnitude, fp32 accumulation in a different order: 2e-3 absolute
+    assert (scores.float() - ref_scores.float()).abs().max().item() <= 2e-3
+    # the label must be a maximiser of OUR rounded scores, lowest index on ties ...
+    first_max = (scores == scores.max(1, keepdim=True)[0]).float().argmax(1)
+    assert torch.equal(arg, first_max)
+    # ... and agree with the reference wherever the reference's top-2 margin exceeds the score tolerance
+    top2 = ref_scores.float().topk(min(2, c), dim=1)[0]
+    clear = (top2[:, 0] - top2[:, -1]) > 4e-3 if c > 1 else torch.ones(n_pts, dtype=torch.bool)
+    assert torch.equal(arg[clear], ref_arg[clear])
+    # no gather = identity
+    s2, a2 = ops.cosine_query(x.to(dev()), t.to(dev()), None, want_scores=False)
+    assert s2 is None and a2.shape[0] == n_vox
+
+
+def test_query_ensemble():
+    from openscene_amd import ops
+    xd, t, gather = _query_inputs(3000, 5000, 768, 20, 1)
+    xf, _, _ = _query_inputs(3000, 5000, 768, 20, 2)
+    ref_scores, ref_arg, ref_sel = cpu_backend.query_ensemble(xd, xf, t, gather, gather)
+    scores, arg, sel = ops.query_ensemble(xd.to(dev()), xf.to(dev()), t.to(dev()), gather.to(dev()), gather.to(dev()))
+    # selection can only differ where the two best normalised scores are within fp16 rounding of each other
+    fd, ff = xd[gather], xf[gather]
+    pd = oq.half_matmul((fd / (fd.norm(dim=-1, keepdim=True) + 1e-5)).half(), t).float().max(1)[0]
+    pf = oq.half_matmul((ff / (ff.norm(dim=-1, keepdim=True) + 1e-5)).half(), t).float().max(1)[0]
+    clear = (pd - pf).abs() > 4e-3
+    assert torch.equal(sel.cpu()[clear], ref_sel[clear])
+    same = sel.cpu() == ref_sel
+    assert (scores.cpu().float()[same] - ref_scores.float()[same]).abs().max().item() <= 2e-3
+    assert same.float().mean().item() > 0.98
+
+
+# ------------------------------------------------------------------- voxelizer
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", ["voxelize_a.npz", "voxelize_b.npz"])
+def test_voxelizer_matches_reference_golden(name):
+    """Bit-exact against outputs of the reference's own Voxelizer (tests/golden/make_golden.py)."""
+    from openscene_amd.voxelizer import Voxelizer
+    g = np.load(os.path.join(GOLDEN, name))
+    rot = ((-np.pi / 64, np.pi / 64), (-np.pi / 64, np.pi / 64), (-np.pi, np.pi))
+    vox = Voxelizer(voxel_size=float(g["voxel_size"]), clip_bound=None, use_augmentation=True,
+                    scale_augmentation_bound=(0.9, 1.1), rotation_augmentation_bound=rot,
+                    translation_augmentation_ratio_bound=((-0.2, 0.2), (-0.2, 0.2), (0, 0)))
+    rng = np.random.default_rng(int(g["np_seed"]))
+    n = g["xyz"].shape[0]
+    feats = rng.random((n, 3)) * 255
+    labels = np.arange(n) % 20
+    np.random.seed(int(g["np_seed"]))
+    c, f, l, inv, inds = vox.voxelize(g["xyz"], feats, labels, return_ind=True)
+    assert np.array_equal(inds, g["inds"])
+    assert np.array_equal(inv, g["inverse"])
+    assert np.array_equal(c, g["coords"])
+    assert np.array_equal(f, feats[g["inds"]]) and np.array_equal(l, labels[g["inds"]])
+
+
+@pytest.mark.parametrize("name", ["quantize_small.npz", "quantize_frac.npz"])
+def test_quantize_golden(name):
+    from openscene_amd import ops
+    g = np.load(os.path.join(GOLDEN, name))
+    # identity transform with unit voxel: voxelize == sparse_quantize(floor(coords - min))
+    coords = g["coords"]
+    T = np.eye(4)
+    grid, inds, inv = ops.voxelize_fnv(torch.from_numpy(coords).to(dev()), T)
+    ref_inds, ref_inv = ov.quantize_first_occurrence(np.floor(np.floor(coords) - np.floor(coords).min(0)))
+    assert np.array_equal(inds.cpu().numpy(), ref_inds) and np.array_equal(inv.cpu().numpy(), ref_inv)
+    if np.floor(coords).min() == 0:     # then it is literally the golden case
+        assert np.array_equal(inds.cpu().numpy(), g["inds"]) and np.array_equal(inv.cpu().numpy(), g["inverse"])
+
+
+def test_fnv_known_answers():
+    from openscene_amd import ops
+    g = np.load(os.path.join(GOLDEN, "hash_kat.npz"))
+    keys = ops.fnv_hash(torch.from_numpy(g["coords"]).to(dev())).cpu().numpy().view(np.uint64)
+    assert [int(v) for v in keys[:3]] == [15658191375538532279, 15657232601398921515, 15489006222804313940]
+    assert np.array_equal(keys, g["fnv"])
+
+
+def test_voxelizer_full_size_properties():
+    """ScanNet-size cloud (200 k points): bit-exact vs the numpy oracle + np.unique structure."""
+    from openscene_amd import ops
+    from openscene_amd import synthetic as syn
+    xyz = syn.room_points(9, n_pts=200000)
+    np.random.seed(4)
+    T = ov.draw_transform(0.02)
+    grid, inds, inv = ops.voxelize_fnv(torch.from_numpy(xyz).to(dev()), T)
+    rc, ri, rv = ov.voxelize_with_matrix(xyz, T)
+    grid, inds, inv = grid.cpu().numpy(), inds.cpu().numpy(), inv.cpu().numpy()
+    assert np.array_equal(inds, ri) and np.array_equal(inv, rv) and np.array_equal(grid[inds], rc)
+    keys = ov.fnv_keys(grid[inds])
+    assert np.all(keys[1:] > keys[:-1])                               # ascending distinct keys
+    assert np.array_equal(grid[inds][inv], grid)                      # every point maps to its voxel
+    first = np.full(inds.shape[0], xyz.shape[0]); np.minimum.at(first, inv, np.arange(xyz.shape[0]))
+    assert np.array_equal(first, inds)                                # first occurrence

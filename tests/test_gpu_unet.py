@@ -1,0 +1,132 @@
+"""End-to-end MinkUNet on the HIP kernels vs the float64 oracle network
+(oracle.sparse_ops.unet_forward): forward in train and eval mode, all parameter
+gradients, running statistics; the reference-shaped DisNet step; the ME alias.
+
+Stated tolerance: fp32 network vs float64 oracle, relative L2 error
+of the output <= 2e-4 and max |delta| <= 1e-3 * max |reference|; gradients rel-L2 <= 1e-3
+(BN in training mode amplifies rounding through 1/sigma)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_ops as so
+from openscene_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def rel_l2(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+
+
+def scene_coords(seed, n_pts, voxel, batch=1):
+    return syn.batch_coords([syn.shuffled(syn.grid_voxels(syn.room_points(seed + b, n_pts=n_pts), voxel), seed + b)
+                             for b in range(batch)])
+
+
+@pytest.mark.parametrize("arch,out_dim,train", [("MinkUNet14A", 16, True), ("MinkUNet18A", 20, False),
+                                                ("MinkUNet18A", 64, True), ("MinkUNet34C", 32, True)])
+def test_unet_vs_oracle(arch, out_dim, train):
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import SparseTensor
+    torch.manual_seed(7)
+    model = mink_unet(3, out_dim, 3, arch)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.3, 0.3)
+    model.train(train)
+    coords = scene_coords(11, 7000, 0.04, batch=2)                  # ~2 x 5 k voxels
+    feats = torch.rand(coords.shape[0], 3)
+    p = {k: v.detach().clone().double() for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+    for k, v in p.items():
+        if "running" not in k:
+            v.requires_grad_(True)
+    ref = so.unet_forward(p, feats.double(), coords, arch, train=train)
+    target = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    (ref * target).sum().backward()
+
+    model = model.to(dev())
+    out = model(SparseTensor(feats.to(dev()), torch.from_numpy(coords).to(dev())))
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    e = rel_l2(out, ref)
+    assert e <= 2e-4, "output rel-L2 %.3e" % e
+    assert (out.double().cpu() - ref.detach()).abs().max().item() <= 1e-3 * ref.abs().max().item()
+    (out * target.float().to(dev())).sum().backward()
+    worst = ("", 0.0)
+    for name, prm in model.named_parameters():
+        g = rel_l2(prm.grad, p[name].grad)
+        if g > worst[1]:
+            worst = (name, g)
+    assert worst[1] <= 1e-3, "gradient of %s rel-L2 %.3e" % worst
+    if train:
+        for name, buf in model.named_buffers():
+            if "running" in name:
+                assert rel_l2(buf, p[name]) <= 1e-5, name
+
+
+def test_disnet_distill_step_and_row_order():
+    """One reference-shaped distillation step (run/distill.py:315-334): shift coords, forward,
+    output[mask], cosine loss, backward -- rows must come back in INPUT order."""
+    from openscene_amd.disnet import DisNet
+    from openscene_amd.sparse import SparseTensor
+
+    class Cfg:
+        arch_3d = "MinkUNet18A"
+        feature_2d_extractor = "lseg"
+
+    torch.manual_seed(0)
+    net = DisNet(Cfg()).to(dev())
+    coords = scene_coords(21, 9000, 0.04)
+    coords[:, 1:4] += (np.random.default_rng(0).random(3) * 100).astype(np.int32)
+    feats = torch.ones(coords.shape[0], 3)
+    c = torch.from_numpy(coords).to(dev())
+    out = net(SparseTensor(feats.to(dev()), c))
+    assert out.shape == (coords.shape[0], 512)
+    # permuting the input rows permutes the output rows identically (row-order contract)
+    perm = torch.randperm(coords.shape[0], generator=torch.Generator().manual_seed(3))
+    net.eval()
+    a = net(SparseTensor(feats.to(dev()), c))
+    b = net(SparseTensor(feats.to(dev()), c[perm.to(dev())]))
+    assert rel_l2(b, a[perm.to(dev())]) < 1e-5
+    net.train()
+    mask = torch.zeros(coords.shape[0], dtype=torch.bool)
+    mask[torch.randperm(coords.shape[0])[:2000]] = True
+    target = torch.nn.functional.normalize(torch.randn(2000, 512), dim=1).to(dev())
+    out = net(SparseTensor(feats.to(dev()), c))
+    loss = (1 - torch.nn.CosineSimilarity()(out[mask.to(dev())], target)).mean()
+    loss.backward()
+    assert torch.isfinite(loss).item()
+    grads = [p.grad for p in net.parameters()]
+    assert all(g is not None and torch.isfinite(g).all().item() for g in grads)
+    assert sum(float(g.abs().sum()) for g in grads) > 0
+
+
+def test_unfused_module_chain_equals_fused():
+    """Calling the modules one by one the way models/mink_unet.py:116-174 does (conv, bn, relu,
+    `out += residual`) gives the fused result."""
+    import openscene_amd.minkowski as ME
+    from openscene_amd.sparse import SparseTensor
+    torch.manual_seed(2)
+    d = dev()
+    conv = ME.MinkowskiConvolution(3, 32, kernel_size=5, dimension=3).to(d)
+    bn = ME.MinkowskiBatchNorm(32).to(d)
+    relu = ME.MinkowskiReLU(inplace=True)
+    blk = ME.BasicBlock(32, 32, dimension=3).to(d)
+    coords = torch.from_numpy(scene_coords(31, 5000, 0.05)).to(d)
+    x = SparseTensor(torch.rand(coords.shape[0], 3, device=d), coords)
+    y = relu(bn(conv(x)))
+    res = y
+    z = blk.conv1(y); z = blk.norm1(z); z = blk.relu(z); z = blk.conv2(z); z = blk.norm2(z)
+    z += res
+    z = blk.relu(z)
+    bn.bn.running_mean.zero_(); bn.bn.running_var.fill_(1)
+    fused = blk(y)
+    assert rel_l2(z.F, fused.F) < 1e-6
