@@ -1,0 +1,373 @@
+#!/usr/bin/env python
+"""Headline benchmark: active voxels/s of one MinkUNet18A distillation step
+(map construction + forward + cosine loss + backward + Adam) at 2 cm on the
+ScanNet-shaped synthetic scene S100k, one scene per GPU,
+data-parallel over N GPUs with RCCL gradient all-reduce (torch DDP, as
+run/distill.py:149-150 does); plus the per-point open-vocabulary query time.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement):
+  value      = voxels processed by ALL ranks in the timed region / max-over-ranks time
+  roofline   = dominant spconv kernel instance: ALGORITHMIC bytes per launch / mean launch
+               duration from HIP events recorded inside the timed region on the launch stream
+  cpu_baseline = the CPU oracle (`oracle/`, kind "port": per-offset gather -> BLAS mm ->
+               index_add, what ME's CPU backend does) on the same scene, host cores, rank 0, N=1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_PEAK_TFLOPS = 157.3       # f32 MFMA / vector peak, same guide
+
+
+class LaunchProfiler:
+    """HIP-event brackets around C-ABI launches (events are recorded on the torch current
+    stream, which is the stream openscene_amd launches on)."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def start(self, kind, dev, **meta):
+        if not self.enabled:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(dev))
+        return (kind, meta, e0, e1, dev)
+
+    def stop(self, tok):
+        if tok is None:
+            return
+        kind, meta, e0, e1, dev = tok
+        e1.record(torch.cuda.current_stream(dev))
+        self.records.append((kind, meta, e0, e1))
+
+    def summarise(self, pair_counts):
+        """Group by kernel instance; algorithmic bytes per SURVEY.md 8(d):
+        conv: 4*(N_in*Cin + N_out*Cout + K*Cin*Cout) + 8*pairs (K == 1: no map term)."""
+        from openscene_amd import ops
+        groups = {}
+        for kind, m, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            pairs = pair_counts.get((m["K"], m["n_out"]), m["n_out"] if m["K"] == 1 else None)
+            if pairs is None:
+                continue
+            byts = 4.0 * (m["n_in"] * m["cin"] + m["n_out"] * m["cout"] + m["K"] * m["cin"] * m["cout"])
+            if m["K"] > 1:
+                byts += 8.0 * pairs
+            flops = 2.0 * pairs * m["cin"] * m["cout"]
+            if kind == "spconv_fwd":
+                wm, wn, tn, bk, S, wgs = ops.spconv_fwd_plan(m["n_out"], m["K"], m["cin"], m["cout"])
+                name = "spconv_fwd_kernel<%d,%d,%d,%d>" % (wm, wn, tn, bk) + ("+reduce" if S > 1 else "")
+            else:
+                name = "spconv_wgrad_kernel"
+            g = groups.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
+            g["launches"] += 1
+            g["ms"] += ms
+            g["bytes"] += byts
+            g["flops"] += flops
+        return groups
+
+
+def build_scene(seed, device):
+    from openscene_amd import synthetic as syn
+    vox = syn.shuffled(syn.grid_voxels(syn.room_points(seed), 0.02), seed)
+    coords = syn.batch_coords([vox])
+    return torch.from_numpy(coords).to(device)
+
+
+def all_pair_counts(coords):
+    """(K, n_rows_of_table) -> #pairs for every kernel map (and its transpose) of the scene."""
+    from openscene_amd import ops
+    from openscene_amd.sparse import CoordinateManager
+    cm = CoordinateManager(coords)
+    out = {}
+    specs = [(1, 1, 5)] + [(s, s, 3) for s in (1, 2, 4, 8, 16)] + [(s, 2 * s, 2) for s in (1, 2, 4, 8)]
+    for si, so, k in specs:
+        fwd, bwd, _ = cm.kmap(si, so, k)
+        cnt = int(ops.kmap_count(fwd).sum())
+        out[(k ** 3, fwd.shape[1])] = cnt
+        out[(k ** 3, bwd.shape[1])] = cnt
+    sizes = [cm.size(s) for s in (1, 2, 4, 8, 16)]
+    return out, sizes
+
+
+def step_algorithmic_bytes(model, sizes, pair_counts):
+    """Whole-step (fwd + bwd, training BN) algorithmic bytes and flops, SURVEY.md 8(d) model."""
+    import openscene_amd.minkowski as ME
+    # walk the convs in module order with their (n_in, n_out) from a shape trace
+    lvl = {1: sizes[0], 2: sizes[1], 4: sizes[2], 8: sizes[3], 16: sizes[4]}
+    total_b, total_f = 0.0, 0.0
+    stride = 1
+    trace = []
+
+    def conv_cost(m, s_in, s_out):
+        K = m.kernel_volume
+        n_in, n_out = lvl[s_in], lvl[s_out]
+        if K == 1:
+            pairs = n_out
+        elif s_in == s_out:
+            pairs = pair_counts[(K, n_out)]
+        else:
+            pairs = max(n_in, n_out)
+        b = 4.0 * (n_in * m.in_channels + n_out * m.out_channels + K * m.in_channels * m.out_channels)
+        b += 8.0 * pairs if K > 1 else 0.0
+        trace.append((3.0 * b + (0.0), 3 * 2.0 * pairs * m.in_channels * m.out_channels))
+
+    def bn_cost(c, s):
+        trace.append((24.0 * lvl[s] * c, 0.0))          # train fwd 12 + bwd 12 bytes per element
+
+    net = model.net3d if hasattr(model, "net3d") else model
+    conv_cost(net.conv0p1s1, 1, 1); bn_cost(net.bn0.bn.num_features, 1)
+    names_down = ("conv1p1s2", "conv2p2s2", "conv3p4s2", "conv4p8s2")
+    names_up = ("convtr4p16s2", "convtr5p8s2", "convtr6p4s2", "convtr7p2s2")
+
+    def stage(blocks, s):
+        for blk in blocks:
+            conv_cost(blk.conv1, s, s); bn_cost(blk.norm1.bn.num_features, s)
+            conv_cost(blk.conv2, s, s); bn_cost(blk.norm2.bn.num_features, s)
+            if blk.downsample is not None:
+                conv_cost(blk.downsample[0], s, s); bn_cost(blk.downsample[1].bn.num_features, s)
+            trace.append((4.0 * lvl[s] * blk.norm2.bn.num_features, 0.0))    # residual read
+
+    for i in range(4):
+        conv_cost(getattr(net, names_down[i]), stride, stride * 2); stride *= 2
+        bn_cost(getattr(net, "bn%d" % (i + 1)).bn.num_features, stride)
+        stage(getattr(net, "block%d" % (i + 1)), stride)
+    for i in range(4):
+        conv_cost(getattr(net, names_up[i]), stride, stride // 2); stride //= 2
+        bn_cost(getattr(net, "bntr%d" % (4 + i)).bn.num_features, stride)
+        stage(getattr(net, "block%d" % (5 + i)), stride)
+    conv_cost(net.final, 1, 1)
+    for b, f in trace:
+        total_b += b
+        total_f += f
+    return total_b, total_f
+
+
+def cpu_baseline(seed, arch, out_dim):
+    """Time the CPU oracle on ONE step of the same workload (bounded sample: one S100k scene)."""
+    from oracle import coords as oc
+    from oracle import sparse_ops as so
+    from openscene_amd import synthetic as syn
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    vox = syn.shuffled(syn.grid_voxels(syn.room_points(seed), 0.02), seed)
+    coords = syn.batch_coords([vox])
+    p = so.init_params(arch, 3, out_dim, dtype=torch.float32)
+    for k, v in p.items():
+        if "running" not in k:
+            v.requires_grad_(True)
+    feats = torch.ones(coords.shape[0], 3)
+    n_sup = min(20000, coords.shape[0])
+    target = torch.nn.functional.normalize(torch.randn(n_sup, out_dim), dim=1)
+    t0 = time.perf_counter()
+    cm = oc.CoordinateManager(coords)
+    out = so.unet_forward(p, feats, coords, arch, train=True, cm=cm)
+    loss = (1 - torch.nn.functional.cosine_similarity(out[:n_sup], target)).mean()
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": coords.shape[0] / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
+            "sample": "1 step (maps + fwd + loss + bwd, fp32, no optimizer) of %s on the same S100k scene "
+                      "(%d voxels), %.1f s on %d threads" % (arch, coords.shape[0], dt, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--arch", default="MinkUNet18A")
+    ap.add_argument("--feature", default="openseg", help="openseg (768-d) | lseg (512-d)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
+
+    from openscene_amd import ops
+    from openscene_amd.disnet import DisNet
+    from openscene_amd.query import query_distill
+    from openscene_amd.sparse import SparseTensor
+
+    class Cfg:
+        arch_3d = args.arch
+        feature_2d_extractor = args.feature
+
+    torch.manual_seed(1463)                         # config/scannet/ours_openseg.yaml:25
+    model = DisNet(Cfg()).to(device)
+    out_dim = model.net3d.final.out_channels
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+    try:
+        optim = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
+    except (TypeError, RuntimeError):
+        optim = torch.optim.Adam(net.parameters(), lr=1e-4)
+
+    coords0 = build_scene(rank, device)             # one scene per GPU (batch 8 over 8 GPUs), seed = rank
+    n_vox = coords0.shape[0]
+    feats = torch.ones(n_vox, 3, device=device)     # input_color: False -> constant ones (feature_loader.py:183-184)
+    g = torch.Generator().manual_seed(100 + rank)
+    n_sup = min(20000, n_vox)
+    mask = torch.zeros(n_vox, dtype=torch.bool)
+    mask[torch.randperm(n_vox, generator=g)[:n_sup]] = True
+    mask = mask.to(device)
+    feat_3d = torch.nn.functional.normalize(torch.randn(n_sup, out_dim, generator=g), dim=1).half().float().to(device)
+    shift_rng = np.random.default_rng(rank)
+    cos = torch.nn.CosineSimilarity()
+
+    def step():
+        coords = coords0.clone()
+        shift = torch.from_numpy((shift_rng.random(3) * 100).astype(np.int32)).to(device)
+        coords[:, 1:4] += shift                                    # run/distill.py:315
+        sinput = SparseTensor(feats, coords)                       # builds every map (ME does per forward)
+        out = net(sinput)
+        loss = (1 - cos(out[mask], feat_3d)).mean()                # run/distill.py:322-326
+        optim.zero_grad(set_to_none=True)
+        loss.backward()
+        optim.step()
+        return loss
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    pair_counts, sizes = all_pair_counts(coords0)
+    for _ in range(args.warmup):
+        step()
+    prof = LaunchProfiler()
+    if not args.no_kernel_events:
+        ops.set_profiler(prof)
+        prof.enabled = True
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof.enabled = False
+    ops.set_profiler(None)
+
+    tt = torch.tensor([dt, float(n_vox)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, vox_total = float(tmax[0]), float(tsum[1])
+    else:
+        dt_max, vox_total = dt, float(n_vox)
+
+    # ---- query timing (per-point feature x text, M2) : eval forward output of this scene
+    qres = None
+    if rank == 0:
+        model.eval()
+        with torch.no_grad():
+            pred = model(SparseTensor(feats, coords0))
+        gq = torch.Generator().manual_seed(5)
+        n_pts = 150000
+        inds_reverse = torch.randint(0, n_vox, (n_pts,), generator=gq).to(device)
+        text = torch.nn.functional.normalize(torch.randn(20, out_dim, generator=gq), dim=1).half().to(device)
+        for _ in range(3):
+            query_distill(pred, text, inds_reverse)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            query_distill(pred, text, inds_reverse)
+        e1.record()
+        torch.cuda.synchronize(device)
+        q_ms = e0.elapsed_time(e1) / reps
+        q_bytes = 4.0 * n_pts * out_dim + 2.0 * 20 * out_dim + 8.0 * n_pts + 8.0 * n_pts
+        qres = {"ms": q_ms, "n_points": n_pts, "dim": out_dim, "labels": 20,
+                "hbm_frac": q_bytes / (q_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        model.train()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    step_bytes, step_flops = step_algorithmic_bytes(model, sizes, pair_counts)
+    ms_per_step = dt_max * 1e3 / args.steps
+    roofline = None
+    kernels = {}
+    if prof.records:
+        groups = prof.summarise(pair_counts)
+        for name, gk in groups.items():
+            kernels[name] = {"launches_per_step": gk["launches"] / args.steps,
+                             "ms_per_step": gk["ms"] / args.steps,
+                             "avg_us": 1e3 * gk["ms"] / gk["launches"],
+                             "GBps": gk["bytes"] / (gk["ms"] * 1e-3) / 1e9,
+                             "TFLOPs": gk["flops"] / (gk["ms"] * 1e-3) / 1e12}
+        dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        name, gk = dom
+        achieved = gk["bytes"] / (gk["ms"] * 1e-3) / 1e9
+        pmc = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path)).get(name.split("+")[0])
+            except Exception:
+                pmc = None
+        roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc,
+                    "avg_launch_us": 1e3 * gk["ms"] / gk["launches"], "launches_per_step": gk["launches"] / args.steps,
+                    "bytes_per_launch": gk["bytes"] / gk["launches"],
+                    "fp32_tflops": gk["flops"] / (gk["ms"] * 1e-3) / 1e12,
+                    "fp32_frac": gk["flops"] / (gk["ms"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                    "step_hbm_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "step_fp32_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(0, args.arch, out_dim)
+
+    line = {
+        "metric": "active voxels/sec MinkUNet18A fwd+bwd @2cm ScanNet; per-point query ms",
+        "value": vox_total * args.steps / dt_max, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ScanNet distillation step (configs[2]): %s, %d-d head, 1 synthetic S100k scene/GPU "
+                               "(%d voxels on rank 0, 2 cm), training-mode BN; timed = coordinate+kernel maps, "
+                               "forward, cosine loss, backward, DDP all-reduce, Adam step" % (args.arch, out_dim, n_vox),
+                   "arch": args.arch, "feature_dim": out_dim, "voxels_rank0": n_vox,
+                   "level_sizes": sizes, "parallelism": "dp%d" % world,
+                   "step_algorithmic_GB": step_bytes / 1e9, "step_GFLOP": step_flops / 1e9},
+        "query": qres, "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "loss": float(loss),
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

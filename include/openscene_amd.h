@@ -93,6 +93,11 @@ int osn_spconv_fwd(const float* in, const float* W, const int32_t* nbr, const in
                    float* out, int64_t n_out, int K, int cin, int cout,
                    void* ws, size_t ws_bytes, osn_stream_t stream);
 
+/* Which kernel instance / launch shape osn_spconv_fwd() uses for a problem (host helper, for
+ * profiling): plan6 = {WM, WN, TN, BK, S (offset splits), workgroups};
+ * the kernel symbol is spconv_fwd_kernel<WM, WN, TN, BK>.                          */
+int osn_spconv_fwd_plan(int64_t n_out, int K, int cin, int cout, int32_t* plan6);
+
 /* Wt[k] = W[flip ? K-1-k : k]^T   ([K, cout, cin]).  The input gradient is
  * osn_spconv_fwd(gout, Wt, table, ...) with table = nbr and flip = 1 for a
  * stride-1 odd kernel (the map is its own mirror), or the transposed table and

@@ -376,6 +376,19 @@ extern "C" size_t osn_spconv_fwd_ws_bytes(int64_t n_out, int K, int cin, int cou
     return p.S > 1 ? size_t(p.S) * size_t(n_out) * size_t(cout) * 4 : 0;
 }
 
+extern "C" int osn_spconv_fwd_plan(int64_t n_out, int K, int cin, int cout, int32_t* plan6) {
+    OSN_REQUIRE(plan6 && n_out >= 0 && K >= 1 && cin >= 1 && cout >= 1, OSN_E_ARG, "osn_spconv_fwd_plan: bad arguments");
+    FwdPlan p = plan_fwd(n_out > 0 ? n_out : 1, K, cin, cout);
+    static const int wm[3] = {4, 2, 1}, wn[3] = {1, 2, 4};
+    plan6[0] = wm[p.cfg];
+    plan6[1] = wn[p.cfg];
+    plan6[2] = p.tn;
+    plan6[3] = cin <= 4 ? 4 : 32;
+    plan6[4] = p.S;
+    plan6[5] = p.gx * p.gy * p.S;
+    return OSN_OK;
+}
+
 template <int WM, int WN, int TN, int BK>
 static void launch_fwd(const FwdPlan& p, hipStream_t st, const float* in, const float* W, const int32_t* nbr,
                        const int32_t* out_rows, float* dst, int n_out, int K, int cin, int cout) {

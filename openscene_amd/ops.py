@@ -10,6 +10,15 @@ from ._lib import check
 
 _vp = ctypes.c_void_p
 
+# Optional launch profiler (bench.py): an object with start(kind, dev, **meta) -> token and
+# stop(token); brackets the C-ABI call with HIP events on the stream the kernels run on.
+_profiler = None
+
+
+def set_profiler(p):
+    global _profiler
+    _profiler = p
+
 
 def _p(t):
     return _vp(t.data_ptr()) if t is not None else None
@@ -141,9 +150,13 @@ def spconv_fwd(feats, weight, nbr, n_out, out_rows=None):
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
     wsb = lib.osn_spconv_fwd_ws_bytes(n_out, K, cin, cout)
     ws = _ws(wsb, dev) if wsb else None
+    tok = _profiler.start("spconv_fwd", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
+        if _profiler is not None else None
     with _Dev(dev):
         check(lib.osn_spconv_fwd(_p(feats), _p(w), _p(nbr), _p(out_rows), _p(out), n_out, K, cin, cout, _p(ws),
                                  int(wsb), _stream(dev)), "osn_spconv_fwd")
+    if tok is not None:
+        _profiler.stop(tok)
     return out
 
 
@@ -173,10 +186,21 @@ def spconv_wgrad(feats, gout, nbr, K):
     gw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
     wsb = lib.osn_spconv_wgrad_ws_bytes(n_out, K, cin, cout)
     ws = _ws(wsb, dev) if wsb else None
+    tok = _profiler.start("spconv_wgrad", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
+        if _profiler is not None else None
     with _Dev(dev):
         check(lib.osn_spconv_wgrad(_p(feats), _p(gout), _p(nbr), _p(gw), n_out, K, cin, cout, _p(ws), int(wsb),
                                    _stream(dev)), "osn_spconv_wgrad")
+    if tok is not None:
+        _profiler.stop(tok)
     return gw
+
+
+def spconv_fwd_plan(n_out, K, cin, cout):
+    """(WM, WN, TN, BK, S, workgroups) of the kernel instance osn_spconv_fwd picks."""
+    plan = (ctypes.c_int32 * 6)()
+    check(_lib.load().osn_spconv_fwd_plan(int(n_out), int(K), int(cin), int(cout), plan), "osn_spconv_fwd_plan")
+    return tuple(plan)
 
 
 # ------------------------------------------------------------------ batch norm

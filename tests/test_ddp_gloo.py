@@ -1,0 +1,95 @@
+"""The N>1 path on CPU: two gloo ranks, one scene each, torch DDP around the model exactly as
+run/distill.py:149-150 wraps it; the all-reduced gradients must equal the mean of the two
+single-rank gradients and parameters/BN buffers must be broadcast from rank 0.  The HIP ops
+are replaced by tests/cpu_backend.py inside the worker processes (host-logic test)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _install_cpu_backend():
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import cpu_backend
+    import openscene_amd.ops as ops
+    for n in cpu_backend._NAMES:
+        setattr(ops, n, getattr(cpu_backend, n))
+
+
+def _scene(seed):
+    rng = np.random.default_rng(seed)
+    g = np.unique(rng.integers(0, 10, (220, 3)), axis=0)
+    g = g[rng.permutation(g.shape[0])]
+    return torch.from_numpy(np.concatenate([np.zeros((g.shape[0], 1)), g], 1).astype(np.int32))
+
+
+def _loss(model, seed):
+    from openscene_amd.sparse import SparseTensor
+    c = _scene(seed)
+    out = model(SparseTensor(torch.ones(c.shape[0], 3, dtype=torch.float64), c))
+    tgt = torch.randn(out.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
+    return (1 - torch.nn.functional.cosine_similarity(out, tgt)).mean()
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    _install_cpu_backend()
+    from openscene_amd.mink_unet import mink_unet
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                          # different init per rank: DDP must broadcast rank 0's
+    model = mink_unet(3, 8, 3, "MinkUNet14A").double()
+    ddp = torch.nn.parallel.DistributedDataParallel(model)
+    loss = _loss(ddp, seed=10 + rank)
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+    params = {n: p.detach().clone() for n, p in model.named_parameters()}
+    torch.save({"grads": grads, "params": params, "loss": float(loss)}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    for n in r0["params"]:
+        assert torch.equal(r0["params"][n], r1["params"][n]), "parameter %s not broadcast" % n
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), "gradient %s not all-reduced" % n
+    # single-process reference: same weights (rank 0's), mean of the two scenes' gradients
+    _install_cpu_backend()
+    try:
+        from openscene_amd.mink_unet import mink_unet
+        torch.manual_seed(100)
+        model = mink_unet(3, 8, 3, "MinkUNet14A").double()
+        for n, p in model.named_parameters():
+            assert torch.equal(p.detach(), r0["params"][n])
+        acc = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+        for seed in (10, 11):
+            model.zero_grad()
+            _loss(model, seed).backward()
+            for n, p in model.named_parameters():
+                acc[n] += p.grad / world
+        for n in acc:
+            scale = acc[n].abs().max().item() + 1e-12
+            assert (acc[n] - r0["grads"][n]).abs().max().item() <= 1e-9 * scale + 1e-12, n
+    finally:
+        import importlib
+        import openscene_amd.ops as ops
+        importlib.reload(ops)
