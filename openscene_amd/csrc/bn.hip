@@ -87,17 +87,39 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
     }
 }
 
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int n_rb, int64_t n, int c,
-                                         float* __restrict__ mean, float* __restrict__ var,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var,
-                                         float momentum) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= c) return;
-    double s1 = 0, s2 = 0;
-    for (int b = 0; b < n_rb; ++b) {
-        s1 += partial[(int64_t(b) * 2 + 0) * c + j];
-        s2 += partial[(int64_t(b) * 2 + 1) * c + j];
+// Final column sums: 64 columns x 16 slices of the partial blocks per workgroup
+// (the partial blocks are summed in a fixed order => deterministic).
+constexpr int FIN_COLS = 64, FIN_PARTS = 16;
+
+__device__ inline void finalize_sums(const double* __restrict__ partial, int n_rb, int c, double& s1, double& s2,
+                                     int& col) {
+    __shared__ double red[2][FIN_PARTS][FIN_COLS];
+    const int cl = threadIdx.x & (FIN_COLS - 1), part = threadIdx.x / FIN_COLS;
+    col = blockIdx.x * FIN_COLS + cl;
+    double a = 0, b = 0;
+    if (col < c) {
+        for (int blk = part; blk < n_rb; blk += FIN_PARTS) {
+            a += partial[(int64_t(blk) * 2 + 0) * c + col];
+            b += partial[(int64_t(blk) * 2 + 1) * c + col];
+        }
     }
+    red[0][part][cl] = a;
+    red[1][part][cl] = b;
+    __syncthreads();
+    s1 = 0; s2 = 0;
+    if (part == 0) {
+#pragma unroll
+        for (int q = 0; q < FIN_PARTS; ++q) { s1 += red[0][q][cl]; s2 += red[1][q][cl]; }
+    }
+}
+
+__global__ __launch_bounds__(FIN_COLS * FIN_PARTS) void bn_stats_finalize_kernel(
+    const double* __restrict__ partial, int n_rb, int64_t n, int c, float* __restrict__ mean, float* __restrict__ var,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
+    double s1, s2;
+    int j;
+    finalize_sums(partial, n_rb, c, s1, s2, j);
+    if (threadIdx.x >= FIN_COLS || j >= c) return;
     const double m = s1 / double(n);
     double v = s2 / double(n) - m * m;
     if (v < 0) v = 0;
@@ -110,15 +132,14 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int n_rb, int c,
-                                       float* __restrict__ sum_g, float* __restrict__ sum_gx) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= c) return;
-    double s1 = 0, s2 = 0;
-    for (int b = 0; b < n_rb; ++b) {
-        s1 += partial[(int64_t(b) * 2 + 0) * c + j];
-        s2 += partial[(int64_t(b) * 2 + 1) * c + j];
-    }
+__global__ __launch_bounds__(FIN_COLS * FIN_PARTS) void bn_bwd_finalize_kernel(const double* __restrict__ partial,
+                                                                              int n_rb, int c,
+                                                                              float* __restrict__ sum_g,
+                                                                              float* __restrict__ sum_gx) {
+    double s1, s2;
+    int j;
+    finalize_sums(partial, n_rb, c, s1, s2, j);
+    if (threadIdx.x >= FIN_COLS || j >= c) return;
     sum_g[j] = float(s1);
     sum_gx[j] = float(s2);
 }
@@ -212,7 +233,7 @@ extern "C" int osn_bn_stats(const float* x, int64_t n, int c, float* mean, float
     hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(p.n_rb, p.n_cg), dim3(256), 0, st, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, 0, n, c,
                        p.rows_per_block, partial);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, partial, p.n_rb, n, c, mean, var,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(c, FIN_COLS)), dim3(FIN_COLS * FIN_PARTS), 0, st, partial, p.n_rb, n, c, mean, var,
                        running_mean, running_var, momentum);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
@@ -253,7 +274,7 @@ extern "C" int osn_bn_backward(const float* x, const float* y, const float* gy, 
     hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(p.n_rb, p.n_cg), dim3(256), 0, st, x, y, gy, mean, var, eps, relu, n,
                        c, p.rows_per_block, partial);
     // ggamma = sum g*xhat, gbeta = sum g  (also the two column sums the apply pass needs)
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, partial, p.n_rb, c, gbeta, ggamma);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, FIN_COLS)), dim3(FIN_COLS * FIN_PARTS), 0, st, partial, p.n_rb, c, gbeta, ggamma);
     const int64_t total4 = n * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, y, gy, mean, var, gamma, eps,
                        relu, training, gbeta, ggamma, 1.f / float(n), gx, gres, total4, c / 4);

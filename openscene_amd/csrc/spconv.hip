@@ -172,37 +172,102 @@ __global__ void weight_transpose_kernel(const float* __restrict__ W, int K, int 
 }
 
 // ------------------------------------------------------------- weight grad ----
-// Block tile: 64 input channels x 128 output channels of gW[k]; wave w owns output
-// channel tile w and both 32-row input-channel tiles.  Reduction over the valid
-// (in,out) pairs of offset k inside the block's row range, compacted in LDS in a
-// deterministic (ballot/prefix) order, staged 16 pairs at a time.
-constexpr int WG_CI = 64, WG_CO = 128, WG_RB = 16, WG_SUB = 1024;
+// gW[k] (CI_T x CO_T tile) = sum over the valid (in,out) pairs of offset k inside the
+// block's row range.  The pairs are compacted in LDS in a deterministic (ballot/prefix)
+// order => exact work, no zero rows fed to the MFMA.  32 pairs per stage; the next
+// stage's rows are fetched into registers while the MFMAs of the current one run
+// (global -> VGPR -> LDS software pipeline, one barrier pair per stage).  The 32x32
+// output tiles of the block are dealt round-robin to the four waves.
+constexpr int WG_T = 128;      // max tile edge (input / output channels per block)
+constexpr int WG_RB = 32;      // pairs per stage
+constexpr int WG_SUB = 1024;   // rows compacted at a time
 
+template <int TPW>   // 32x32 tiles per wave (1..4)
 __global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                            const int32_t* __restrict__ nbr, float* __restrict__ dst,
                                                            int n_out, int K, int cin, int cout, int rows_per_split,
-                                                           int n_co_blocks) {
-    __shared__ __attribute__((aligned(16))) float As[WG_RB][WG_CI];
-    __shared__ __attribute__((aligned(16))) float Gs[WG_RB][WG_CO];
+                                                           int n_co_blocks, int ci_t, int co_t) {
+    __shared__ __attribute__((aligned(16))) float As[WG_RB][WG_T];
+    __shared__ __attribute__((aligned(16))) float Gs[WG_RB][WG_T];
     __shared__ int list_o[WG_SUB];
     __shared__ int list_i[WG_SUB];
     __shared__ int wcnt[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ci0 = (blockIdx.x / n_co_blocks) * WG_CI;
-    const int co0 = (blockIdx.x % n_co_blocks) * WG_CO;
+    const int ci0 = (blockIdx.x / n_co_blocks) * ci_t;
+    const int co0 = (blockIdx.x % n_co_blocks) * co_t;
     const int k = blockIdx.z;
     const int r_begin = blockIdx.y * rows_per_split;
     const int r_end = min(n_out, r_begin + rows_per_split);
     const bool a_vec = (cin & 3) == 0, g_vec = (cout & 3) == 0;
-    const bool tile_on[2] = {ci0 < cin, ci0 + 32 < cin};
-    const bool wave_on = co0 + wave * 32 < cout;
+    const int nti = (min(ci_t, cin - ci0) + 31) >> 5;       // live 32-row tiles along the input channels
+    const int ntj = (min(co_t, cout - co0) + 31) >> 5;
+    const int ntiles = nti * ntj;
 
-    f32x16 acc[2];
+    // staging geometry: A rows hold ci_t floats (ci_t/4 float4), G rows co_t floats
+    const int a_v = ci_t >> 2, g_v = co_t >> 2;               // float4 per row
+    const int a_total = WG_RB * a_v, g_total = WG_RB * g_v;   // <= 1024 each  (<= 4 per thread)
+
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float4 pa[4], pg[4];
+
+    auto fetch = [&](int p0, int cnt) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int f = tid + h * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < a_total) {
+                const int j = f / a_v, c4 = f - j * a_v;
+                const int p = p0 + j, c = ci0 + c4 * 4;
+                if (p < cnt && c < cin) {
+                    const float* src = in + int64_t(list_i[p]) * cin + c;
+                    if (a_vec) v = *reinterpret_cast<const float4*>(src);
+                    else {
+                        v.x = src[0];
+                        if (c + 1 < cin) v.y = src[1];
+                        if (c + 2 < cin) v.z = src[2];
+                        if (c + 3 < cin) v.w = src[3];
+                    }
+                }
+            }
+            pa[h] = v;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < g_total) {
+                const int j = f / g_v, c4 = f - j * g_v;
+                const int p = p0 + j, c = co0 + c4 * 4;
+                if (p < cnt && c < cout) {
+                    const float* src = gout + int64_t(list_o[p]) * cout + c;
+                    if (g_vec) w = *reinterpret_cast<const float4*>(src);
+                    else {
+                        w.x = src[0];
+                        if (c + 1 < cout) w.y = src[1];
+                        if (c + 2 < cout) w.z = src[2];
+                        if (c + 3 < cout) w.w = src[3];
+                    }
+                }
+            }
+            pg[h] = w;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int f = tid + h * 256;
+            if (f < a_total) {
+                const int j = f / a_v, c4 = f - j * a_v;
+                *reinterpret_cast<float4*>(&As[j][c4 * 4]) = pa[h];
+            }
+            if (f < g_total) {
+                const int j = f / g_v, c4 = f - j * g_v;
+                *reinterpret_cast<float4*>(&Gs[j][c4 * 4]) = pg[h];
+            }
+        }
+    };
 
     for (int base = r_begin; base < r_end; base += WG_SUB) {
         // ---- compact the valid pairs of rows [base, base + WG_SUB)
@@ -231,74 +296,45 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float* __restri
             cnt += tot;
             __syncthreads();
         }
-        // ---- reduce the compacted pairs, WG_RB at a time
+        if (cnt == 0) continue;
+        // ---- pipelined reduction over the compacted pairs
+        fetch(0, cnt);
+        stash();
+        __syncthreads();
         for (int p0 = 0; p0 < cnt; p0 += WG_RB) {
-            {   // A: in[list_i[p0+j]][ci0 : ci0+64)   -- 16 rows x 16 float4 = one per thread
-                const int j = tid >> 4, c4 = tid & 15;
-                const int p = p0 + j;
-                const int c = ci0 + c4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p < cnt) {
-                    const float* src = in + int64_t(list_i[p]) * cin + c;
-                    if (a_vec) {
-                        if (c < cin) v = *reinterpret_cast<const float4*>(src);
-                    } else {
-                        if (c + 0 < cin) v.x = src[0];
-                        if (c + 1 < cin) v.y = src[1];
-                        if (c + 2 < cin) v.z = src[2];
-                        if (c + 3 < cin) v.w = src[3];
-                    }
-                }
-                *reinterpret_cast<float4*>(&As[j][c4 * 4]) = v;
-            }
+            const bool more = p0 + WG_RB < cnt;
+            if (more) fetch(p0 + WG_RB, cnt);            // loads in flight during the MFMAs below
+            const int kh = lane >> 5;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {  // G: gout[list_o[p0+j]][co0 : co0+128)  -- 16 rows x 32 float4
-                const int f = tid + h * 256;
-                const int j = f >> 5, c4 = f & 31;
-                const int p = p0 + j;
-                const int c = co0 + c4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p < cnt) {
-                    const float* src = gout + int64_t(list_o[p]) * cout + c;
-                    if (g_vec) {
-                        if (c < cout) v = *reinterpret_cast<const float4*>(src);
-                    } else {
-                        if (c + 0 < cout) v.x = src[0];
-                        if (c + 1 < cout) v.y = src[1];
-                        if (c + 2 < cout) v.z = src[2];
-                        if (c + 3 < cout) v.w = src[3];
-                    }
-                }
-                *reinterpret_cast<float4*>(&Gs[j][c4 * 4]) = v;
-            }
-            __syncthreads();
-            if (wave_on) {
-                const int kh = lane >> 5;
+            for (int t = 0; t < TPW; ++t) {
+                const int tile = wave + 4 * t;
+                if (tile < ntiles) {
+                    const int ti = tile / ntj, tj = tile - ti * ntj;
 #pragma unroll
-                for (int kk = 0; kk < WG_RB; kk += 2) {
-                    const float b = Gs[kk + kh][wave * 32 + (lane & 31)];
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        if (tile_on[t]) {
-                            const float a = As[kk + kh][t * 32 + (lane & 31)];
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-                        }
+                    for (int kk = 0; kk < WG_RB; kk += 2) {
+                        const float a = As[kk + kh][ti * 32 + (lane & 31)];
+                        const float b = Gs[kk + kh][tj * 32 + (lane & 31)];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
                     }
                 }
             }
+            __syncthreads();                              // everyone is done reading this stage
+            if (more) stash();
             __syncthreads();
         }
     }
 
     // ---- store: dst[(split, k)][ci][co]
     float* d = dst + (int64_t(blockIdx.y) * K + k) * cin * cout;
-    if (wave_on) {
-        const int co = co0 + wave * 32 + (lane & 31);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wave + 4 * t;
+        if (tile < ntiles) {
+            const int ti = tile / ntj, tj = tile - ti * ntj;
+            const int co = co0 + tj * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ci = ci0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int ci = ci0 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (ci < cin && co < cout) d[int64_t(ci) * cout + co] = acc[t][r];
             }
         }
@@ -347,13 +383,19 @@ static FwdPlan plan_fwd(int64_t n_out, int K, int cin, int cout) {
 }
 
 struct WgradPlan {
-    int n_ci, n_co, S, rps;
+    int ci_t, co_t, n_ci, n_co, tpw, S, rps;
 };
+
+static int pad32(int c) { return (c + 31) / 32 * 32; }
 
 static WgradPlan plan_wgrad(int64_t n_out, int K, int cin, int cout) {
     WgradPlan p;
-    p.n_ci = int(cdiv(cin, WG_CI));
-    p.n_co = int(cdiv(cout, WG_CO));
+    p.ci_t = pad32(cin) < WG_T ? pad32(cin) : WG_T;
+    p.co_t = pad32(cout) < WG_T ? pad32(cout) : WG_T;
+    p.n_ci = int(cdiv(cin, p.ci_t));
+    p.n_co = int(cdiv(cout, p.co_t));
+    const int tiles = (p.ci_t / 32) * (p.co_t / 32);
+    p.tpw = (tiles + 3) / 4;
     const int64_t base = int64_t(K) * p.n_ci * p.n_co;
     int64_t S = cdiv(1024, base);
     const int64_t smax = cdiv(n_out, 2 * WG_SUB);
@@ -485,8 +527,13 @@ extern "C" int osn_spconv_wgrad(const float* in, const float* gout, const int32_
         OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_spconv_wgrad: workspace %zu < %zu", ws_bytes, need);
         dst = static_cast<float*>(ws);
     }
-    hipLaunchKernelGGL(spconv_wgrad_kernel, dim3(p.n_ci * p.n_co, p.S, K), dim3(256), 0, st, in, gout, nbr, dst,
-                       int(n_out), K, cin, cout, p.rps, p.n_co);
+    const dim3 grid(p.n_ci * p.n_co, p.S, K), block(256);
+    switch (p.tpw) {
+        case 1: hipLaunchKernelGGL((spconv_wgrad_kernel<1>), grid, block, 0, st, in, gout, nbr, dst, int(n_out), K, cin, cout, p.rps, p.n_co, p.ci_t, p.co_t); break;
+        case 2: hipLaunchKernelGGL((spconv_wgrad_kernel<2>), grid, block, 0, st, in, gout, nbr, dst, int(n_out), K, cin, cout, p.rps, p.n_co, p.ci_t, p.co_t); break;
+        case 3: hipLaunchKernelGGL((spconv_wgrad_kernel<3>), grid, block, 0, st, in, gout, nbr, dst, int(n_out), K, cin, cout, p.rps, p.n_co, p.ci_t, p.co_t); break;
+        default: hipLaunchKernelGGL((spconv_wgrad_kernel<4>), grid, block, 0, st, in, gout, nbr, dst, int(n_out), K, cin, cout, p.rps, p.n_co, p.ci_t, p.co_t); break;
+    }
     OSN_LAUNCH_CHECK();
     if (p.S > 1) {
         int g = int(cdiv(wtotal, 256));

@@ -49,6 +49,7 @@ def _loss(model, seed):
 def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
     _install_cpu_backend()
     from openscene_amd.mink_unet import mink_unet
     dist.init_process_group("gloo", rank=rank, world_size=world)
