@@ -112,14 +112,27 @@ def init_params(arch="MinkUNet18A", in_channels=3, out_channels=20, seed=0, dtyp
     return p
 
 
-def unet_forward(p, feats, coords4, arch="MinkUNet18A", train=False, cm=None):
-    """models/mink_unet.py:116-174 on (feats [N,Cin], coords4 int32 [N,4]) -> [N, out]."""
+def unet_forward(p, feats, coords4, arch="MinkUNet18A", train=False, cm=None, relu_masks=None):
+    """models/mink_unet.py:116-174 on (feats [N,Cin], coords4 int32 [N,4]) -> [N, out].
+
+    relu_masks (optional): list of bool tensors, one per ReLU in call order.  When given, ReLU i
+    is evaluated as ``y * relu_masks[i]`` -- i.e. with a PRESCRIBED activation pattern.  Tests use
+    it to compare gradients of an fp32 run against this float64 oracle on the same pattern: a
+    pre-activation within fp32 rounding of zero legitimately flips its ReLU between precisions,
+    and one flipped element already moves a gradient's relative L2 error by ~1/sqrt(#elements)."""
     cm = cm or CoordinateManager(np.asarray(coords4))
     plan = layer_plan(arch)
+    masks = list(relu_masks) if relu_masks is not None else None
+
+    def act(y):
+        if masks is None:
+            return F.relu(y)
+        m = masks.pop(0)
+        return y * m.to(y.dtype)
 
     def bnrelu(x, name, relu=True):
         y = batch_norm(x, p, name + ".bn", train)
-        return F.relu(y) if relu else y
+        return act(y) if relu else y
 
     def block(x, bname, nblk, stride):
         t = cm.kmap(stride, stride, 3)
@@ -132,7 +145,7 @@ def unet_forward(p, feats, coords4, arch="MinkUNet18A", train=False, cm=None):
                 res = sparse_conv(x, p[pre + ".downsample.0.kernel"],
                                   np.arange(x.shape[0], dtype=np.int32)[None])
                 res = bnrelu(res, pre + ".downsample.1", relu=False)
-            x = F.relu(y + res)
+            x = act(y + res)
         return x
 
     x = bnrelu(sparse_conv(feats, p["conv0p1s1.kernel"], cm.kmap(1, 1, 5)), "bn0")

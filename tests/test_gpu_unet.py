@@ -3,8 +3,12 @@
 gradients, running statistics; the reference-shaped DisNet step; the ME alias.
 
 Stated tolerance: fp32 network vs float64 oracle, relative L2 error
-of the output <= 2e-4 and max |delta| <= 1e-3 * max |reference|; gradients rel-L2 <= 1e-3
-(BN in training mode amplifies rounding through 1/sigma)."""
+of the output <= 2e-4 and max |delta| <= 1e-3 * max |reference|; every parameter gradient
+rel-L2 <= 2e-4 ON THE SAME ReLU ACTIVATION PATTERN: a pre-activation within fp32 rounding of
+zero flips its ReLU between fp32 and float64 (any fp32 implementation does, a CPU fp32 run
+flips the same elements), and a single flipped element moves a gradient's relative L2 error by
+~1/sqrt(#elements) (2e-3 on these small scenes), so the oracle's backward is evaluated with the
+activation pattern of the run under test (at most a handful of elements differ; asserted)."""
 import numpy as np
 import pytest
 import torch
@@ -22,6 +26,27 @@ def dev():
 def rel_l2(got, ref):
     got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
     return ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+
+
+class record_relu_masks:
+    """Record (y > 0) of every fused BN(+residual)+ReLU call, in call order (= the oracle's ReLU order)."""
+
+    def __init__(self):
+        from openscene_amd import functional as F_
+        self.F_ = F_
+        self.real = F_.batch_norm_act
+        self.masks = []
+
+        def spy(x, bn, residual=None, relu=False):
+            y = self.real(x, bn, residual=residual, relu=relu)
+            if relu:
+                self.masks.append((y.detach() > 0).cpu())
+            return y
+        F_.batch_norm_act = spy
+
+    def stop(self):
+        self.F_.batch_norm_act = self.real
+        return self.masks
 
 
 def scene_coords(seed, n_pts, voxel, batch=1):
@@ -49,23 +74,29 @@ def test_unet_vs_oracle(arch, out_dim, train):
     for k, v in p.items():
         if "running" not in k:
             v.requires_grad_(True)
-    ref = so.unet_forward(p, feats.double(), coords, arch, train=train)
-    target = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
-    (ref * target).sum().backward()
+    free = so.unet_forward({k: v.detach().clone() for k, v in p.items()}, feats.double(), coords, arch, train=train)
 
     model = model.to(dev())
+    masks = record_relu_masks()
     out = model(SparseTensor(feats.to(dev()), torch.from_numpy(coords).to(dev())))
-    assert out.shape == ref.shape and out.dtype == torch.float32
-    e = rel_l2(out, ref)
+    masks = masks.stop()
+    assert out.shape == free.shape and out.dtype == torch.float32
+    e = rel_l2(out, free)
     assert e <= 2e-4, "output rel-L2 %.3e" % e
-    assert (out.double().cpu() - ref.detach()).abs().max().item() <= 1e-3 * ref.abs().max().item()
+    assert (out.double().cpu() - free.detach()).abs().max().item() <= 1e-3 * free.abs().max().item()
+
+    # float64 oracle on the activation pattern of the fp32 run (see module docstring)
+    ref = so.unet_forward(p, feats.double(), coords, arch, train=train, relu_masks=masks)
+    assert rel_l2(ref, free) <= 1e-6, "prescribing the fp32 activation pattern changed the oracle output"
+    target = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    (ref * target).sum().backward()
     (out * target.float().to(dev())).sum().backward()
     worst = ("", 0.0)
     for name, prm in model.named_parameters():
         g = rel_l2(prm.grad, p[name].grad)
         if g > worst[1]:
             worst = (name, g)
-    assert worst[1] <= 1e-3, "gradient of %s rel-L2 %.3e" % worst
+    assert worst[1] <= 2e-4, "gradient of %s rel-L2 %.3e" % worst
     if train:
         for name, buf in model.named_buffers():
             if "running" in name:
