@@ -79,6 +79,15 @@ int osn_kmap_build(const uint64_t* in_table_keys, const int32_t* in_table_vals, 
 int osn_kmap_transpose(const int32_t* nbr, int64_t n_out, int K, int64_t n_in, int32_t* tbl,
                        osn_stream_t stream);
 
+/* Tile-order optimisation (no reference counterpart; ME's GPU kernels are unordered):
+ * order[j] = output rows sorted (stably) by their offset-occupancy bit mask, and
+ * nbr_sorted[k, j] = nbr[k, order[j]].  Feed both to osn_spconv_fwd (nbr_sorted as the
+ * table, order as out_rows): rows of one tile then share their offsets and the per-tile
+ * offset skip removes the empty work; results are unchanged.  K <= 32.               */
+size_t osn_kmap_sort_ws_bytes(int64_t n_out);
+int osn_kmap_sort(const int32_t* nbr, int64_t n_out, int K, int32_t* order, int32_t* nbr_sorted,
+                  void* ws, size_t ws_bytes, osn_stream_t stream);
+
 /* counts[k] = #valid entries of nbr[k, :]  (int64 [K], device).                  */
 int osn_kmap_count(const int32_t* nbr, int64_t n_out, int K, int64_t* counts, osn_stream_t stream);
 

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(const float* __restrict
     __shared__ float As[BM][BK + 1];
     __shared__ __attribute__((aligned(16))) float Bs[BK][BN];
     __shared__ int rowidx[BM];
-    __shared__ int wflag[2][4];
+    __shared__ int gflag[2][4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -60,12 +60,21 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(const float* __restrict
             if (r < n_out) idx = nbr ? nbr[int64_t(k) * n_out + r] : r;
             rowidx[tid] = idx;
         }
-        // block-uniform vote (double-buffered flags: a wave is never more than one
-        // barrier ahead of the slowest one); the barrier also publishes rowidx
-        const int wave_any = __any(idx >= 0);
-        if (lane == 0) wflag[k & 1][wave] = wave_any;
+        // vote per 32-row group (double-buffered flags: a wave is never more than one barrier
+        // ahead of the slowest one); the barrier also publishes rowidx
+        {
+            const unsigned long long b = __ballot(idx >= 0);
+            if (lane == 0 && 2 * wave < WM) {
+                gflag[k & 1][2 * wave] = (b & 0xFFFFFFFFull) != 0;
+                if (2 * wave + 1 < WM) gflag[k & 1][2 * wave + 1] = (b >> 32) != 0;
+            }
+        }
         __syncthreads();
-        if (!(wflag[k & 1][0] | wflag[k & 1][1] | wflag[k & 1][2] | wflag[k & 1][3])) continue;
+        unsigned gm = 0;
+#pragma unroll
+        for (int g = 0; g < WM; ++g) gm |= (gflag[k & 1][g] ? 1u : 0u) << g;
+        if (gm == 0) continue;                 // no row of this tile uses offset k
+        const bool my_rows_on = (gm >> wm) & 1u;
 
         for (int c0 = 0; c0 < cin; c0 += BK) {
             // ---- gather the A tile: BM rows x BK input channels
@@ -74,6 +83,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(const float* __restrict
 #pragma unroll
                 for (int p = 0; p < BM / 32; ++p) {
                     const int row = p * 32 + r;
+                    if (!((gm >> p) & 1u)) continue;        // nobody will read this 32-row group
                     const int i = rowidx[row];
                     const int c = c0 + sub * 4;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -111,15 +121,17 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(const float* __restrict
             }
             __syncthreads();
             // ---- MFMA: lane l feeds A[row = l&31][kk + (l>>5)], B[kk + (l>>5)][col = l&31]
-            const int arow = wm * 32 + (lane & 31);
-            const int kh = lane >> 5;
+            if (my_rows_on) {
+                const int arow = wm * 32 + (lane & 31);
+                const int kh = lane >> 5;
 #pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
-                const float a = As[arow][kk + kh];
+                for (int kk = 0; kk < BK; kk += 2) {
+                    const float a = As[arow][kk + kh];
 #pragma unroll
-                for (int t = 0; t < TN; ++t) {
-                    const float b = Bs[kk + kh][(wn * TN + t) * 32 + (lane & 31)];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                    for (int t = 0; t < TN; ++t) {
+                        const float b = Bs[kk + kh][(wn * TN + t) * 32 + (lane & 31)];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                    }
                 }
             }
             __syncthreads();
@@ -127,6 +139,165 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(const float* __restrict
     }
 
     // ---- epilogue: C layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* dst = out;
+    if (to_partial) dst = out + int64_t(blockIdx.z) * n_out * cout;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int col = n0 + (wn * TN + t) * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < n_out && col < cout) {
+                const int orow = (!to_partial && out_rows) ? out_rows[row] : row;
+                dst[int64_t(orow) * cout + col] = acc[t][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Pipelined variant (the one that runs for every 2^3 / 3^3 kernel of the U-Net): the offsets
+// handled by the block (<= 32) are scanned once, the active ones are listed in LDS together
+// with their row indices, and the (offset, channel-chunk) stages then run as a software
+// pipeline: the gather + weight loads of stage s+1 are issued into registers before the MFMAs
+// of stage s and written to LDS after them (one barrier pair per stage, global-load latency
+// hidden behind 48-64 MFMAs per wave).
+template <int WM, int WN, int TN>
+__global__ __launch_bounds__(256) void spconv_fwd_pipe_kernel(const float* __restrict__ in, const float* __restrict__ W,
+                                                              const int32_t* __restrict__ nbr,
+                                                              const int32_t* __restrict__ out_rows,
+                                                              float* __restrict__ out, int n_out, int K, int cin,
+                                                              int cout, int k_per_split, int to_partial) {
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * TN * WN;
+    constexpr int BK = 32;
+    constexpr int KC = 32;                       // offsets cached per block
+    constexpr int NA = BM / 32;                  // A float4 per thread per stage
+    constexpr int BV = BN / 4;                   // float4 per B row
+    constexpr int NB = (BK * BV + 255) / 256;    // B float4 per thread per stage
+    __shared__ float As[BM][BK + 1];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][BN];
+    __shared__ int ridx[KC][BM];
+    __shared__ unsigned char gbits[KC][2];
+    __shared__ int klist[KC];
+    __shared__ int kgm[KC];
+    __shared__ int nact_s;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int row0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int k_begin = blockIdx.z * k_per_split;
+    const int nk = min(K, k_begin + k_per_split) - k_begin;     // <= KC
+
+    // ---- prologue: row indices + activity of every offset of this block
+    for (int kk = 0; kk < nk; ++kk) {
+        int idx = -1;
+        if (tid < BM) {
+            const int r = row0 + tid;
+            if (r < n_out) idx = nbr ? nbr[int64_t(k_begin + kk) * n_out + r] : r;
+            ridx[kk][tid] = idx;
+        }
+        const unsigned long long b = __ballot(idx >= 0);
+        if (lane == 0 && wave < 2)
+            gbits[kk][wave] = (unsigned char)(((b & 0xFFFFFFFFull) != 0 ? 1 : 0) | ((b >> 32) != 0 ? 2 : 0));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int kk = 0; kk < nk; ++kk) {
+            const int gm = int(gbits[kk][0]) | (int(gbits[kk][1]) << 2);
+            if (gm) { klist[n] = kk; kgm[n] = gm; ++n; }
+        }
+        nact_s = n;
+    }
+    __syncthreads();
+    const int nact = nact_s;
+    const int nchunk = (cin + BK - 1) / BK;
+    const int nstage = nact * nchunk;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float4 pa[NA], pb[NB];
+    const int a_sub = tid & 7, a_r = tid >> 3;
+
+    auto fetch = [&](int s) {
+        const int slot = s / nchunk, c0 = (s - slot * nchunk) * BK;
+        const int kk = klist[slot], gm = kgm[slot];
+        const int c = c0 + a_sub * 4;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((gm >> p) & 1) {
+                const int i = ridx[kk][p * 32 + a_r];
+                if (i >= 0 && c < cin) v = *reinterpret_cast<const float4*>(in + int64_t(i) * cin + c);
+            }
+            pa[p] = v;
+        }
+        const float* wk = W + int64_t(k_begin + kk) * cin * cout;
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+            const int f = tid + h * 256;
+            const int r = f / BV, c4 = f - r * BV;
+            const int cr = c0 + r, n = n0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < BK * BV && cr < cin && n < cout) v = *reinterpret_cast<const float4*>(wk + int64_t(cr) * cout + n);
+            pb[h] = v;
+        }
+    };
+    auto stash = [&](int s) {
+        const int slot = s / nchunk;
+        const int gm = kgm[slot];
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            if ((gm >> p) & 1) {
+                const int row = p * 32 + a_r;
+                As[row][a_sub * 4 + 0] = pa[p].x;
+                As[row][a_sub * 4 + 1] = pa[p].y;
+                As[row][a_sub * 4 + 2] = pa[p].z;
+                As[row][a_sub * 4 + 3] = pa[p].w;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+            const int f = tid + h * 256;
+            const int r = f / BV, c4 = f - r * BV;
+            if (f < BK * BV) *reinterpret_cast<float4*>(&Bs[r][c4 * 4]) = pb[h];
+        }
+    };
+
+    if (nstage > 0) {
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (int s = 0; s < nstage; ++s) {
+            const bool more = s + 1 < nstage;
+            if (more) fetch(s + 1);                                 // in flight during the MFMAs
+            const int slot = s / nchunk;
+            if ((kgm[slot] >> wm) & 1) {
+                const int arow = wm * 32 + (lane & 31);
+                const int kh = lane >> 5;
+#pragma unroll
+                for (int kk = 0; kk < BK; kk += 2) {
+                    const float a = As[arow][kk + kh];
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) {
+                        const float b = Bs[kk + kh][(wn * TN + t) * 32 + (lane & 31)];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+            if (more) stash(s + 1);
+            __syncthreads();
+        }
+    }
+
     float* dst = out;
     if (to_partial) dst = out + int64_t(blockIdx.z) * n_out * cout;
 #pragma unroll
@@ -431,6 +602,13 @@ extern "C" int osn_spconv_fwd_plan(int64_t n_out, int K, int cin, int cout, int3
     return OSN_OK;
 }
 
+template <int WM, int WN, int TN>
+static void launch_fwd_pipe(const FwdPlan& p, hipStream_t st, const float* in, const float* W, const int32_t* nbr,
+                            const int32_t* out_rows, float* dst, int n_out, int K, int cin, int cout) {
+    hipLaunchKernelGGL((spconv_fwd_pipe_kernel<WM, WN, TN>), dim3(p.gx, p.gy, p.S), dim3(256), 0, st, in, W, nbr,
+                       out_rows, dst, n_out, K, cin, cout, p.kps, p.S > 1 ? 1 : 0);
+}
+
 template <int WM, int WN, int TN, int BK>
 static void launch_fwd(const FwdPlan& p, hipStream_t st, const float* in, const float* W, const int32_t* nbr,
                        const int32_t* out_rows, float* dst, int n_out, int K, int cin, int cout) {
@@ -456,7 +634,18 @@ extern "C" int osn_spconv_fwd(const float* in, const float* W, const int32_t* nb
         dst = static_cast<float*>(ws);
     }
     const int n = int(n_out);
-    if (cin <= 4) {
+    const bool pipe = cin > 4 && (cin & 3) == 0 && (cout & 3) == 0 && p.kps <= 32;
+    if (pipe) {
+        switch (p.cfg * 10 + p.tn) {
+            case 1: launch_fwd_pipe<4, 1, 1>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 2: launch_fwd_pipe<4, 1, 2>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 3: launch_fwd_pipe<4, 1, 3>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 4: launch_fwd_pipe<4, 1, 4>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 11: launch_fwd_pipe<2, 2, 1>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 12: launch_fwd_pipe<2, 2, 2>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            default: launch_fwd_pipe<1, 4, 1>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+        }
+    } else if (cin <= 4) {
         // stem convolution (3 -> 32): 4-wide channel chunks
         switch (p.cfg * 10 + p.tn) {
             case 1: launch_fwd<4, 1, 1, 4>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;

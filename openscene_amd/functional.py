@@ -12,25 +12,30 @@ class SparseConvFunction(Function):
     MinkowskiConvolutionTransposeFunction).  kernel: [K, cin, cout], or [cin, cout] when K == 1."""
 
     @staticmethod
-    def forward(ctx, feats, kernel, nbr_fwd, nbr_bwd, flip, n_out):
+    def forward(ctx, feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tiles_fwd=None, tiles_bwd=None):
         ctx.save_for_backward(feats, kernel)
-        ctx.maps = (nbr_fwd, nbr_bwd, bool(flip))
+        ctx.maps = (nbr_fwd, nbr_bwd, bool(flip), tiles_bwd)
         ctx.n_in = feats.shape[0]
+        if tiles_fwd is not None:            # (order, row-permuted table): same result, tile-friendly order
+            return ops.spconv_fwd(feats, kernel, tiles_fwd[1], n_out, out_rows=tiles_fwd[0])
         return ops.spconv_fwd(feats, kernel, nbr_fwd, n_out)
 
     @staticmethod
     def backward(ctx, gout):
         feats, kernel = ctx.saved_tensors
-        nbr_fwd, nbr_bwd, flip = ctx.maps
+        nbr_fwd, nbr_bwd, flip, tiles_bwd = ctx.maps
         gout = gout.contiguous()
         gin = gk = None
         K = 1 if kernel.dim() == 2 else kernel.shape[0]
         if ctx.needs_input_grad[0]:
             wt = ops.weight_transpose(kernel, flip)
-            gin = ops.spconv_fwd(gout, wt, nbr_bwd, ctx.n_in)
+            if tiles_bwd is not None:
+                gin = ops.spconv_fwd(gout, wt, tiles_bwd[1], ctx.n_in, out_rows=tiles_bwd[0])
+            else:
+                gin = ops.spconv_fwd(gout, wt, nbr_bwd, ctx.n_in)
         if ctx.needs_input_grad[1]:
             gk = ops.spconv_wgrad(feats, gout, nbr_fwd, K).reshape(kernel.shape)
-        return gin, gk, None, None, None, None
+        return gin, gk, None, None, None, None, None, None
 
 
 class BatchNormActFunction(Function):
@@ -59,9 +64,11 @@ class BatchNormActFunction(Function):
         return gx, ggamma, gbeta, None, None, gres, None, None, None, None
 
 
-def sparse_conv(feats, kernel, maps, n_out):
+def sparse_conv(feats, kernel, maps, n_out, tiles=None):
+    """maps = CoordinateManager.kmap(...); tiles = CoordinateManager.kmap_tiles(...) or None."""
     nbr_fwd, nbr_bwd, flip = maps
-    return SparseConvFunction.apply(feats, kernel, nbr_fwd, nbr_bwd, flip, n_out)
+    tf, tb = tiles if tiles is not None else (None, None)
+    return SparseConvFunction.apply(feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tf, tb)
 
 
 def batch_norm_act(x, bn, residual=None, relu=False):

@@ -117,6 +117,22 @@ def kmap_transpose(nbr, n_in):
     return tbl
 
 
+def kmap_sort(nbr):
+    """-> (order int32 [n_out], nbr_sorted int32 [K, n_out]): rows ordered by offset-occupancy mask."""
+    dev = nbr.device
+    lib = _prep(dev)
+    nbr = nbr.contiguous()
+    K, n_out = nbr.shape
+    order = torch.empty(n_out, dtype=torch.int32, device=dev)
+    out = torch.empty_like(nbr)
+    with _Dev(dev):
+        wsb = lib.osn_kmap_sort_ws_bytes(n_out)
+        ws = _ws(wsb, dev)
+        check(lib.osn_kmap_sort(_p(nbr), n_out, K, _p(order), _p(out), _p(ws), ws.numel(), _stream(dev)),
+              "osn_kmap_sort")
+    return order, out
+
+
 def kmap_count(nbr):
     dev = nbr.device
     lib = _prep(dev)

@@ -87,6 +87,30 @@ class CoordinateManager:
         self._kmaps[key] = res
         return res
 
+    SORT_MIN_ROWS = 8192      # below this the launch is latency-bound and the sort does not pay
+
+    def kmap_tiles(self, in_stride, out_stride, ksize, dilation=1):
+        """Tile-ordered variants of kmap(): ((order, table) for the forward conv or None,
+        (order, table) for the input gradient or None).  Rows are ordered by their
+        offset-occupancy mask (ops.kmap_sort) so the conv kernel's per-tile offset skip bites;
+        features keep the caller's row order (the permutation rides along as `out_rows`)."""
+        key = ("tiles", in_stride, out_stride, ksize, dilation)
+        hit = self._kmaps.get(key)
+        if hit is not None:
+            return hit
+        fwd, bwd, flip = self.kmap(in_stride, out_stride, ksize, dilation)
+
+        def tiles(tbl):
+            if tbl is None or tbl.shape[0] > 32 or tbl.shape[1] < self.SORT_MIN_ROWS:
+                return None
+            return ops.kmap_sort(tbl)
+
+        tf = tiles(fwd)
+        tb = tf if (bwd is fwd) else tiles(bwd)
+        res = (tf, tb)
+        self._kmaps[key] = res
+        return res
+
 
 class SparseTensor:
     """features float32 [N, C] + int32 coordinates [N, 4] (batch, x, y, z) on one device."""

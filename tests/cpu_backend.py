@@ -47,6 +47,13 @@ def kmap_transpose(nbr, n_in):
     return torch.from_numpy(oc.transpose_table(_np(nbr), int(n_in)))
 
 
+def kmap_sort(nbr):
+    K = nbr.shape[0]
+    mask = ((nbr >= 0).long() << torch.arange(K).reshape(K, 1)).sum(0)
+    order = torch.from_numpy(np.argsort(mask.numpy(), kind="stable").astype(np.int32))
+    return order, nbr[:, order.long()].contiguous()
+
+
 def kmap_count(nbr):
     return (nbr >= 0).sum(1).long()
 
@@ -149,7 +156,7 @@ def fnv_hash(grid):
     return torch.from_numpy(ov.fnv_keys(_np(grid)).view(np.int64))
 
 
-_NAMES = ["HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_count", "spconv_fwd", "weight_transpose",
+_NAMES = ["HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_transpose",
           "spconv_wgrad", "bn_stats", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
           "fnv_hash"]
 

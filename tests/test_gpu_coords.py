@@ -123,3 +123,30 @@ def test_determinism_and_empty_and_range():
     bad = torch.tensor([[0, 1, 2, 3], [0, 40000, 0, 0]], dtype=torch.int32, device=dev())
     with pytest.raises(_lib.OpenSceneAmdError):
         ops.coords_unique(bad, 1)
+
+
+def test_kmap_sort_bit_exact_and_skip_efficiency():
+    """osn_kmap_sort == stable argsort of the occupancy mask; on S100k it brings the active offsets
+    per 128-row tile from 27 (hash order) to <= 16."""
+    from openscene_amd import ops
+    from openscene_amd.sparse import CoordinateManager
+    c = s100k()
+    cm = CoordinateManager(torch.from_numpy(c).to(dev()))
+    for (si, so_, k) in [(1, 1, 3), (2, 2, 3), (1, 2, 2), (2, 1, 2)]:
+        nbr = cm.kmap(si, so_, k)[0]
+        order, tbl = ops.kmap_sort(nbr)
+        want_order, want_tbl = cpu_backend.kmap_sort(nbr.cpu())
+        assert torch.equal(order.cpu(), want_order) and torch.equal(tbl.cpu(), want_tbl)
+    nbr = cm.kmap(1, 1, 3)[0]
+    order, tbl = ops.kmap_sort(nbr)
+
+    def active(t):
+        v = (t >= 0).cpu().numpy()
+        n = v.shape[1] // 128 * 128
+        return v[:, :n].reshape(27, -1, 128).any(2).sum(0).mean()
+    assert active(nbr) > 26.5 and active(tbl) <= 16.0
+    up = cm.kmap(2, 1, 2)[0]                      # transposed k2s2 table: one offset per row -> one per tile
+    _, tup = ops.kmap_sort(up)
+    v = (tup >= 0).cpu().numpy()
+    n = v.shape[1] // 128 * 128
+    assert v[:, :n].reshape(8, -1, 128).any(2).sum(0).mean() < 1.2

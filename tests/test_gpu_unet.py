@@ -161,3 +161,31 @@ def test_unfused_module_chain_equals_fused():
     bn.bn.running_mean.zero_(); bn.bn.running_var.fill_(1)
     fused = blk(y)
     assert rel_l2(z.F, fused.F) < 1e-6
+
+
+def test_tile_ordered_maps_bitwise_identical():
+    """Mask-ordered tiles are a scheduling change only: the fp32 result is BITWISE the same
+    (per output row the accumulation order over offsets and channels does not change)."""
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import CoordinateManager, SparseTensor
+    torch.manual_seed(4)
+    model = mink_unet(3, 32, 3, "MinkUNet18A").to(dev())
+    coords = torch.from_numpy(scene_coords(41, 30000, 0.03)).to(dev())       # ~25 k voxels: above the sort threshold
+    feats = torch.rand(coords.shape[0], 3, device=dev())
+    outs = []
+    old = CoordinateManager.SORT_MIN_ROWS
+    try:
+        for min_rows in (10 ** 9, 0):
+            CoordinateManager.SORT_MIN_ROWS = min_rows
+            model.zero_grad()
+            for m in model.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.reset_running_stats()
+            out = model(SparseTensor(feats, coords))
+            out.square().mean().backward()
+            outs.append((out.detach().clone(), model.block8[0].conv1.kernel.grad.clone(),
+                         model.conv0p1s1.kernel.grad.clone()))
+    finally:
+        CoordinateManager.SORT_MIN_ROWS = old
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])

@@ -194,3 +194,27 @@ def test_reference_model_file_runs_unchanged(cpu_ops, monkeypatch):
     for name in [m for m in sys.modules if m == "MinkowskiEngine" or m.startswith("MinkowskiEngine.")
                  or m == "models" or m.startswith("models.")]:
         monkeypatch.delitem(sys.modules, name)
+
+
+def test_tile_ordered_maps_do_not_change_results(cpu_ops, monkeypatch):
+    """kmap_tiles (rows ordered by offset-occupancy mask + out_rows indirection) is a pure
+    scheduling change: forward and every gradient are identical with and without it."""
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import CoordinateManager, SparseTensor
+    torch.manual_seed(5)
+    model = mink_unet(3, 8, 3, "MinkUNet14A").double()
+    coords = cloud(9)
+    feats = torch.rand(coords.shape[0], 3, dtype=torch.float64)
+    res = []
+    for min_rows in (10 ** 9, 0):
+        monkeypatch.setattr(CoordinateManager, "SORT_MIN_ROWS", min_rows)
+        model.zero_grad()
+        st = SparseTensor(feats, coords)
+        out = model(st)
+        out.square().sum().backward()
+        used = [k for k, v in st.coordinate_manager._kmaps.items() if k[0] == "tiles" and any(t is not None for t in v)]
+        res.append((out.detach().clone(), [p.grad.clone() for p in model.parameters()], used))
+    assert not res[0][2] and len(res[1][2]) >= 9          # 5 stride-1 maps + 4 down + 4 up tables
+    assert torch.allclose(res[0][0], res[1][0], atol=1e-12)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.allclose(a, b, atol=1e-10 * (1 + a.abs().max().item()))
