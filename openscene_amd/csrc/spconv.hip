@@ -386,15 +386,23 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float* __restri
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     float4 pa[4], pg[4];
+    // loop-invariant staging coordinates of this thread's four A / four G float4 slots
+    int aj[4], ac[4], gj[4], gc[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int f = tid + h * 256;
+        aj[h] = f < a_total ? f / a_v : -1;
+        ac[h] = f < a_total ? (f - aj[h] * a_v) * 4 : 0;
+        gj[h] = f < g_total ? f / g_v : -1;
+        gc[h] = f < g_total ? (f - gj[h] * g_v) * 4 : 0;
+    }
 
     auto fetch = [&](int p0, int cnt) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const int f = tid + h * 256;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < a_total) {
-                const int j = f / a_v, c4 = f - j * a_v;
-                const int p = p0 + j, c = ci0 + c4 * 4;
+            if (aj[h] >= 0) {
+                const int p = p0 + aj[h], c = ci0 + ac[h];
                 if (p < cnt && c < cin) {
                     const float* src = in + int64_t(list_i[p]) * cin + c;
                     if (a_vec) v = *reinterpret_cast<const float4*>(src);
@@ -408,9 +416,8 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float* __restri
             }
             pa[h] = v;
             float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < g_total) {
-                const int j = f / g_v, c4 = f - j * g_v;
-                const int p = p0 + j, c = co0 + c4 * 4;
+            if (gj[h] >= 0) {
+                const int p = p0 + gj[h], c = co0 + gc[h];
                 if (p < cnt && c < cout) {
                     const float* src = gout + int64_t(list_o[p]) * cout + c;
                     if (g_vec) w = *reinterpret_cast<const float4*>(src);
@@ -428,15 +435,8 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float* __restri
     auto stash = [&]() {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const int f = tid + h * 256;
-            if (f < a_total) {
-                const int j = f / a_v, c4 = f - j * a_v;
-                *reinterpret_cast<float4*>(&As[j][c4 * 4]) = pa[h];
-            }
-            if (f < g_total) {
-                const int j = f / g_v, c4 = f - j * g_v;
-                *reinterpret_cast<float4*>(&Gs[j][c4 * 4]) = pg[h];
-            }
+            if (aj[h] >= 0) *reinterpret_cast<float4*>(&As[aj[h]][ac[h]]) = pa[h];
+            if (gj[h] >= 0) *reinterpret_cast<float4*>(&Gs[gj[h]][gc[h]]) = pg[h];
         }
     };
 
