@@ -115,10 +115,13 @@ int osn_weight_transpose(const float* W, int K, int cin, int cout, int flip, flo
                          osn_stream_t stream);
 
 /* gW[k] = sum_{o : nbr[k,o] >= 0} in[nbr[k,o], :]^T (x) gout[o, :]   ([K, cin, cout]).
- * Deterministic: fixed split of the row range, partial sums reduced in order.    */
+ * counts (nullable, device int64 [K], = osn_kmap_count of nbr): pair count per offset, used
+ * to split each offset's rows into work items of equal pair count on the device (the centre
+ * offset of a 3^3 map holds 19 % of the pairs, a corner offset < 1 %).  Deterministic: the
+ * split is a pure function of (counts, sizes); partial sums are reduced in item order.     */
 size_t osn_spconv_wgrad_ws_bytes(int64_t n_out, int K, int cin, int cout);
-int osn_spconv_wgrad(const float* in, const float* gout, const int32_t* nbr, float* gW,
-                     int64_t n_out, int K, int cin, int cout,
+int osn_spconv_wgrad(const float* in, const float* gout, const int32_t* nbr, const int64_t* counts,
+                     float* gW, int64_t n_out, int K, int cin, int cout,
                      void* ws, size_t ws_bytes, osn_stream_t stream);
 
 /* ---- batch norm (+ReLU, +residual) -------------------------------------- *

@@ -31,7 +31,7 @@ PROTOTYPES = {
     "osn_spconv_fwd_plan": (_i32, [_i64, _i32, _i32, _i32, _c.POINTER(_i32)]),
     "osn_weight_transpose": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "osn_spconv_wgrad_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
-    "osn_spconv_wgrad": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "osn_spconv_wgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "osn_bn_ws_bytes": (_sz, [_i64, _i32]),
     "osn_bn_stats": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _sz, _vp]),
     "osn_bn_apply": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _i64, _i32, _vp]),

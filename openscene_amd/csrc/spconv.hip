@@ -226,8 +226,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_pipe_kernel(const float* __res
     float4 pa[NA], pb[NB];
     const int a_sub = tid & 7, a_r = tid >> 3;
 
-    auto fetch = [&](int s) {
-        const int slot = s / nchunk, c0 = (s - slot * nchunk) * BK;
+    auto fetch = [&](int slot, int c0) {
         const int kk = klist[slot], gm = kgm[slot];
         const int c = c0 + a_sub * 4;
 #pragma unroll
@@ -250,8 +249,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_pipe_kernel(const float* __res
             pb[h] = v;
         }
     };
-    auto stash = [&](int s) {
-        const int slot = s / nchunk;
+    auto stash = [&](int slot) {
         const int gm = kgm[slot];
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
@@ -272,13 +270,15 @@ __global__ __launch_bounds__(256) void spconv_fwd_pipe_kernel(const float* __res
     };
 
     if (nstage > 0) {
-        fetch(0);
+        fetch(0, 0);
         stash(0);
         __syncthreads();
+        int slot = 0, ch = 0;                                       // current stage = (slot, channel chunk ch)
         for (int s = 0; s < nstage; ++s) {
             const bool more = s + 1 < nstage;
-            if (more) fetch(s + 1);                                 // in flight during the MFMAs
-            const int slot = s / nchunk;
+            int nslot = slot, nch = ch + 1;
+            if (nch == nchunk) { nch = 0; ++nslot; }
+            if (more) fetch(nslot, nch * BK);                       // in flight during the MFMAs
             if ((kgm[slot] >> wm) & 1) {
                 const int arow = wm * 32 + (lane & 31);
                 const int kh = lane >> 5;
@@ -293,8 +293,10 @@ __global__ __launch_bounds__(256) void spconv_fwd_pipe_kernel(const float* __res
                 }
             }
             __syncthreads();
-            if (more) stash(s + 1);
+            if (more) stash(nslot);
             __syncthreads();
+            slot = nslot;
+            ch = nch;
         }
     }
 
@@ -356,8 +358,8 @@ constexpr int WG_SUB = 1024;   // rows compacted at a time
 template <int TPW>   // 32x32 tiles per wave (1..4)
 __global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                            const int32_t* __restrict__ nbr, float* __restrict__ dst,
-                                                           int n_out, int K, int cin, int cout, int rows_per_split,
-                                                           int n_co_blocks, int ci_t, int co_t) {
+                                                           const int* __restrict__ items, int n_out, int K, int cin,
+                                                           int cout, int n_co_blocks, int ci_t, int co_t) {
     __shared__ __attribute__((aligned(16))) float As[WG_RB][WG_T];
     __shared__ __attribute__((aligned(16))) float Gs[WG_RB][WG_T];
     __shared__ int list_o[WG_SUB];
@@ -367,9 +369,11 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci0 = (blockIdx.x / n_co_blocks) * ci_t;
     const int co0 = (blockIdx.x % n_co_blocks) * co_t;
-    const int k = blockIdx.z;
-    const int r_begin = blockIdx.y * rows_per_split;
-    const int r_end = min(n_out, r_begin + rows_per_split);
+    // work item = (kernel offset, row range); items are balanced by pair count on the device
+    const int k = items[blockIdx.y * 4 + 0];
+    if (k < 0) return;
+    const int r_begin = items[blockIdx.y * 4 + 1];
+    const int r_end = items[blockIdx.y * 4 + 2];
     const bool a_vec = (cin & 3) == 0, g_vec = (cout & 3) == 0;
     const int nti = (min(ci_t, cin - ci0) + 31) >> 5;       // live 32-row tiles along the input channels
     const int ntj = (min(co_t, cout - co0) + 31) >> 5;
@@ -495,8 +499,8 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float* __restri
         }
     }
 
-    // ---- store: dst[(split, k)][ci][co]
-    float* d = dst + (int64_t(blockIdx.y) * K + k) * cin * cout;
+    // ---- store: dst[item][ci][co]
+    float* d = dst + int64_t(blockIdx.y) * cin * cout;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int tile = wave + 4 * t;
@@ -509,6 +513,70 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float* __restri
                 if (ci < cin && co < cout) d[int64_t(ci) * cout + co] = acc[t][r];
             }
         }
+    }
+}
+
+// One block: split every offset's row range into a number of items proportional to its pair
+// count (count_k = n_out when `counts` is null), at most T items in total.  items[t] =
+// (k, row_begin, row_end, 0), k = -1 for unused slots; range[k] = (first item, last item + 1).
+__global__ __launch_bounds__(256) void wgrad_plan_kernel(const long long* __restrict__ counts, int n_out, int K, int T,
+                                                         int min_rows, int* __restrict__ items, int* __restrict__ range) {
+    __shared__ long long total_s;
+    __shared__ int sk[128];
+    __shared__ int start[129];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        long long tot = 0;
+        for (int k = 0; k < K; ++k) tot += counts ? counts[k] : (long long)n_out;
+        total_s = tot;
+    }
+    __syncthreads();
+    const long long total = total_s;
+    long long quota = (T > K) ? (total + (T - K) - 1) / (T - K) : total;
+    if (quota < 1) quota = 1;
+    const int max_s = max(1, (n_out + min_rows - 1) / min_rows);
+    if (tid < K) {
+        const long long c = counts ? counts[tid] : (long long)n_out;
+        int sp = c > 0 ? int((c + quota - 1) / quota) : 0;
+        if (sp > max_s) sp = max_s;
+        sk[tid] = sp;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int k = 0; k < K; ++k) { start[k] = acc; acc += sk[k]; }
+        start[K] = acc;
+    }
+    __syncthreads();
+    if (tid < K) {
+        range[2 * tid] = start[tid];
+        range[2 * tid + 1] = start[tid + 1];
+    }
+    const int used = start[K];
+    for (int t = tid; t < T; t += 256) {
+        int k = -1, rb = 0, re = 0;
+        if (t < used) {
+            // offset of item t: the last k with start[k] <= t  (K <= 125: linear scan)
+            k = 0;
+            while (k + 1 < K && start[k + 1] <= t) ++k;
+            const int j = t - start[k], sp = sk[k];
+            const long long rows = n_out;
+            rb = int(rows * j / sp);
+            re = int(rows * (j + 1) / sp);
+        }
+        items[4 * t + 0] = k; items[4 * t + 1] = rb; items[4 * t + 2] = re; items[4 * t + 3] = 0;
+    }
+}
+
+__global__ void reduce_items_kernel(const float* __restrict__ partial, const int* __restrict__ range, int K,
+                                    int64_t per_k, float* __restrict__ out) {
+    const int64_t total = int64_t(K) * per_k;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        const int k = int(e / per_k);
+        const int64_t r = e - int64_t(k) * per_k;
+        float s = 0.f;
+        for (int t = range[2 * k]; t < range[2 * k + 1]; ++t) s += partial[int64_t(t) * per_k + r];
+        out[e] = s;
     }
 }
 
@@ -554,7 +622,8 @@ static FwdPlan plan_fwd(int64_t n_out, int K, int cin, int cout) {
 }
 
 struct WgradPlan {
-    int ci_t, co_t, n_ci, n_co, tpw, S, rps;
+    int ci_t, co_t, n_ci, n_co, tpw, T, min_rows;
+    size_t items_bytes, partial_bytes;
 };
 
 static int pad32(int c) { return (c + 31) / 32 * 32; }
@@ -567,15 +636,16 @@ static WgradPlan plan_wgrad(int64_t n_out, int K, int cin, int cout) {
     p.n_co = int(cdiv(cout, p.co_t));
     const int tiles = (p.ci_t / 32) * (p.co_t / 32);
     p.tpw = (tiles + 3) / 4;
-    const int64_t base = int64_t(K) * p.n_ci * p.n_co;
-    int64_t S = cdiv(1024, base);
-    const int64_t smax = cdiv(n_out, 2 * WG_SUB);
-    if (S > smax) S = smax;
-    if (S > 64) S = 64;
-    if (S < 1) S = 1;
-    p.rps = int(cdiv(cdiv(n_out, S), WG_SUB) * WG_SUB);
-    p.S = int(cdiv(n_out, p.rps));
-    if (p.S < 1) p.S = 1;
+    p.min_rows = 512;
+    // ~1024 workgroups per launch (4 per CU), but never more items than the rows can feed
+    int64_t T = cdiv(1024, int64_t(p.n_ci) * p.n_co);
+    const int64_t tmax = int64_t(K) * cdiv(n_out, p.min_rows);
+    if (T > tmax) T = tmax;
+    if (T < K) T = K;
+    if (T > 4096) T = 4096;
+    p.T = int(T);
+    p.items_bytes = align_up(size_t(p.T) * 16 + size_t(K) * 8, 256);
+    p.partial_bytes = size_t(p.T) * size_t(cin) * size_t(cout) * 4;
     return p;
 }
 
@@ -693,14 +763,15 @@ extern "C" int osn_weight_transpose(const float* W, int K, int cin, int cout, in
 extern "C" size_t osn_spconv_wgrad_ws_bytes(int64_t n_out, int K, int cin, int cout) {
     if (n_out <= 0) return 0;
     WgradPlan p = plan_wgrad(n_out, K, cin, cout);
-    return p.S > 1 ? size_t(p.S) * size_t(K) * size_t(cin) * size_t(cout) * 4 : 0;
+    return p.items_bytes + p.partial_bytes;
 }
 
-extern "C" int osn_spconv_wgrad(const float* in, const float* gout, const int32_t* nbr, float* gW, int64_t n_out, int K,
-                                int cin, int cout, void* ws, size_t ws_bytes, osn_stream_t stream) {
+extern "C" int osn_spconv_wgrad(const float* in, const float* gout, const int32_t* nbr, const int64_t* counts, float* gW,
+                                int64_t n_out, int K, int cin, int cout, void* ws, size_t ws_bytes,
+                                osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_spconv_wgrad: n_out out of range");
-    OSN_REQUIRE(K >= 1 && cin >= 1 && cout >= 1 && gW, OSN_E_ARG, "osn_spconv_wgrad: bad arguments");
+    OSN_REQUIRE(K >= 1 && K <= 125 && cin >= 1 && cout >= 1 && gW, OSN_E_ARG, "osn_spconv_wgrad: bad arguments");
     const int64_t wtotal = int64_t(K) * cin * cout;
     if (n_out == 0) {
         OSN_HIP(hipMemsetAsync(gW, 0, size_t(wtotal) * 4, st));
@@ -710,25 +781,24 @@ extern "C" int osn_spconv_wgrad(const float* in, const float* gout, const int32_
     OSN_REQUIRE(nbr || K == 1, OSN_E_ARG, "osn_spconv_wgrad: nbr may be null only for K == 1");
     OSN_REQUIRE(aligned16(in) && aligned16(gout) && aligned16(gW), OSN_E_ARG, "osn_spconv_wgrad: pointers must be 16-byte aligned");
     WgradPlan p = plan_wgrad(n_out, K, cin, cout);
-    float* dst = gW;
-    if (p.S > 1) {
-        const size_t need = size_t(p.S) * size_t(wtotal) * 4;
-        OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_spconv_wgrad: workspace %zu < %zu", ws_bytes, need);
-        dst = static_cast<float*>(ws);
-    }
-    const dim3 grid(p.n_ci * p.n_co, p.S, K), block(256);
+    OSN_REQUIRE(ws && ws_bytes >= p.items_bytes + p.partial_bytes, OSN_E_WS, "osn_spconv_wgrad: workspace %zu < %zu",
+                ws_bytes, p.items_bytes + p.partial_bytes);
+    int* items = static_cast<int*>(ws);
+    int* range = items + size_t(p.T) * 4;
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + p.items_bytes);
+    hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const long long*>(counts),
+                       int(n_out), K, p.T, p.min_rows, items, range);
+    const dim3 grid(p.n_ci * p.n_co, p.T), block(256);
     switch (p.tpw) {
-        case 1: hipLaunchKernelGGL((spconv_wgrad_kernel<1>), grid, block, 0, st, in, gout, nbr, dst, int(n_out), K, cin, cout, p.rps, p.n_co, p.ci_t, p.co_t); break;
-        case 2: hipLaunchKernelGGL((spconv_wgrad_kernel<2>), grid, block, 0, st, in, gout, nbr, dst, int(n_out), K, cin, cout, p.rps, p.n_co, p.ci_t, p.co_t); break;
-        case 3: hipLaunchKernelGGL((spconv_wgrad_kernel<3>), grid, block, 0, st, in, gout, nbr, dst, int(n_out), K, cin, cout, p.rps, p.n_co, p.ci_t, p.co_t); break;
-        default: hipLaunchKernelGGL((spconv_wgrad_kernel<4>), grid, block, 0, st, in, gout, nbr, dst, int(n_out), K, cin, cout, p.rps, p.n_co, p.ci_t, p.co_t); break;
+        case 1: hipLaunchKernelGGL((spconv_wgrad_kernel<1>), grid, block, 0, st, in, gout, nbr, partial, items, int(n_out), K, cin, cout, p.n_co, p.ci_t, p.co_t); break;
+        case 2: hipLaunchKernelGGL((spconv_wgrad_kernel<2>), grid, block, 0, st, in, gout, nbr, partial, items, int(n_out), K, cin, cout, p.n_co, p.ci_t, p.co_t); break;
+        case 3: hipLaunchKernelGGL((spconv_wgrad_kernel<3>), grid, block, 0, st, in, gout, nbr, partial, items, int(n_out), K, cin, cout, p.n_co, p.ci_t, p.co_t); break;
+        default: hipLaunchKernelGGL((spconv_wgrad_kernel<4>), grid, block, 0, st, in, gout, nbr, partial, items, int(n_out), K, cin, cout, p.n_co, p.ci_t, p.co_t); break;
     }
     OSN_LAUNCH_CHECK();
-    if (p.S > 1) {
-        int g = int(cdiv(wtotal, 256));
-        if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(reduce_partial_flat_kernel, dim3(g), dim3(256), 0, st, dst, p.S, wtotal, gW);
-        OSN_LAUNCH_CHECK();
-    }
+    int g = int(cdiv(wtotal, 256));
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(reduce_items_kernel, dim3(g), dim3(256), 0, st, partial, range, K, int64_t(cin) * cout, gW);
+    OSN_LAUNCH_CHECK();
     return OSN_OK;
 }

@@ -12,9 +12,9 @@ class SparseConvFunction(Function):
     MinkowskiConvolutionTransposeFunction).  kernel: [K, cin, cout], or [cin, cout] when K == 1."""
 
     @staticmethod
-    def forward(ctx, feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tiles_fwd=None, tiles_bwd=None):
+    def forward(ctx, feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tiles_fwd=None, tiles_bwd=None, counts=None):
         ctx.save_for_backward(feats, kernel)
-        ctx.maps = (nbr_fwd, nbr_bwd, bool(flip), tiles_bwd)
+        ctx.maps = (nbr_fwd, nbr_bwd, bool(flip), tiles_bwd, counts)
         ctx.n_in = feats.shape[0]
         if tiles_fwd is not None:            # (order, row-permuted table): same result, tile-friendly order
             return ops.spconv_fwd(feats, kernel, tiles_fwd[1], n_out, out_rows=tiles_fwd[0])
@@ -23,7 +23,7 @@ class SparseConvFunction(Function):
     @staticmethod
     def backward(ctx, gout):
         feats, kernel = ctx.saved_tensors
-        nbr_fwd, nbr_bwd, flip, tiles_bwd = ctx.maps
+        nbr_fwd, nbr_bwd, flip, tiles_bwd, counts = ctx.maps
         gout = gout.contiguous()
         gin = gk = None
         K = 1 if kernel.dim() == 2 else kernel.shape[0]
@@ -34,8 +34,8 @@ class SparseConvFunction(Function):
             else:
                 gin = ops.spconv_fwd(gout, wt, nbr_bwd, ctx.n_in)
         if ctx.needs_input_grad[1]:
-            gk = ops.spconv_wgrad(feats, gout, nbr_fwd, K).reshape(kernel.shape)
-        return gin, gk, None, None, None, None, None, None
+            gk = ops.spconv_wgrad(feats, gout, nbr_fwd, K, counts).reshape(kernel.shape)
+        return gin, gk, None, None, None, None, None, None, None
 
 
 class BatchNormActFunction(Function):
@@ -64,11 +64,11 @@ class BatchNormActFunction(Function):
         return gx, ggamma, gbeta, None, None, gres, None, None, None, None
 
 
-def sparse_conv(feats, kernel, maps, n_out, tiles=None):
-    """maps = CoordinateManager.kmap(...); tiles = CoordinateManager.kmap_tiles(...) or None."""
+def sparse_conv(feats, kernel, maps, n_out, tiles=None, counts=None):
+    """maps = CoordinateManager.kmap(...); tiles = .kmap_tiles(...) or None; counts = .kmap_counts(...) or None."""
     nbr_fwd, nbr_bwd, flip = maps
     tf, tb = tiles if tiles is not None else (None, None)
-    return SparseConvFunction.apply(feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tf, tb)
+    return SparseConvFunction.apply(feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tf, tb, counts)
 
 
 def batch_norm_act(x, bn, residual=None, relu=False):

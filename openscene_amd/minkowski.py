@@ -81,7 +81,8 @@ class MinkowskiConvolutionBase(nn.Module):
             s_out = s_in * self.stride
         maps = cm.kmap(s_in, s_out, self.kernel_size, self.dilation)
         tiles = cm.kmap_tiles(s_in, s_out, self.kernel_size, self.dilation)
-        out = F_.sparse_conv(x.F, self.kernel, maps, cm.size(s_out), tiles)
+        counts = cm.kmap_counts(s_in, s_out, self.kernel_size, self.dilation) if self.kernel.requires_grad else None
+        out = F_.sparse_conv(x.F, self.kernel, maps, cm.size(s_out), tiles, counts)
         if self.bias is not None:
             out = out + self.bias
         return SparseTensor(out, tensor_stride=s_out, coordinate_manager=cm)

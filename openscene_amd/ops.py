@@ -188,7 +188,7 @@ def weight_transpose(weight, flip):
     return wt
 
 
-def spconv_wgrad(feats, gout, nbr, K):
+def spconv_wgrad(feats, gout, nbr, K, counts=None):
     dev = feats.device
     lib = _prep(dev)
     feats = _f32c(feats, "features")
@@ -205,8 +205,8 @@ def spconv_wgrad(feats, gout, nbr, K):
     tok = _profiler.start("spconv_wgrad", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
         if _profiler is not None else None
     with _Dev(dev):
-        check(lib.osn_spconv_wgrad(_p(feats), _p(gout), _p(nbr), _p(gw), n_out, K, cin, cout, _p(ws), int(wsb),
-                                   _stream(dev)), "osn_spconv_wgrad")
+        check(lib.osn_spconv_wgrad(_p(feats), _p(gout), _p(nbr), _p(counts), _p(gw), n_out, K, cin, cout, _p(ws),
+                                   int(wsb), _stream(dev)), "osn_spconv_wgrad")
     if tok is not None:
         _profiler.stop(tok)
     return gw

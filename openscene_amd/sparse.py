@@ -87,6 +87,15 @@ class CoordinateManager:
         self._kmaps[key] = res
         return res
 
+    def kmap_counts(self, in_stride, out_stride, ksize, dilation=1):
+        """int64 [K] pair count per offset of the forward table (device), or None for K == 1;
+        lets the weight-gradient kernel balance its work items."""
+        key = ("counts", in_stride, out_stride, ksize, dilation)
+        if key not in self._kmaps:
+            fwd = self.kmap(in_stride, out_stride, ksize, dilation)[0]
+            self._kmaps[key] = ops.kmap_count(fwd) if fwd is not None else None
+        return self._kmaps[key]
+
     SORT_MIN_ROWS = 8192      # below this the launch is latency-bound and the sort does not pay
 
     def kmap_tiles(self, in_stride, out_stride, ksize, dilation=1):

@@ -81,7 +81,7 @@ def weight_transpose(weight, flip):
     return w.transpose(1, 2).contiguous()
 
 
-def spconv_wgrad(feats, gout, nbr, K):
+def spconv_wgrad(feats, gout, nbr, K, counts=None):
     n_out = gout.shape[0]
     if nbr is None:
         nbr = torch.arange(n_out, dtype=torch.int32)[None]

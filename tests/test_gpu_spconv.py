@@ -129,6 +129,11 @@ def test_out_rows_indirection_and_determinism():
     ga = ops.spconv_wgrad(feats, a, nbr, 27)
     gb = ops.spconv_wgrad(feats, a, nbr, 27)
     assert torch.equal(ga, gb), "weight gradient is not bitwise reproducible"
+    cnt = ops.kmap_count(nbr)
+    gc = ops.spconv_wgrad(feats, a, nbr, 27, cnt)            # pair-count-balanced work items
+    gd = ops.spconv_wgrad(feats, a, nbr, 27, cnt)
+    assert torch.equal(gc, gd), "balanced weight gradient is not bitwise reproducible"
+    assert (gc - ga).abs().max().item() <= 1e-5 * ga.abs().max().item()
 
 
 def test_known_answer_cases():

@@ -40,11 +40,14 @@ def main():
         g = torch.randn(n, cout, device=dev)
         t_fwd_sorted = timed(lambda: ops.spconv_fwd(x, w, tbl, n, out_rows=order), reps)
         t_fwd_plain = timed(lambda: ops.spconv_fwd(x, w, nbr, n), reps)
-        t_wgrad = timed(lambda: ops.spconv_wgrad(x, g, nbr, 27), reps)
+        cnt = ops.kmap_count(nbr)
+        t_wgrad = timed(lambda: ops.spconv_wgrad(x, g, nbr, 27, cnt), reps)
+        t_wgrad_u = timed(lambda: ops.spconv_wgrad(x, g, nbr, 27), reps)
         fl = 2.0 * pairs * cin * cout
         print("stride %d  N=%d pairs=%d  %d->%d : fwd(tile-ordered) %.1f us = %.1f TF exact | fwd(hash order) %.1f us | "
-              "wgrad %.1f us = %.1f TF" % (stride, n, pairs, cin, cout, t_fwd_sorted, fl / t_fwd_sorted / 1e6,
-                                           t_fwd_plain, t_wgrad, fl / t_wgrad / 1e6))
+              "wgrad(balanced) %.1f us = %.1f TF | wgrad(uniform) %.1f us" % (
+                  stride, n, pairs, cin, cout, t_fwd_sorted, fl / t_fwd_sorted / 1e6, t_fwd_plain, t_wgrad,
+                  fl / t_wgrad / 1e6, t_wgrad_u))
 
 
 if __name__ == "__main__":
