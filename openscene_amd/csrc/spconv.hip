@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(const float* __restrict
 // of stage s and written to LDS after them (one barrier pair per stage, global-load latency
 // hidden behind 48-64 MFMAs per wave).
 template <int WM, int WN, int TN>
-__global__ __launch_bounds__(256) void spconv_fwd_pipe_kernel(const float* __restrict__ in, const float* __restrict__ W,
+__global__ __launch_bounds__(256, 2) void spconv_fwd_pipe_kernel(const float* __restrict__ in, const float* __restrict__ W,
                                                               const int32_t* __restrict__ nbr,
                                                               const int32_t* __restrict__ out_rows,
                                                               float* __restrict__ out, int n_out, int K, int cin,
@@ -172,13 +172,13 @@ __global__ __launch_bounds__(256) void spconv_fwd_pipe_kernel(const float* __res
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * TN * WN;
     constexpr int BK = 32;
-    constexpr int KC = 32;                       // offsets cached per block
+    constexpr int KC = 32;                       // offsets per block (k_per_split <= KC)
     constexpr int NA = BM / 32;                  // A float4 per thread per stage
     constexpr int BV = BN / 4;                   // float4 per B row
     constexpr int NB = (BK * BV + 255) / 256;    // B float4 per thread per stage
     __shared__ float As[BM][BK + 1];
     __shared__ __attribute__((aligned(16))) float Bs[BK][BN];
-    __shared__ int ridx[KC][BM];
+    __shared__ int ridx[2][BM];                  // row indices of the next two stages (by stage parity)
     __shared__ unsigned char gbits[KC][2];
     __shared__ int klist[KC];
     __shared__ int kgm[KC];
@@ -190,18 +190,23 @@ __global__ __launch_bounds__(256) void spconv_fwd_pipe_kernel(const float* __res
     const int n0 = blockIdx.y * BN;
     const int k_begin = blockIdx.z * k_per_split;
     const int nk = min(K, k_begin + k_per_split) - k_begin;     // <= KC
+    const int my_row = row0 + tid;                               // meaningful for tid < BM
+    const bool row_ok = tid < BM && my_row < n_out;
 
-    // ---- prologue: row indices + activity of every offset of this block
-    for (int kk = 0; kk < nk; ++kk) {
-        int idx = -1;
-        if (tid < BM) {
-            const int r = row0 + tid;
-            if (r < n_out) idx = nbr ? nbr[int64_t(k_begin + kk) * n_out + r] : r;
-            ridx[kk][tid] = idx;
+    // ---- prologue: which offsets does this tile use, and which of its 32-row groups
+    for (int kk0 = 0; kk0 < nk; kk0 += 8) {
+        int idx[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            idx[j] = -1;
+            if (row_ok && kk0 + j < nk) idx[j] = nbr ? nbr[int64_t(k_begin + kk0 + j) * n_out + my_row] : my_row;
         }
-        const unsigned long long b = __ballot(idx >= 0);
-        if (lane == 0 && wave < 2)
-            gbits[kk][wave] = (unsigned char)(((b & 0xFFFFFFFFull) != 0 ? 1 : 0) | ((b >> 32) != 0 ? 2 : 0));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned long long b = __ballot(idx[j] >= 0);
+            if (lane == 0 && wave < 2 && kk0 + j < nk)
+                gbits[kk0 + j][wave] = (unsigned char)(((b & 0xFFFFFFFFull) != 0 ? 1 : 0) | ((b >> 32) != 0 ? 2 : 0));
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -226,14 +231,19 @@ __global__ __launch_bounds__(256) void spconv_fwd_pipe_kernel(const float* __res
     float4 pa[NA], pb[NB];
     const int a_sub = tid & 7, a_r = tid >> 3;
 
-    auto fetch = [&](int slot, int c0) {
+    // row index of this thread's row for the offset of list slot `slot` (coalesced 4-byte loads)
+    auto load_idx = [&](int slot) -> int {
+        if (!row_ok) return -1;
+        return nbr ? nbr[int64_t(k_begin + klist[slot]) * n_out + my_row] : my_row;
+    };
+    auto fetch = [&](int slot, int c0, int par) {
         const int kk = klist[slot], gm = kgm[slot];
         const int c = c0 + a_sub * 4;
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((gm >> p) & 1) {
-                const int i = ridx[kk][p * 32 + a_r];
+                const int i = ridx[par][p * 32 + a_r];
                 if (i >= 0 && c < cin) v = *reinterpret_cast<const float4*>(in + int64_t(i) * cin + c);
             }
             pa[p] = v;
@@ -270,15 +280,23 @@ __global__ __launch_bounds__(256) void spconv_fwd_pipe_kernel(const float* __res
     };
 
     if (nstage > 0) {
-        fetch(0, 0);
-        stash(0);
+        // stage s = (slot, chunk); stage s+1 = (slot1, ch1); stage s+2 = (slot2, ch2)
+        int slot = 0, ch = 0;
+        int slot1 = 0, ch1 = 1;
+        if (ch1 == nchunk) { ch1 = 0; slot1 = 1; }
+        if (tid < BM) ridx[0][tid] = load_idx(0);
         __syncthreads();
-        int slot = 0, ch = 0;                                       // current stage = (slot, channel chunk ch)
+        fetch(0, 0, 0);
+        const int i1 = (nstage > 1) ? load_idx(slot1) : -1;
+        stash(0);
+        if (tid < BM) ridx[1][tid] = i1;
+        __syncthreads();
         for (int s = 0; s < nstage; ++s) {
-            const bool more = s + 1 < nstage;
-            int nslot = slot, nch = ch + 1;
-            if (nch == nchunk) { nch = 0; ++nslot; }
-            if (more) fetch(nslot, nch * BK);                       // in flight during the MFMAs
+            const bool more = s + 1 < nstage, more2 = s + 2 < nstage;
+            int slot2 = slot1, ch2 = ch1 + 1;
+            if (ch2 == nchunk) { ch2 = 0; ++slot2; }
+            if (more) fetch(slot1, ch1 * BK, (s + 1) & 1);            // loads in flight during the MFMAs
+            const int i2 = more2 ? load_idx(slot2) : -1;
             if ((kgm[slot] >> wm) & 1) {
                 const int arow = wm * 32 + (lane & 31);
                 const int kh = lane >> 5;
@@ -292,11 +310,12 @@ __global__ __launch_bounds__(256) void spconv_fwd_pipe_kernel(const float* __res
                     }
                 }
             }
+            __syncthreads();                  // stage s consumed; ridx[s&1] free (its fetch was issued an iteration ago)
+            if (more) stash(slot1);
+            if (more2 && tid < BM) ridx[s & 1][tid] = i2;     // indices of stage s+2 reuse stage s' slot
             __syncthreads();
-            if (more) stash(nslot);
-            __syncthreads();
-            slot = nslot;
-            ch = nch;
+            slot = slot1; ch = ch1;
+            slot1 = slot2; ch1 = ch2;
         }
     }
 
@@ -356,7 +375,7 @@ constexpr int WG_RB = 32;      // pairs per stage
 constexpr int WG_SUB = 1024;   // rows compacted at a time
 
 template <int TPW>   // 32x32 tiles per wave (1..4)
-__global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+__global__ __launch_bounds__(256, 2) void spconv_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                            const int32_t* __restrict__ nbr, float* __restrict__ dst,
                                                            const int* __restrict__ items, int n_out, int K, int cin,
                                                            int cout, int n_co_blocks, int ci_t, int co_t) {
