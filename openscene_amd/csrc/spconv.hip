@@ -231,32 +231,31 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_pipe_kernel(const float* __
     float4 pa[NA], pb[NB];
     const int a_sub = tid & 7, a_r = tid >> 3;
 
-    // row index of this thread's row for the offset of list slot `slot` (coalesced 4-byte loads)
-    auto load_idx = [&](int slot) -> int {
-        if (!row_ok) return -1;
-        return nbr ? nbr[int64_t(k_begin + klist[slot]) * n_out + my_row] : my_row;
-    };
+    // All loads below are UNCONDITIONAL (invalid lanes read a clamped, valid address and the value
+    // is zeroed when it is written to LDS): straight-line code, so the compiler keeps the loads in
+    // flight across the MFMA block instead of draining them at a control-flow join.
+    unsigned pa_ok = 0, pb_ok = 0;
     auto fetch = [&](int slot, int c0, int par) {
         const int kk = klist[slot], gm = kgm[slot];
         const int c = c0 + a_sub * 4;
+        pa_ok = 0;
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((gm >> p) & 1) {
-                const int i = ridx[par][p * 32 + a_r];
-                if (i >= 0 && c < cin) v = *reinterpret_cast<const float4*>(in + int64_t(i) * cin + c);
-            }
-            pa[p] = v;
+            const int i = ridx[par][p * 32 + a_r];
+            const bool ok = ((gm >> p) & 1) && i >= 0 && c < cin;
+            pa[p] = *reinterpret_cast<const float4*>(in + (ok ? int64_t(i) * cin + c : 0));
+            pa_ok |= (ok ? 1u : 0u) << p;
         }
         const float* wk = W + int64_t(k_begin + kk) * cin * cout;
+        pb_ok = 0;
 #pragma unroll
         for (int h = 0; h < NB; ++h) {
             const int f = tid + h * 256;
             const int r = f / BV, c4 = f - r * BV;
             const int cr = c0 + r, n = n0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < BK * BV && cr < cin && n < cout) v = *reinterpret_cast<const float4*>(wk + int64_t(cr) * cout + n);
-            pb[h] = v;
+            const bool ok = f < BK * BV && cr < cin && n < cout;
+            pb[h] = *reinterpret_cast<const float4*>(ok ? wk + int64_t(cr) * cout + n : W);
+            pb_ok |= (ok ? 1u : 0u) << h;
         }
     };
     auto stash = [&](int slot) {
@@ -265,38 +264,54 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_pipe_kernel(const float* __
         for (int p = 0; p < NA; ++p) {
             if ((gm >> p) & 1) {
                 const int row = p * 32 + a_r;
-                As[row][a_sub * 4 + 0] = pa[p].x;
-                As[row][a_sub * 4 + 1] = pa[p].y;
-                As[row][a_sub * 4 + 2] = pa[p].z;
-                As[row][a_sub * 4 + 3] = pa[p].w;
+                const bool ok = (pa_ok >> p) & 1;
+                As[row][a_sub * 4 + 0] = ok ? pa[p].x : 0.f;
+                As[row][a_sub * 4 + 1] = ok ? pa[p].y : 0.f;
+                As[row][a_sub * 4 + 2] = ok ? pa[p].z : 0.f;
+                As[row][a_sub * 4 + 3] = ok ? pa[p].w : 0.f;
             }
         }
 #pragma unroll
         for (int h = 0; h < NB; ++h) {
             const int f = tid + h * 256;
             const int r = f / BV, c4 = f - r * BV;
-            if (f < BK * BV) *reinterpret_cast<float4*>(&Bs[r][c4 * 4]) = pb[h];
+            if (f < BK * BV) {
+                const bool ok = (pb_ok >> h) & 1;
+                float4 v = pb[h];
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&Bs[r][c4 * 4]) = v;
+            }
         }
     };
 
     if (nstage > 0) {
-        // stage s = (slot, chunk); stage s+1 = (slot1, ch1); stage s+2 = (slot2, ch2)
+        // stage s = (slot, chunk ch).  Gathered rows + weights are fetched one stage ahead into
+        // registers; the row indices of stage s+2 are fetched during stage s.  That index load is
+        // issued through inline asm: hipcc's waitcnt pass otherwise drains every load in flight
+        // around a loop-carried load destination (vmcnt is in-order), which serialises the prefetch.
+        // The value is consumed in the same iteration, after an explicit vmcnt(0).
+        auto advance = [&](int& sl, int& c) { if (++c == nchunk) { c = 0; ++sl; } };
         int slot = 0, ch = 0;
-        int slot1 = 0, ch1 = 1;
-        if (ch1 == nchunk) { ch1 = 0; slot1 = 1; }
-        if (tid < BM) ridx[0][tid] = load_idx(0);
+        int slot1 = 0, ch1 = 0; advance(slot1, ch1);
+        int slot2 = slot1, ch2 = ch1; advance(slot2, ch2);
+        auto idx_ptr = [&](int sl) -> const int32_t* {
+            return nbr + (row_ok ? int64_t(k_begin + klist[sl]) * n_out + my_row : 0);
+        };
+        if (tid < BM) ridx[0][tid] = row_ok ? (nbr ? *idx_ptr(0) : my_row) : -1;
         __syncthreads();
         fetch(0, 0, 0);
-        const int i1 = (nstage > 1) ? load_idx(slot1) : -1;
+        const int i1 = nbr ? *idx_ptr(nstage > 1 ? slot1 : 0) : my_row;
         stash(0);
-        if (tid < BM) ridx[1][tid] = i1;
+        if (tid < BM) ridx[1][tid] = row_ok ? i1 : -1;
         __syncthreads();
         for (int s = 0; s < nstage; ++s) {
             const bool more = s + 1 < nstage, more2 = s + 2 < nstage;
-            int slot2 = slot1, ch2 = ch1 + 1;
-            if (ch2 == nchunk) { ch2 = 0; ++slot2; }
             if (more) fetch(slot1, ch1 * BK, (s + 1) & 1);            // loads in flight during the MFMAs
-            const int i2 = more2 ? load_idx(slot2) : -1;
+            int i2 = my_row;
+            if (nbr) {
+                const int32_t* p2 = idx_ptr(more2 ? slot2 : slot);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(i2) : "v"(p2) : "memory");
+            }
             if ((kgm[slot] >> wm) & 1) {
                 const int arow = wm * 32 + (lane & 31);
                 const int kh = lane >> 5;
@@ -310,12 +325,14 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_pipe_kernel(const float* __
                     }
                 }
             }
-            __syncthreads();                  // stage s consumed; ridx[s&1] free (its fetch was issued an iteration ago)
+            __syncthreads();                  // stage s consumed; ridx[s&1] is free (its fetch ran an iteration ago)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // covers the asm index load above
             if (more) stash(slot1);
-            if (more2 && tid < BM) ridx[s & 1][tid] = i2;     // indices of stage s+2 reuse stage s' slot
+            if (more2 && tid < BM) ridx[s & 1][tid] = row_ok ? i2 : -1;       // stage s+2 reuses stage s' slot
             __syncthreads();
             slot = slot1; ch = ch1;
             slot1 = slot2; ch1 = ch2;
+            advance(slot2, ch2);
         }
     }
 
@@ -374,7 +391,7 @@ constexpr int WG_T = 128;      // max tile edge (input / output channels per blo
 constexpr int WG_RB = 32;      // pairs per stage
 constexpr int WG_SUB = 1024;   // rows compacted at a time
 
-template <int TPW>   // 32x32 tiles per wave (1..4)
+template <int TPW, bool AVEC, bool GVEC>   // 32x32 tiles per wave (1..4); 16-byte loads possible for in / gout rows
 __global__ __launch_bounds__(256, 2) void spconv_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                            const int32_t* __restrict__ nbr, float* __restrict__ dst,
                                                            const int* __restrict__ items, int n_out, int K, int cin,
@@ -383,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_kernel(const float* __res
     __shared__ __attribute__((aligned(16))) float Gs[WG_RB][WG_T];
     __shared__ int list_o[WG_SUB];
     __shared__ int list_i[WG_SUB];
-    __shared__ int wcnt[4];
+    __shared__ int wcnt[WG_SUB / 256][4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci0 = (blockIdx.x / n_co_blocks) * ci_t;
@@ -393,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_kernel(const float* __res
     if (k < 0) return;
     const int r_begin = items[blockIdx.y * 4 + 1];
     const int r_end = items[blockIdx.y * 4 + 2];
-    const bool a_vec = (cin & 3) == 0, g_vec = (cout & 3) == 0;
+    constexpr bool a_vec = AVEC, g_vec = GVEC;
     const int nti = (min(ci_t, cin - ci0) + 31) >> 5;       // live 32-row tiles along the input channels
     const int ntj = (min(co_t, cout - co0) + 31) >> 5;
     const int ntiles = nti * ntj;
@@ -420,76 +437,103 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_kernel(const float* __res
         gc[h] = f < g_total ? (f - gj[h] * g_v) * 4 : 0;
     }
 
+    // Vector path: unconditional loads from clamped addresses (zeroed at LDS-write time) so that the
+    // prefetch stays in flight across the MFMA block; the scalar path (channels % 4 != 0) keeps guards.
+    unsigned a_ok = 0, g_ok = 0;
     auto fetch = [&](int p0, int cnt) {
+        a_ok = 0; g_ok = 0;
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (aj[h] >= 0) {
-                const int p = p0 + aj[h], c = ci0 + ac[h];
-                if (p < cnt && c < cin) {
-                    const float* src = in + int64_t(list_i[p]) * cin + c;
-                    if (a_vec) v = *reinterpret_cast<const float4*>(src);
-                    else {
+            {
+                const int p = p0 + max(aj[h], 0), c = ci0 + ac[h];
+                const bool ok = aj[h] >= 0 && p < cnt && c < cin;
+                if (a_vec) {
+                    pa[h] = *reinterpret_cast<const float4*>(in + (ok ? int64_t(list_i[p]) * cin + c : 0));
+                } else {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) {
+                        const float* src = in + int64_t(list_i[p]) * cin + c;
                         v.x = src[0];
                         if (c + 1 < cin) v.y = src[1];
                         if (c + 2 < cin) v.z = src[2];
                         if (c + 3 < cin) v.w = src[3];
                     }
+                    pa[h] = v;
                 }
+                a_ok |= (ok ? 1u : 0u) << h;
             }
-            pa[h] = v;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gj[h] >= 0) {
-                const int p = p0 + gj[h], c = co0 + gc[h];
-                if (p < cnt && c < cout) {
-                    const float* src = gout + int64_t(list_o[p]) * cout + c;
-                    if (g_vec) w = *reinterpret_cast<const float4*>(src);
-                    else {
+            {
+                const int p = p0 + max(gj[h], 0), c = co0 + gc[h];
+                const bool ok = gj[h] >= 0 && p < cnt && c < cout;
+                if (g_vec) {
+                    pg[h] = *reinterpret_cast<const float4*>(gout + (ok ? int64_t(list_o[p]) * cout + c : 0));
+                } else {
+                    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) {
+                        const float* src = gout + int64_t(list_o[p]) * cout + c;
                         w.x = src[0];
                         if (c + 1 < cout) w.y = src[1];
                         if (c + 2 < cout) w.z = src[2];
                         if (c + 3 < cout) w.w = src[3];
                     }
+                    pg[h] = w;
                 }
+                g_ok |= (ok ? 1u : 0u) << h;
             }
-            pg[h] = w;
         }
     };
     auto stash = [&]() {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            if (aj[h] >= 0) *reinterpret_cast<float4*>(&As[aj[h]][ac[h]]) = pa[h];
-            if (gj[h] >= 0) *reinterpret_cast<float4*>(&Gs[gj[h]][gc[h]]) = pg[h];
+            // element-wise selects (a struct-level `c ? pa[h] : z` makes the arrays address-taken -> scratch)
+            const bool oa = (a_ok >> h) & 1, og = (g_ok >> h) & 1;
+            float4 va, vg;
+            va.x = oa ? pa[h].x : 0.f; va.y = oa ? pa[h].y : 0.f; va.z = oa ? pa[h].z : 0.f; va.w = oa ? pa[h].w : 0.f;
+            vg.x = og ? pg[h].x : 0.f; vg.y = og ? pg[h].y : 0.f; vg.z = og ? pg[h].z : 0.f; vg.w = og ? pg[h].w : 0.f;
+            if (aj[h] >= 0) *reinterpret_cast<float4*>(&As[aj[h]][ac[h]]) = va;
+            if (gj[h] >= 0) *reinterpret_cast<float4*>(&Gs[gj[h]][gc[h]]) = vg;
         }
     };
 
     for (int base = r_begin; base < r_end; base += WG_SUB) {
-        // ---- compact the valid pairs of rows [base, base + WG_SUB)
+        // ---- compact the valid pairs of rows [base, base + WG_SUB): all table loads first
+        // (unconditional, clamped), then one ballot round and two barriers for the whole chunk
+        constexpr int NJ = WG_SUB / 256;
+        int iv[NJ];
+        bool vv[NJ];
+        unsigned long long mm[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int o = base + j * 256 + tid;
+            const bool in_range = o < r_end;
+            iv[j] = nbr ? nbr[int64_t(k) * n_out + (in_range ? o : r_begin)] : o;
+            vv[j] = in_range;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            vv[j] = vv[j] && iv[j] >= 0;
+            mm[j] = __ballot(vv[j]);
+            if (lane == 0) wcnt[j][wave] = __popcll(mm[j]);
+        }
+        __syncthreads();
         int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < WG_SUB / 256; ++j) {
-            const int o = base + j * 256 + tid;
-            int i = -1;
-            if (o < r_end) i = nbr ? nbr[int64_t(k) * n_out + o] : o;
-            const bool valid = i >= 0;
-            const unsigned long long m = __ballot(valid);
-            if (lane == 0) wcnt[wave] = __popcll(m);
-            __syncthreads();
+        for (int j = 0; j < NJ; ++j) {
             int woff = 0, tot = 0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const int c = wcnt[w];
+                const int c = wcnt[j][w];
                 if (w < wave) woff += c;
                 tot += c;
             }
-            if (valid) {
-                const int pos = cnt + woff + __popcll(m & ((1ull << lane) - 1ull));
-                list_o[pos] = o;
-                list_i[pos] = i;
+            if (vv[j]) {
+                const int pos = cnt + woff + __popcll(mm[j] & ((1ull << lane) - 1ull));
+                list_o[pos] = base + j * 256 + tid;
+                list_i[pos] = iv[j];
             }
             cnt += tot;
-            __syncthreads();
         }
+        __syncthreads();
         if (cnt == 0) continue;
         // ---- pipelined reduction over the compacted pairs
         fetch(0, cnt);
@@ -808,12 +852,25 @@ extern "C" int osn_spconv_wgrad(const float* in, const float* gout, const int32_
     hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const long long*>(counts),
                        int(n_out), K, p.T, p.min_rows, items, range);
     const dim3 grid(p.n_ci * p.n_co, p.T), block(256);
+    const bool av = (cin & 3) == 0, gv = (cout & 3) == 0;
+#define OSN_WG(T_, A_, G_)                                                                                          \
+    hipLaunchKernelGGL((spconv_wgrad_kernel<T_, A_, G_>), grid, block, 0, st, in, gout, nbr, partial, items, int(n_out), K, \
+                       cin, cout, p.n_co, p.ci_t, p.co_t)
+#define OSN_WG_T(T_)                                     \
+    do {                                                 \
+        if (av && gv) OSN_WG(T_, true, true);            \
+        else if (av) OSN_WG(T_, true, false);            \
+        else if (gv) OSN_WG(T_, false, true);            \
+        else OSN_WG(T_, false, false);                   \
+    } while (0)
     switch (p.tpw) {
-        case 1: hipLaunchKernelGGL((spconv_wgrad_kernel<1>), grid, block, 0, st, in, gout, nbr, partial, items, int(n_out), K, cin, cout, p.n_co, p.ci_t, p.co_t); break;
-        case 2: hipLaunchKernelGGL((spconv_wgrad_kernel<2>), grid, block, 0, st, in, gout, nbr, partial, items, int(n_out), K, cin, cout, p.n_co, p.ci_t, p.co_t); break;
-        case 3: hipLaunchKernelGGL((spconv_wgrad_kernel<3>), grid, block, 0, st, in, gout, nbr, partial, items, int(n_out), K, cin, cout, p.n_co, p.ci_t, p.co_t); break;
-        default: hipLaunchKernelGGL((spconv_wgrad_kernel<4>), grid, block, 0, st, in, gout, nbr, partial, items, int(n_out), K, cin, cout, p.n_co, p.ci_t, p.co_t); break;
+        case 1: OSN_WG_T(1); break;
+        case 2: OSN_WG_T(2); break;
+        case 3: OSN_WG_T(3); break;
+        default: OSN_WG_T(4); break;
     }
+#undef OSN_WG_T
+#undef OSN_WG
     OSN_LAUNCH_CHECK();
     int g = int(cdiv(wtotal, 256));
     if (g > 4096) g = 4096;
