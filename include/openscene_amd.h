@@ -71,7 +71,8 @@ int osn_coords_unique(const int32_t* coords4, int64_t n, int stride,
  * multiplied by `offset_scale` (= dilation * tensor stride of the INPUT map).  */
 int osn_kmap_build(const uint64_t* in_table_keys, const int32_t* in_table_vals, int64_t cap,
                    const int32_t* out_coords4, int64_t n_out, int ksize, int offset_scale,
-                   int32_t* nbr, osn_stream_t stream);
+                   int32_t* nbr, int64_t* counts /* nullable: int64 [K] pairs per offset */,
+                   osn_stream_t stream);
 
 /* tbl[k, i] = o  <=>  nbr[k, o] = i : the map of the transposed operator
  * ([ME] MinkowskiConvolutionTranspose, models/mink_unet.py:77-78,84-85,91-92,98-99,

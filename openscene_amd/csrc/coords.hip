@@ -171,19 +171,24 @@ __global__ void table_renumber_kernel(int32_t* __restrict__ vals, const int32_t*
 // ------------------------------------------------------------ kernel maps ----
 __global__ void kmap_build_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals, uint32_t mask,
                                   const int4* __restrict__ out_coords, int64_t n_out, int ksize, int scale,
-                                  int32_t* __restrict__ nbr) {
+                                  int32_t* __restrict__ nbr, unsigned long long* __restrict__ counts) {
     const int64_t o = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const int k = blockIdx.y;
-    if (o >= n_out) return;
-    const int ix = k % ksize, iy = (k / ksize) % ksize, iz = k / (ksize * ksize);
-    const int c = (ksize & 1) ? ksize / 2 : 0;
-    const int4 p = out_coords[o];
-    const int x = p.y + (ix - c) * scale, y = p.z + (iy - c) * scale, z = p.w + (iz - c) * scale;
-    const int lim = COORD_BIAS - 1;
     int r = -1;
-    if (x >= -lim && x <= lim && y >= -lim && y <= lim && z >= -lim && z <= lim)
-        r = table_find(keys, vals, mask, pack_key(p.x, x, y, z));
-    nbr[int64_t(k) * n_out + o] = r;
+    if (o < n_out) {
+        const int ix = k % ksize, iy = (k / ksize) % ksize, iz = k / (ksize * ksize);
+        const int c = (ksize & 1) ? ksize / 2 : 0;
+        const int4 p = out_coords[o];
+        const int x = p.y + (ix - c) * scale, y = p.z + (iy - c) * scale, z = p.w + (iz - c) * scale;
+        const int lim = COORD_BIAS - 1;
+        if (x >= -lim && x <= lim && y >= -lim && y <= lim && z >= -lim && z <= lim)
+            r = table_find(keys, vals, mask, pack_key(p.x, x, y, z));
+        nbr[int64_t(k) * n_out + o] = r;
+    }
+    if (counts) {                                   // pairs per offset: one atomic per workgroup
+        const int c = __syncthreads_count(r >= 0);
+        if (threadIdx.x == 0 && c) atomicAdd(&counts[k], (unsigned long long)c);
+    }
 }
 
 __global__ void kmap_transpose_kernel(const int32_t* __restrict__ nbr, int64_t n_out, int64_t n_in,
@@ -200,9 +205,14 @@ __global__ void kmap_count_kernel(const int32_t* __restrict__ nbr, int64_t n_out
     int64_t c = 0;
     for (int64_t o = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; o < n_out; o += int64_t(gridDim.x) * blockDim.x)
         c += nbr[int64_t(k) * n_out + o] >= 0;
-    // wave reduce
+    __shared__ long long wsum[4];
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[k], (unsigned long long)c);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (t) atomicAdd(&counts[k], (unsigned long long)t);
+    }
 }
 
 }  // namespace osn
@@ -288,18 +298,20 @@ extern "C" int osn_coords_unique(const int32_t* coords4, int64_t n, int stride, 
 
 extern "C" int osn_kmap_build(const uint64_t* in_table_keys, const int32_t* in_table_vals, int64_t cap,
                               const int32_t* out_coords4, int64_t n_out, int ksize, int offset_scale, int32_t* nbr,
-                              osn_stream_t stream) {
+                              int64_t* counts, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(ksize >= 1 && ksize <= 7, OSN_E_ARG, "osn_kmap_build: ksize=%d unsupported", ksize);
     OSN_REQUIRE(cap >= 2 && (cap & (cap - 1)) == 0, OSN_E_ARG, "osn_kmap_build: cap must be a power of two");
     OSN_REQUIRE(n_out >= 0, OSN_E_ARG, "osn_kmap_build: n_out < 0");
+    if (counts) OSN_HIP(hipMemsetAsync(counts, 0, size_t(ksize) * ksize * ksize * 8, st));
     if (n_out == 0) return OSN_OK;
     OSN_REQUIRE(in_table_keys && in_table_vals && out_coords4 && nbr, OSN_E_ARG, "osn_kmap_build: null pointer");
     OSN_REQUIRE(aligned16(out_coords4), OSN_E_ARG, "osn_kmap_build: out_coords4 must be 16-byte aligned");
     const int K = ksize * ksize * ksize;
     const int T = 256;
     hipLaunchKernelGGL(kmap_build_kernel, dim3(cdiv(n_out, T), K), dim3(T), 0, st, in_table_keys, in_table_vals,
-                       uint32_t(cap - 1), reinterpret_cast<const int4*>(out_coords4), n_out, ksize, offset_scale, nbr);
+                       uint32_t(cap - 1), reinterpret_cast<const int4*>(out_coords4), n_out, ksize, offset_scale, nbr,
+                       reinterpret_cast<unsigned long long*>(counts));
     OSN_LAUNCH_CHECK();
     return OSN_OK;
 }

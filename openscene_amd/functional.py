@@ -71,15 +71,36 @@ def sparse_conv(feats, kernel, maps, n_out, tiles=None, counts=None):
     return SparseConvFunction.apply(feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tf, tb, counts)
 
 
+class deferred_bn_counters:
+    """Context: collect the `num_batches_tracked += 1` of every BN in a forward pass and apply them as ONE
+    multi-tensor add at exit (48 one-element launches -> 1).  Same final buffer values as nn.BatchNorm1d."""
+    active = None
+
+    def __enter__(self):
+        self.prev = deferred_bn_counters.active
+        deferred_bn_counters.active = self.pending = []
+        return self
+
+    def __exit__(self, *exc):
+        deferred_bn_counters.active = self.prev
+        if self.pending:
+            torch._foreach_add_(self.pending, 1)
+        return False
+
+
 def batch_norm_act(x, bn, residual=None, relu=False):
     """`bn` is a torch.nn.BatchNorm1d (the `.bn` of MinkowskiBatchNorm): same parameters,
     buffers and train/eval semantics, computed by the HIP kernels."""
     training = bn.training or (bn.running_mean is None)
     momentum = 0.1 if bn.momentum is None else bn.momentum
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        if bn.momentum is None:
+        if bn.momentum is None:                       # cumulative average: needs the count now (host sync)
+            bn.num_batches_tracked.add_(1)
             momentum = 1.0 / float(bn.num_batches_tracked)
+        elif deferred_bn_counters.active is not None:
+            deferred_bn_counters.active.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     if not training and rm is None:

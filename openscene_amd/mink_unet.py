@@ -85,6 +85,10 @@ class MinkUNetBase(nn.Module):
         return y._like(F_.batch_norm_act(y.F, norm.bn, relu=True))
 
     def forward(self, x):
+        with F_.deferred_bn_counters():
+            return self._forward(x)
+
+    def _forward(self, x):
         out = self._conv_bn_relu(x, self.conv0p1s1, self.bn0)
         skips = [out]
         for i in range(4):

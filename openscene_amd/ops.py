@@ -94,17 +94,19 @@ def coords_unique(coords4, stride=1):
     return out[:u], inverse[:n], first[:u], table
 
 
-def kmap_build(table, out_coords4, ksize, offset_scale):
+def kmap_build(table, out_coords4, ksize, offset_scale, with_counts=False):
+    """nbr int32 [K, n_out] (and, with_counts, int64 [K] pairs per offset from the same pass)."""
     dev = out_coords4.device
     lib = _prep(dev)
     out_coords4 = out_coords4.contiguous()
     n_out = out_coords4.shape[0]
     K = ksize ** 3
     nbr = torch.empty((K, n_out), dtype=torch.int32, device=dev)
+    counts = torch.empty(K, dtype=torch.int64, device=dev) if with_counts else None
     with _Dev(dev):
         check(lib.osn_kmap_build(_p(table.keys), _p(table.vals), table.cap, _p(out_coords4), n_out, int(ksize),
-                                 int(offset_scale), _p(nbr), _stream(dev)), "osn_kmap_build")
-    return nbr
+                                 int(offset_scale), _p(nbr), _p(counts), _stream(dev)), "osn_kmap_build")
+    return (nbr, counts) if with_counts else nbr
 
 
 def kmap_transpose(nbr, n_in):

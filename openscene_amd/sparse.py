@@ -72,17 +72,22 @@ class CoordinateManager:
             res = (None, None, False)
         elif in_stride == out_stride:
             self.coords(in_stride)
-            nbr = ops.kmap_build(self._tables[in_stride], self._coords[in_stride], ksize, dilation * in_stride)
+            nbr, cnt = ops.kmap_build(self._tables[in_stride], self._coords[in_stride], ksize, dilation * in_stride,
+                                      with_counts=True)
+            self._kmaps[("counts",) + key] = cnt
             if ksize % 2 == 1:
                 res = (nbr, nbr, True)            # the map of an odd stride-1 kernel is its own mirror
             else:
                 res = (nbr, ops.kmap_transpose(nbr, self.size(in_stride)), False)
         elif out_stride > in_stride:              # strided conv: fine -> coarse
             out_c = self.coords(out_stride)
-            nbr = ops.kmap_build(self._tables[in_stride], out_c, ksize, dilation * in_stride)
+            nbr, cnt = ops.kmap_build(self._tables[in_stride], out_c, ksize, dilation * in_stride, with_counts=True)
+            self._kmaps[("counts",) + key] = cnt
             res = (nbr, ops.kmap_transpose(nbr, self.size(in_stride)), False)
         else:                                     # transposed conv: swap the fine -> coarse map
             down_fwd, down_bwd, _ = self.kmap(out_stride, in_stride, ksize, dilation)
+            # the swapped table holds the same pairs per offset
+            self._kmaps[("counts",) + key] = self._kmaps.get(("counts", out_stride, in_stride, ksize, dilation))
             res = (down_bwd, down_fwd, False)
         self._kmaps[key] = res
         return res
@@ -92,8 +97,9 @@ class CoordinateManager:
         lets the weight-gradient kernel balance its work items."""
         key = ("counts", in_stride, out_stride, ksize, dilation)
         if key not in self._kmaps:
-            fwd = self.kmap(in_stride, out_stride, ksize, dilation)[0]
-            self._kmaps[key] = ops.kmap_count(fwd) if fwd is not None else None
+            fwd = self.kmap(in_stride, out_stride, ksize, dilation)[0]       # kmap_build fills the count as it goes
+            if key not in self._kmaps:
+                self._kmaps[key] = ops.kmap_count(fwd) if fwd is not None else None
         return self._kmaps[key]
 
     SORT_MIN_ROWS = 8192      # below this the launch is latency-bound and the sort does not pay

@@ -37,10 +37,11 @@ def coords_unique(coords4, stride=1):
             torch.from_numpy(first.astype(np.int32)), HashTable(uniq))
 
 
-def kmap_build(table, out_coords4, ksize, offset_scale):
+def kmap_build(table, out_coords4, ksize, offset_scale, with_counts=False):
     # kernel_offsets(ksize, tensor_stride) scales by the tensor stride; dilation folded into offset_scale
     off = oc.kernel_offsets(ksize, offset_scale)
-    return torch.from_numpy(oc.kernel_map(table.coords4, _np(out_coords4), off))
+    nbr = torch.from_numpy(oc.kernel_map(table.coords4, _np(out_coords4), off))
+    return (nbr, (nbr >= 0).sum(1).long()) if with_counts else nbr
 
 
 def kmap_transpose(nbr, n_in):

@@ -92,6 +92,7 @@ def test_s100k_full_size_properties():
     for lvl, s in enumerate((1, 2, 4, 8, 16)):
         nbr, _, _ = cm.kmap(s, s, 3)
         cnt = ops.kmap_count(nbr).cpu().numpy()
+        assert np.array_equal(cm.kmap_counts(s, s, 3).cpu().numpy(), cnt)   # fused count of kmap_build
         assert int(cnt.sum()) == S100K_PAIRS27[lvl]
         assert int(cnt[13]) == sizes[lvl]                              # centre offset: every voxel sees itself
         assert np.array_equal(cnt, cnt[::-1])                          # (i,o) in map_k <=> (o,i) in map_{K-1-k}
@@ -103,6 +104,8 @@ def test_s100k_full_size_properties():
     for s in (1, 2, 4, 8):                                             # k2s2: exactly one parent per fine voxel
         down, up, _ = cm.kmap(s, 2 * s, 2)
         assert int(ops.kmap_count(down).sum()) == cm.size(s)
+        assert torch.equal(cm.kmap_counts(s, 2 * s, 2), ops.kmap_count(down))
+        assert torch.equal(cm.kmap_counts(2 * s, s, 2), ops.kmap_count(up))
         assert torch.all((up >= 0).sum(0) == 1)
         par = cm.parent(2 * s).long()
         assert torch.equal(up.max(0)[0].long(), par)

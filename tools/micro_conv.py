@@ -30,7 +30,11 @@ def main():
     dev = torch.device("cuda", 0)
     vox = syn.shuffled(syn.grid_voxels(syn.room_points(0), 0.02), 0)
     cm = CoordinateManager(torch.from_numpy(syn.batch_coords([vox])).to(dev))
-    for stride, cin, cout in ((1, 96, 96), (2, 128, 96), (1, 128, 96)):
+    only = os.environ.get("ONLY", "")
+    shapes = ((1, 96, 96), (2, 128, 96), (1, 128, 96))
+    if only:
+        shapes = shapes[:1]
+    for stride, cin, cout in shapes:
         n = cm.size(stride)
         nbr = cm.kmap(stride, stride, 3)[0]
         order, tbl = ops.kmap_sort(nbr)
@@ -38,6 +42,13 @@ def main():
         x = torch.randn(n, cin, device=dev)
         w = torch.randn(27, cin, cout, device=dev) * 0.05
         g = torch.randn(n, cout, device=dev)
+        if only == "fwd":
+            print("fwd(tile-ordered) %.1f us" % timed(lambda: ops.spconv_fwd(x, w, tbl, n, out_rows=order), reps))
+            continue
+        if only == "wgrad":
+            cnt = ops.kmap_count(nbr)
+            print("wgrad(balanced) %.1f us" % timed(lambda: ops.spconv_wgrad(x, g, nbr, 27, cnt), reps))
+            continue
         t_fwd_sorted = timed(lambda: ops.spconv_fwd(x, w, tbl, n, out_rows=order), reps)
         t_fwd_plain = timed(lambda: ops.spconv_fwd(x, w, nbr, n), reps)
         cnt = ops.kmap_count(nbr)
