@@ -87,6 +87,8 @@ int osn_kmap_transpose(const int32_t* nbr, int64_t n_out, int K, int64_t n_in, i
  * offset skip removes the empty work; results are unchanged.  K <= 32.               */
 size_t osn_kmap_sort_ws_bytes(int64_t n_out);
 int osn_kmap_sort(const int32_t* nbr, int64_t n_out, int K, int32_t* order, int32_t* nbr_sorted,
+                  uint32_t* gmask /* nullable: uint32 [ceil(n_out/32)], OR of the occupancy masks of
+                                     each 32-row group of the sorted table */,
                   void* ws, size_t ws_bytes, osn_stream_t stream);
 
 /* counts[k] = #valid entries of nbr[k, :]  (int64 [K], device).                  */
@@ -100,6 +102,8 @@ int osn_kmap_count(const int32_t* nbr, int64_t n_out, int K, int64_t* counts, os
  * out_rows (nullable): out row of tile slot j is out_rows[j] instead of j.       */
 size_t osn_spconv_fwd_ws_bytes(int64_t n_out, int K, int cin, int cout);
 int osn_spconv_fwd(const float* in, const float* W, const int32_t* nbr, const int32_t* out_rows,
+                   const uint32_t* gmask /* nullable: osn_kmap_sort's group masks of `nbr`; lets the
+                       kernel split each tile's ACTIVE offsets into equal work units (load balance) */,
                    float* out, int64_t n_out, int K, int cin, int cout,
                    void* ws, size_t ws_bytes, osn_stream_t stream);
 

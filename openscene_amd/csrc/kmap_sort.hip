@@ -32,6 +32,16 @@ __global__ void kmap_permute_kernel(const int32_t* __restrict__ nbr, const int32
     out[int64_t(k) * n_out + j] = nbr[int64_t(k) * n_out + order[j]];
 }
 
+// gmask[g] = OR of the occupancy masks of rows 32g .. 32g+31 (in the sorted order)
+__global__ void kmap_group_mask_kernel(const uint32_t* __restrict__ mask_sorted, int64_t n_out,
+                                       uint32_t* __restrict__ gmask) {
+    const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    uint32_t m = j < n_out ? mask_sorted[j] : 0u;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) m |= __shfl_xor(m, d, 64);
+    if ((threadIdx.x & 31) == 0 && j < n_out) gmask[j >> 5] = m;
+}
+
 struct SortWs {
     uint32_t *mask, *mask_sorted;
     int32_t* iota;
@@ -72,8 +82,8 @@ extern "C" size_t osn_kmap_sort_ws_bytes(int64_t n_out) {
     return carve_sort(nullptr, n_out, tb).bytes;
 }
 
-extern "C" int osn_kmap_sort(const int32_t* nbr, int64_t n_out, int K, int32_t* order, int32_t* nbr_sorted, void* ws,
-                             size_t ws_bytes, osn_stream_t stream) {
+extern "C" int osn_kmap_sort(const int32_t* nbr, int64_t n_out, int K, int32_t* order, int32_t* nbr_sorted,
+                             uint32_t* gmask, void* ws, size_t ws_bytes, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(K >= 1 && K <= 32, OSN_E_ARG, "osn_kmap_sort: K=%d (only K <= 32 offsets fit the 32-bit occupancy mask)", K);
     OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_kmap_sort: n_out out of range");
@@ -89,6 +99,8 @@ extern "C" int osn_kmap_sort(const int32_t* nbr, int64_t n_out, int K, int32_t* 
     size_t t2 = w.tmp_bytes;
     OSN_HIP(rocprim::radix_sort_pairs(w.tmp, t2, w.mask, w.mask_sorted, w.iota, order, size_t(n_out), 0u, unsigned(K), st));
     hipLaunchKernelGGL(kmap_permute_kernel, dim3(cdiv(n_out, T), K), dim3(T), 0, st, nbr, order, n_out, nbr_sorted);
+    if (gmask)
+        hipLaunchKernelGGL(kmap_group_mask_kernel, dim3(cdiv(n_out, T)), dim3(T), 0, st, w.mask_sorted, n_out, gmask);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
 }

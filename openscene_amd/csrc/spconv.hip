@@ -166,8 +166,11 @@ template <int WM, int WN, int TN>
 __global__ __launch_bounds__(256, 2) void spconv_fwd_pipe_kernel(const float* __restrict__ in, const float* __restrict__ W,
                                                               const int32_t* __restrict__ nbr,
                                                               const int32_t* __restrict__ out_rows,
-                                                              float* __restrict__ out, int n_out, int K, int cin,
-                                                              int cout, int k_per_split, int to_partial) {
+                                                              const uint32_t* __restrict__ gmask,
+                                                              int32_t* __restrict__ tile_parts,
+                                                              float* __restrict__ out, float* __restrict__ extra,
+                                                              int n_out, int K, int cin, int cout, int k_per_split,
+                                                              int to_partial, int unit_k) {
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * TN * WN;
@@ -188,11 +191,44 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_pipe_kernel(const float* __
     const int wm = wave / WN, wn = wave % WN;
     const int row0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int k_begin = blockIdx.z * k_per_split;
-    const int nk = min(K, k_begin + k_per_split) - k_begin;     // <= KC
+    // Two ways to cut the offset loop across blockIdx.z:
+    //  * units mode (gmask given): part z takes the z-th group of `unit_k` ACTIVE offsets of this tile
+    //    (work per block is bounded and even; parts > 0 go to `extra`, summed in order by a fix-up pass);
+    //  * uniform mode: part z takes offsets [z*k_per_split, (z+1)*k_per_split) (small maps).
+    const bool units = gmask != nullptr;
+    const int part = blockIdx.z;
+    const int k_begin = units ? 0 : part * k_per_split;
+    const int nk = units ? K : min(K, k_begin + k_per_split) - k_begin;     // <= KC
     const int my_row = row0 + tid;                               // meaningful for tid < BM
     const bool row_ok = tid < BM && my_row < n_out;
+    __shared__ uint32_t gm_s[4];
 
+    if (units) {
+        // ---- prologue from the precomputed 32-row group masks: no table scan
+        if (tid < 4) {
+            const int64_t g = int64_t(blockIdx.x) * WM + tid;
+            gm_s[tid] = (tid < WM && g * 32 < n_out) ? gmask[g] : 0u;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t tm = gm_s[0] | gm_s[1] | gm_s[2] | gm_s[3];
+            int i = 0, n = 0;
+            for (int kk = 0; kk < nk; ++kk) {
+                if (!((tm >> kk) & 1u)) continue;
+                if (i >= part * unit_k && i < (part + 1) * unit_k) {
+                    klist[n] = kk;
+                    kgm[n] = int((gm_s[0] >> kk) & 1u) | (int((gm_s[1] >> kk) & 1u) << 1) |
+                             (int((gm_s[2] >> kk) & 1u) << 2) | (int((gm_s[3] >> kk) & 1u) << 3);
+                    ++n;
+                }
+                ++i;
+            }
+            nact_s = n;
+            if (part == 0 && blockIdx.y == 0) tile_parts[blockIdx.x] = (i + unit_k - 1) / unit_k;
+        }
+        __syncthreads();
+        if (part > 0 && nact_s == 0) return;     // this tile has no offsets left for part z
+    } else {
     // ---- prologue: which offsets does this tile use, and which of its 32-row groups
     for (int kk0 = 0; kk0 < nk; kk0 += 8) {
         int idx[8];
@@ -218,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_pipe_kernel(const float* __
         nact_s = n;
     }
     __syncthreads();
+    }   // !units
     const int nact = nact_s;
     const int nchunk = (cin + BK - 1) / BK;
     const int nstage = nact * nchunk;
@@ -337,7 +374,12 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_pipe_kernel(const float* __
     }
 
     float* dst = out;
-    if (to_partial) dst = out + int64_t(blockIdx.z) * n_out * cout;
+    bool direct = !to_partial;                   // rows go to their final place (through out_rows)
+    if (units) {
+        if (part > 0) { dst = extra + int64_t(part - 1) * n_out * cout; direct = false; }
+    } else if (to_partial) {
+        dst = out + int64_t(blockIdx.z) * n_out * cout;
+    }
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
         const int col = n0 + (wn * TN + t) * 32 + (lane & 31);
@@ -345,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_pipe_kernel(const float* __
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < n_out && col < cout) {
-                const int orow = (!to_partial && out_rows) ? out_rows[row] : row;
+                const int orow = (direct && out_rows) ? out_rows[row] : row;
                 dst[int64_t(orow) * cout + col] = acc[t][r];
             }
         }
@@ -364,6 +406,23 @@ __global__ void reduce_partial_rows_kernel(const float* __restrict__ partial, in
         } else {
             out[e] = s;
         }
+    }
+}
+
+// units mode: out[row] += extra[0][j] + extra[1][j] + ... (parts 1 .. tile_parts-1 of the row's tile, in order)
+__global__ void fixup_units_kernel(const float* __restrict__ extra, const int32_t* __restrict__ tile_parts, int bm,
+                                   int64_t n_out, int cout, const int32_t* __restrict__ out_rows,
+                                   float* __restrict__ out) {
+    const int64_t total = n_out * cout;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t j = e / cout;
+        const int np = tile_parts[j / bm];
+        if (np <= 1) continue;
+        const int64_t c = e - j * cout;
+        const int64_t o = (out_rows ? int64_t(out_rows[j]) : j) * cout + c;
+        float s = out[o];
+        for (int p = 1; p < np; ++p) s += extra[int64_t(p - 1) * total + e];
+        out[o] = s;
     }
 }
 
@@ -658,7 +717,10 @@ struct FwdPlan {
     int tn;
     int bm, bn;
     int gx, gy, S, kps;
+    int unit_k, unit_parts;    // units mode (needs gmask): active offsets per block, max parts per tile
 };
+
+constexpr int UNIT_K = 8;
 
 static FwdPlan plan_fwd(int64_t n_out, int K, int cin, int cout) {
     FwdPlan p;
@@ -681,6 +743,10 @@ static FwdPlan plan_fwd(int64_t n_out, int K, int cin, int cout) {
     }
     p.kps = int(cdiv(K, S));
     p.S = int(cdiv(K, p.kps));
+    // units mode pays when the plain launch would not be split and every tile walks many offsets
+    p.unit_k = UNIT_K;
+    p.unit_parts = (p.S == 1 && K > UNIT_K && K <= 32 && cin > 4 && (cin & 3) == 0 && (cout & 3) == 0)
+                       ? int(cdiv(K, UNIT_K)) : 0;
     return p;
 }
 
@@ -716,10 +782,17 @@ static WgradPlan plan_wgrad(int64_t n_out, int K, int cin, int cout) {
 
 using namespace osn;
 
+static size_t units_ws_bytes(const FwdPlan& p, int64_t n_out, int cout) {
+    if (p.unit_parts <= 1) return 0;
+    return align_up(size_t(p.gx) * 4, 256) + size_t(p.unit_parts - 1) * size_t(n_out) * size_t(cout) * 4;
+}
+
 extern "C" size_t osn_spconv_fwd_ws_bytes(int64_t n_out, int K, int cin, int cout) {
     if (n_out <= 0) return 0;
     FwdPlan p = plan_fwd(n_out, K, cin, cout);
-    return p.S > 1 ? size_t(p.S) * size_t(n_out) * size_t(cout) * 4 : 0;
+    const size_t uniform = p.S > 1 ? size_t(p.S) * size_t(n_out) * size_t(cout) * 4 : 0;
+    const size_t units = units_ws_bytes(p, n_out, cout);       // only used when the caller passes gmask
+    return uniform > units ? uniform : units;
 }
 
 extern "C" int osn_spconv_fwd_plan(int64_t n_out, int K, int cin, int cout, int32_t* plan6) {
@@ -735,11 +808,20 @@ extern "C" int osn_spconv_fwd_plan(int64_t n_out, int K, int cin, int cout, int3
     return OSN_OK;
 }
 
+struct UnitsArgs {
+    const uint32_t* gmask;
+    int32_t* tile_parts;
+    float* extra;
+};
+
 template <int WM, int WN, int TN>
 static void launch_fwd_pipe(const FwdPlan& p, hipStream_t st, const float* in, const float* W, const int32_t* nbr,
-                            const int32_t* out_rows, float* dst, int n_out, int K, int cin, int cout) {
-    hipLaunchKernelGGL((spconv_fwd_pipe_kernel<WM, WN, TN>), dim3(p.gx, p.gy, p.S), dim3(256), 0, st, in, W, nbr,
-                       out_rows, dst, n_out, K, cin, cout, p.kps, p.S > 1 ? 1 : 0);
+                            const int32_t* out_rows, float* dst, int n_out, int K, int cin, int cout,
+                            const UnitsArgs& u) {
+    const int gz = u.gmask ? p.unit_parts : p.S;
+    hipLaunchKernelGGL((spconv_fwd_pipe_kernel<WM, WN, TN>), dim3(p.gx, p.gy, gz), dim3(256), 0, st, in, W, nbr,
+                       out_rows, u.gmask, u.tile_parts, dst, u.extra, n_out, K, cin, cout, p.kps,
+                       (!u.gmask && p.S > 1) ? 1 : 0, p.unit_k);
 }
 
 template <int WM, int WN, int TN, int BK>
@@ -749,9 +831,9 @@ static void launch_fwd(const FwdPlan& p, hipStream_t st, const float* in, const 
                        out_rows, dst, n_out, K, cin, cout, p.kps, p.S > 1 ? 1 : 0);
 }
 
-extern "C" int osn_spconv_fwd(const float* in, const float* W, const int32_t* nbr, const int32_t* out_rows, float* out,
-                              int64_t n_out, int K, int cin, int cout, void* ws, size_t ws_bytes,
-                              osn_stream_t stream) {
+extern "C" int osn_spconv_fwd(const float* in, const float* W, const int32_t* nbr, const int32_t* out_rows,
+                              const uint32_t* gmask, float* out, int64_t n_out, int K, int cin, int cout, void* ws,
+                              size_t ws_bytes, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_spconv_fwd: n_out out of range");
     OSN_REQUIRE(K >= 1 && cin >= 1 && cout >= 1, OSN_E_ARG, "osn_spconv_fwd: bad K/cin/cout (%d,%d,%d)", K, cin, cout);
@@ -761,7 +843,15 @@ extern "C" int osn_spconv_fwd(const float* in, const float* W, const int32_t* nb
     OSN_REQUIRE(aligned16(in) && aligned16(W) && aligned16(out), OSN_E_ARG, "osn_spconv_fwd: pointers must be 16-byte aligned");
     FwdPlan p = plan_fwd(n_out, K, cin, cout);
     float* dst = out;
-    if (p.S > 1) {
+    UnitsArgs ua = {nullptr, nullptr, nullptr};
+    const bool use_units = gmask && nbr && p.unit_parts > 1;
+    if (use_units) {
+        const size_t need = units_ws_bytes(p, n_out, cout);
+        OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_spconv_fwd: workspace %zu < %zu", ws_bytes, need);
+        ua.gmask = gmask;
+        ua.tile_parts = static_cast<int32_t*>(ws);
+        ua.extra = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up(size_t(p.gx) * 4, 256));
+    } else if (p.S > 1) {
         const size_t need = size_t(p.S) * size_t(n_out) * size_t(cout) * 4;
         OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_spconv_fwd: workspace %zu < %zu", ws_bytes, need);
         dst = static_cast<float*>(ws);
@@ -770,13 +860,13 @@ extern "C" int osn_spconv_fwd(const float* in, const float* W, const int32_t* nb
     const bool pipe = cin > 4 && (cin & 3) == 0 && (cout & 3) == 0 && p.kps <= 32;
     if (pipe) {
         switch (p.cfg * 10 + p.tn) {
-            case 1: launch_fwd_pipe<4, 1, 1>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
-            case 2: launch_fwd_pipe<4, 1, 2>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
-            case 3: launch_fwd_pipe<4, 1, 3>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
-            case 4: launch_fwd_pipe<4, 1, 4>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
-            case 11: launch_fwd_pipe<2, 2, 1>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
-            case 12: launch_fwd_pipe<2, 2, 2>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
-            default: launch_fwd_pipe<1, 4, 1>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout); break;
+            case 1: launch_fwd_pipe<4, 1, 1>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout, ua); break;
+            case 2: launch_fwd_pipe<4, 1, 2>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout, ua); break;
+            case 3: launch_fwd_pipe<4, 1, 3>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout, ua); break;
+            case 4: launch_fwd_pipe<4, 1, 4>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout, ua); break;
+            case 11: launch_fwd_pipe<2, 2, 1>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout, ua); break;
+            case 12: launch_fwd_pipe<2, 2, 2>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout, ua); break;
+            default: launch_fwd_pipe<1, 4, 1>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout, ua); break;
         }
     } else if (cin <= 4) {
         // stem convolution (3 -> 32): 4-wide channel chunks
@@ -801,7 +891,14 @@ extern "C" int osn_spconv_fwd(const float* in, const float* W, const int32_t* nb
         }
     }
     OSN_LAUNCH_CHECK();
-    if (p.S > 1) {
+    if (use_units) {
+        const int64_t total = n_out * cout;
+        int g = int(cdiv(total, 256));
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(fixup_units_kernel, dim3(g), dim3(256), 0, st, ua.extra, ua.tile_parts, p.bm, n_out, cout,
+                           out_rows, out);
+        OSN_LAUNCH_CHECK();
+    } else if (p.S > 1) {
         const int64_t total = n_out * cout;
         int g = int(cdiv(total, 256));
         if (g > 4096) g = 4096;

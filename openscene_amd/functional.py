@@ -17,7 +17,7 @@ class SparseConvFunction(Function):
         ctx.maps = (nbr_fwd, nbr_bwd, bool(flip), tiles_bwd, counts)
         ctx.n_in = feats.shape[0]
         if tiles_fwd is not None:            # (order, row-permuted table): same result, tile-friendly order
-            return ops.spconv_fwd(feats, kernel, tiles_fwd[1], n_out, out_rows=tiles_fwd[0])
+            return ops.spconv_fwd(feats, kernel, tiles_fwd[1], n_out, out_rows=tiles_fwd[0], gmask=tiles_fwd[2])
         return ops.spconv_fwd(feats, kernel, nbr_fwd, n_out)
 
     @staticmethod
@@ -30,7 +30,7 @@ class SparseConvFunction(Function):
         if ctx.needs_input_grad[0]:
             wt = ops.weight_transpose(kernel, flip)
             if tiles_bwd is not None:
-                gin = ops.spconv_fwd(gout, wt, tiles_bwd[1], ctx.n_in, out_rows=tiles_bwd[0])
+                gin = ops.spconv_fwd(gout, wt, tiles_bwd[1], ctx.n_in, out_rows=tiles_bwd[0], gmask=tiles_bwd[2])
             else:
                 gin = ops.spconv_fwd(gout, wt, nbr_bwd, ctx.n_in)
         if ctx.needs_input_grad[1]:

@@ -120,19 +120,21 @@ def kmap_transpose(nbr, n_in):
 
 
 def kmap_sort(nbr):
-    """-> (order int32 [n_out], nbr_sorted int32 [K, n_out]): rows ordered by offset-occupancy mask."""
+    """-> (order int32 [n_out], nbr_sorted int32 [K, n_out], gmask int32 [ceil(n_out/32)]): rows ordered by
+    offset-occupancy mask; gmask = OR of the masks of each 32-row group of the sorted table."""
     dev = nbr.device
     lib = _prep(dev)
     nbr = nbr.contiguous()
     K, n_out = nbr.shape
     order = torch.empty(n_out, dtype=torch.int32, device=dev)
     out = torch.empty_like(nbr)
+    gmask = torch.empty((n_out + 31) // 32, dtype=torch.int32, device=dev)
     with _Dev(dev):
         wsb = lib.osn_kmap_sort_ws_bytes(n_out)
         ws = _ws(wsb, dev)
-        check(lib.osn_kmap_sort(_p(nbr), n_out, K, _p(order), _p(out), _p(ws), ws.numel(), _stream(dev)),
+        check(lib.osn_kmap_sort(_p(nbr), n_out, K, _p(order), _p(out), _p(gmask), _p(ws), ws.numel(), _stream(dev)),
               "osn_kmap_sort")
-    return order, out
+    return order, out, gmask
 
 
 def kmap_count(nbr):
@@ -150,8 +152,9 @@ def _w3(weight):
     return weight.unsqueeze(0) if weight.dim() == 2 else weight
 
 
-def spconv_fwd(feats, weight, nbr, n_out, out_rows=None):
-    """out[o] = sum_k feats[nbr[k,o]] @ weight[k].  nbr None <=> K == 1 identity map."""
+def spconv_fwd(feats, weight, nbr, n_out, out_rows=None, gmask=None):
+    """out[o] = sum_k feats[nbr[k,o]] @ weight[k].  nbr None <=> K == 1 identity map.
+    (out_rows, gmask) come with a tile-ordered table from kmap_sort."""
     dev = feats.device
     lib = _prep(dev)
     feats = _f32c(feats, "features")
@@ -171,8 +174,8 @@ def spconv_fwd(feats, weight, nbr, n_out, out_rows=None):
     tok = _profiler.start("spconv_fwd", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
         if _profiler is not None else None
     with _Dev(dev):
-        check(lib.osn_spconv_fwd(_p(feats), _p(w), _p(nbr), _p(out_rows), _p(out), n_out, K, cin, cout, _p(ws),
-                                 int(wsb), _stream(dev)), "osn_spconv_fwd")
+        check(lib.osn_spconv_fwd(_p(feats), _p(w), _p(nbr), _p(out_rows), _p(gmask), _p(out), n_out, K, cin, cout,
+                                 _p(ws), int(wsb), _stream(dev)), "osn_spconv_fwd")
     if tok is not None:
         _profiler.stop(tok)
     return out

@@ -52,7 +52,13 @@ def kmap_sort(nbr):
     K = nbr.shape[0]
     mask = ((nbr >= 0).long() << torch.arange(K).reshape(K, 1)).sum(0)
     order = torch.from_numpy(np.argsort(mask.numpy(), kind="stable").astype(np.int32))
-    return order, nbr[:, order.long()].contiguous()
+    ms = mask[order.long()]
+    pad = (-ms.shape[0]) % 32
+    g = torch.cat([ms, ms.new_zeros(pad)]).reshape(-1, 32)
+    gmask = g[:, 0].clone()
+    for j in range(1, 32):
+        gmask |= g[:, j]
+    return order, nbr[:, order.long()].contiguous(), gmask.int()
 
 
 def kmap_count(nbr):
@@ -63,7 +69,7 @@ def _w3(w):
     return w.unsqueeze(0) if w.dim() == 2 else w
 
 
-def spconv_fwd(feats, weight, nbr, n_out, out_rows=None):
+def spconv_fwd(feats, weight, nbr, n_out, out_rows=None, gmask=None):
     w = _w3(weight)
     if nbr is None:
         nbr = torch.arange(n_out, dtype=torch.int32)[None]

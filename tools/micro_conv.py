@@ -37,19 +37,19 @@ def main():
     for stride, cin, cout in shapes:
         n = cm.size(stride)
         nbr = cm.kmap(stride, stride, 3)[0]
-        order, tbl = ops.kmap_sort(nbr)
+        order, tbl, gm = ops.kmap_sort(nbr)
         pairs = int(ops.kmap_count(nbr).sum())
         x = torch.randn(n, cin, device=dev)
         w = torch.randn(27, cin, cout, device=dev) * 0.05
         g = torch.randn(n, cout, device=dev)
         if only == "fwd":
-            print("fwd(tile-ordered) %.1f us" % timed(lambda: ops.spconv_fwd(x, w, tbl, n, out_rows=order), reps))
+            print("fwd(tile-ordered) %.1f us" % timed(lambda: ops.spconv_fwd(x, w, tbl, n, out_rows=order, gmask=gm), reps))
             continue
         if only == "wgrad":
             cnt = ops.kmap_count(nbr)
             print("wgrad(balanced) %.1f us" % timed(lambda: ops.spconv_wgrad(x, g, nbr, 27, cnt), reps))
             continue
-        t_fwd_sorted = timed(lambda: ops.spconv_fwd(x, w, tbl, n, out_rows=order), reps)
+        t_fwd_sorted = timed(lambda: ops.spconv_fwd(x, w, tbl, n, out_rows=order, gmask=gm), reps)
         t_fwd_plain = timed(lambda: ops.spconv_fwd(x, w, nbr, n), reps)
         cnt = ops.kmap_count(nbr)
         t_wgrad = timed(lambda: ops.spconv_wgrad(x, g, nbr, 27, cnt), reps)
