@@ -350,16 +350,28 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_pipe_kernel(const float* __
                 asm volatile("global_load_dword %0, %1, off" : "=v"(i2) : "v"(p2) : "memory");
             }
             if ((kgm[slot] >> wm) & 1) {
+                // operands of step kk+1 are read from LDS while the MFMAs of step kk issue
+                // (rolling two-step register window; the compiler otherwise waits lgkmcnt(0) per MFMA pair)
                 const int arow = wm * 32 + (lane & 31);
                 const int kh = lane >> 5;
+                const int bcol = wn * TN * 32 + (lane & 31);
+                float av[2], bv[2][TN];
+                av[0] = As[arow][kh];
 #pragma unroll
-                for (int kk = 0; kk < BK; kk += 2) {
-                    const float a = As[arow][kk + kh];
+                for (int t = 0; t < TN; ++t) bv[0][t] = Bs[kh][bcol + t * 32];
 #pragma unroll
-                    for (int t = 0; t < TN; ++t) {
-                        const float b = Bs[kk + kh][(wn * TN + t) * 32 + (lane & 31)];
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                for (int kk = 0; kk < BK / 2; ++kk) {
+                    const int cur = kk & 1, nxt = cur ^ 1;
+                    if (kk + 1 < BK / 2) {
+                        av[nxt] = As[arow][2 * (kk + 1) + kh];
+#pragma unroll
+                        for (int t = 0; t < TN; ++t) bv[nxt][t] = Bs[2 * (kk + 1) + kh][bcol + t * 32];
                     }
+                    __builtin_amdgcn_sched_barrier(0);       // keep the next step's reads ahead of these MFMAs
+#pragma unroll
+                    for (int t = 0; t < TN; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][t], acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __syncthreads();                  // stage s consumed; ridx[s&1] is free (its fetch ran an iteration ago)
@@ -607,11 +619,21 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_kernel(const float* __res
                 const int tile = wave + 4 * t;
                 if (tile < ntiles) {
                     const int ti = tile / ntj, tj = tile - ti * ntj;
+                    const int ca = ti * 32 + (lane & 31), cb = tj * 32 + (lane & 31);
+                    // rolling two-step operand window: LDS reads of step kk+1 overlap the MFMA of step kk
+                    float av[2], bv[2];
+                    av[0] = As[kh][ca];
+                    bv[0] = Gs[kh][cb];
 #pragma unroll
-                    for (int kk = 0; kk < WG_RB; kk += 2) {
-                        const float a = As[kk + kh][ti * 32 + (lane & 31)];
-                        const float b = Gs[kk + kh][tj * 32 + (lane & 31)];
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                    for (int kk = 0; kk < WG_RB / 2; ++kk) {
+                        const int cur = kk & 1, nxt = cur ^ 1;
+                        if (kk + 1 < WG_RB / 2) {
+                            av[nxt] = As[2 * (kk + 1) + kh][ca];
+                            bv[nxt] = Gs[2 * (kk + 1) + kh][cb];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur], acc[t], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
