@@ -19,6 +19,7 @@
 //     loop across workgroups (deterministic partial buffers + ordered reduce) so
 //     the launch still covers the 256 CUs.
 #include "common.h"
+#include <stdlib.h>
 
 namespace osn {
 
@@ -766,9 +767,10 @@ static FwdPlan plan_fwd(int64_t n_out, int K, int cin, int cout) {
     p.kps = int(cdiv(K, S));
     p.S = int(cdiv(K, p.kps));
     // units mode pays when the plain launch would not be split and every tile walks many offsets
-    p.unit_k = UNIT_K;
-    p.unit_parts = (p.S == 1 && K > UNIT_K && K <= 32 && cin > 4 && (cin & 3) == 0 && (cout & 3) == 0)
-                       ? int(cdiv(K, UNIT_K)) : 0;
+    static const int tune_U = getenv("OSN_UNIT_K") ? atoi(getenv("OSN_UNIT_K")) : UNIT_K;    // experiment knob
+    p.unit_k = tune_U;
+    p.unit_parts = (p.S == 1 && K > tune_U && K <= 32 && cin > 4 && (cin & 3) == 0 && (cout & 3) == 0)
+                       ? int(cdiv(K, tune_U)) : 0;
     return p;
 }
 
@@ -789,7 +791,8 @@ static WgradPlan plan_wgrad(int64_t n_out, int K, int cin, int cout) {
     p.tpw = (tiles + 3) / 4;
     p.min_rows = 512;
     // ~1024 workgroups per launch (4 per CU), but never more items than the rows can feed
-    int64_t T = cdiv(1024, int64_t(p.n_ci) * p.n_co);
+    static const int tune_T = getenv("OSN_WGRAD_T") ? atoi(getenv("OSN_WGRAD_T")) : 1024;   // experiment knob
+    int64_t T = cdiv(tune_T, int64_t(p.n_ci) * p.n_co);
     const int64_t tmax = int64_t(K) * cdiv(n_out, p.min_rows);
     if (T > tmax) T = tmax;
     if (T < K) T = K;
