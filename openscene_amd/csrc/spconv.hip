@@ -791,7 +791,7 @@ static WgradPlan plan_wgrad(int64_t n_out, int K, int cin, int cout) {
     p.tpw = (tiles + 3) / 4;
     p.min_rows = 512;
     // ~1024 workgroups per launch (4 per CU), but never more items than the rows can feed
-    static const int tune_T = getenv("OSN_WGRAD_T") ? atoi(getenv("OSN_WGRAD_T")) : 1024;   // experiment knob
+    static const int tune_T = getenv("OSN_WGRAD_T") ? atoi(getenv("OSN_WGRAD_T")) : 512;   // experiment knob
     int64_t T = cdiv(tune_T, int64_t(p.n_ci) * p.n_co);
     const int64_t tmax = int64_t(K) * cdiv(n_out, p.min_rows);
     if (T > tmax) T = tmax;

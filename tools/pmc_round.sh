@@ -6,13 +6,13 @@ rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
 i=0
-for only in fwd wgrad; do
+for only in ${PMC_ONLY:-fwd wgrad}; do
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" \
            "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM" \
            "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum"; do
   i=$((i+1))
   ONLY=$only REPS=2 timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/${only}_p$i -o p -- python $R/tools/micro_conv.py > $O/${only}_p$i.log 2>&1
-  echo "$only pass $i exit $?"; tail -n 1 $O/${only}_p$i.log
+  echo "$only pass $i exit $?"
 done
 done
-python $R/tools/pmc_summary.py $O > $O/summary.txt 2>&1; cat $O/summary.txt | head -80
+python $R/tools/pmc_summary.py $O > $O/summary.txt 2>&1; cat $O/summary.txt | head -120
