@@ -334,6 +334,7 @@ def main():
 
     # ---- query timing (per-point feature x text, M2) : eval forward output of this scene
     qres = None
+    vox_res = None
     if rank == 0:
         model.eval()
         with torch.no_grad():
@@ -356,6 +357,41 @@ def main():
         q_bytes = 4.0 * n_pts * out_dim + 2.0 * 20 * out_dim + 8.0 * n_pts + 8.0 * n_pts
         qres = {"ms": q_ms, "n_points": n_pts, "dim": out_dim, "labels": 20,
                 "hbm_frac": q_bytes / (q_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # Matterport-160-shaped query (configs[3]): 500 k points x 160 labels, with the fp16 score matrix
+        n2, c2 = 500000, 160
+        x2 = torch.randn(n2 // 4, out_dim, generator=gq).to(device)
+        g2 = torch.randint(0, n2 // 4, (n2,), generator=gq).to(device)
+        t2 = torch.nn.functional.normalize(torch.randn(c2, out_dim, generator=gq), dim=1).half().to(device)
+        for _ in range(2):
+            query_distill(x2, t2, g2, return_scores=True)
+        torch.cuda.synchronize(device)
+        e0.record()
+        for _ in range(10):
+            query_distill(x2, t2, g2, return_scores=True)
+        e1.record()
+        torch.cuda.synchronize(device)
+        q2_ms = e0.elapsed_time(e1) / 10
+        q2_bytes = 4.0 * n2 * out_dim + 2.0 * c2 * out_dim + 2.0 * n2 * c2 + 16.0 * n2
+        qres["matterport160"] = {"ms": q2_ms, "n_points": n2, "labels": c2, "scores_written": True,
+                                 "hbm_frac": q2_bytes / (q2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # voxeliser (M3): 200 k points, 2 cm, reference transform draw; includes the one host sync for n_vox
+        from openscene_amd import synthetic as syn
+        from openscene_amd.voxelizer import Voxelizer
+        pts = torch.from_numpy(syn.room_points(7, n_pts=200000)).to(device)
+        np.random.seed(0)
+        vx = Voxelizer(voxel_size=0.02, use_augmentation=True, scale_augmentation_bound=(0.9, 1.1),
+                       rotation_augmentation_bound=((-np.pi / 64, np.pi / 64), (-np.pi / 64, np.pi / 64), (-np.pi, np.pi)))
+        M_v, M_r = vx.get_transformation_matrix()
+        T = M_r @ M_v
+        for _ in range(2):
+            vx.voxelize_tensors(pts, T)
+        torch.cuda.synchronize(device)
+        tv = time.perf_counter()
+        for _ in range(10):
+            _, inds_v, _ = vx.voxelize_tensors(pts, T)
+        torch.cuda.synchronize(device)
+        v_ms = (time.perf_counter() - tv) * 1e3 / 10
+        vox_res = {"ms": v_ms, "n_points": 200000, "n_voxels": int(inds_v.shape[0]), "points_per_s": 200000 / (v_ms * 1e-3)}
         model.train()
 
     if rank != 0:
@@ -416,7 +452,7 @@ def main():
                    "arch": args.arch, "feature_dim": out_dim, "voxels_rank0": n_vox,
                    "level_sizes": sizes, "parallelism": "dp%d" % world,
                    "step_algorithmic_GB": step_bytes / 1e9, "step_GFLOP": step_flops / 1e9},
-        "query": qres, "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "loss": float(loss),
+        "query": qres, "voxelizer": vox_res, "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "loss": float(loss.detach()),
     }
     print(json.dumps(line))
     if world > 1:

@@ -62,35 +62,58 @@ __global__ __launch_bounds__(256) void query_kernel(const float* __restrict__ X0
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-        for (int d0 = 0; d0 < d; d0 += Q_DK) {
-            {   // X chunk: 128 rows x 64 floats -> fp16
-                const int q = tid & 15, r = tid >> 4;
+        // software pipeline over the feature chunks: the rows / text of chunk i+1 are loaded into
+        // registers (unconditional loads from clamped addresses) while the MFMAs of chunk i run
+        float4 px[Q_BM / 16];
+        uint4 pt[CT];
+        const int xq = tid & 15, xr = tid >> 4;
+        auto fetch = [&](int d0) {
 #pragma unroll
-                for (int ps = 0; ps < Q_BM / 16; ++ps) {
-                    const int row = ps * 16 + r;
-                    const float* src = rowptr[row];
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (src && d0 + q * 4 < d) v = *reinterpret_cast<const float4*>(src + d0 + q * 4);
-                    if (rowdiv) {
-                        const float den = rowden[row];
-                        v.x /= den; v.y /= den; v.z /= den; v.w /= den;
-                    }
-                    half4 h;
-                    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-                    *reinterpret_cast<half4*>(&Xs[row][q * 4]) = h;
-                }
+            for (int ps = 0; ps < Q_BM / 16; ++ps) {
+                const float* src = rowptr[ps * 16 + xr];
+                const bool ok = src != nullptr && d0 + xq * 4 < d;
+                px[ps] = *reinterpret_cast<const float4*>(ok ? src + d0 + xq * 4 : X0);
             }
 #pragma unroll
-            for (int j = 0; j < CT; ++j) {  // T chunk: CT*32 text rows x 64 halfs
+            for (int j = 0; j < CT; ++j) {
                 const int f = tid + 256 * j;
                 const int trow = f >> 3, ch = f & 7;
                 const int col = cg0 + trow;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (col < c && d0 + ch * 8 < d)
-                    v = *reinterpret_cast<const uint4*>(T + int64_t(col) * d + d0 + ch * 8);
+                const bool ok = col < c && d0 + ch * 8 < d;
+                pt[j] = *reinterpret_cast<const uint4*>(ok ? T + int64_t(col) * d + d0 + ch * 8 : T);
+            }
+        };
+        auto stash = [&](int d0) {
+#pragma unroll
+            for (int ps = 0; ps < Q_BM / 16; ++ps) {
+                const int row = ps * 16 + xr;
+                const bool ok = rowptr[row] != nullptr && d0 + xq * 4 < d;
+                float4 v = px[ps];
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rowdiv) {
+                    const float den = rowden[row];
+                    v.x /= den; v.y /= den; v.z /= den; v.w /= den;
+                }
+                half4 h;
+                h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+                *reinterpret_cast<half4*>(&Xs[row][xq * 4]) = h;
+            }
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int f = tid + 256 * j;
+                const int trow = f >> 3, ch = f & 7;
+                const bool ok = cg0 + trow < c && d0 + ch * 8 < d;
+                uint4 v = pt[j];
+                if (!ok) v = make_uint4(0, 0, 0, 0);
                 *reinterpret_cast<uint4*>(&Ts[trow][ch * 8]) = v;
             }
-            __syncthreads();
+        };
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (int d0 = 0; d0 < d; d0 += Q_DK) {
+            const bool more = d0 + Q_DK < d;
+            if (more) fetch(d0 + Q_DK);
             const int arow = wave * 32 + (lane & 31);
             const int kh = 8 * (lane >> 5);
 #pragma unroll
@@ -102,6 +125,8 @@ __global__ __launch_bounds__(256) void query_kernel(const float* __restrict__ X0
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
                 }
             }
+            __syncthreads();
+            if (more) stash(d0 + Q_DK);
             __syncthreads();
         }
         // ---- group epilogue: round to fp16, optional store, running argmax
