@@ -107,6 +107,19 @@ int osn_spconv_fwd(const float* in, const float* W, const int32_t* nbr, const in
                    float* out, int64_t n_out, int K, int cin, int cout,
                    void* ws, size_t ws_bytes, osn_stream_t stream);
 
+/* Split-bf16 ("bf16x6") variant of osn_spconv_fwd: same result contract (fp32 in / fp32 out, fp32-level
+ * accuracy: every operand is split into three bf16 pieces and the six significant cross products are
+ * accumulated in fp32 on v_mfma_f32_32x32x16_bf16, 2.7x the fp32 MFMA throughput).  Wp comes from
+ * osn_weight_prep_x6: bf16 [3][K][n_out_channels][c_padded]; for_dgrad = 1 prepares the (optionally
+ * mirrored) transposed weights of the input gradient, replacing osn_weight_transpose.
+ * Here `cin` = contraction channels of `in`, `cout` = output channels.  Needs cin % 4 == 0.          */
+size_t osn_weight_prep_x6_bytes(int K, int cin, int cout, int for_dgrad);
+int osn_weight_prep_x6(const float* W, int K, int cin, int cout, int flip, int for_dgrad, void* Wp,
+                       osn_stream_t stream);
+int osn_spconv_fwd_x6(const float* in, const void* Wp, const int32_t* nbr, const int32_t* out_rows,
+                      const uint32_t* gmask, float* out, int64_t n_out, int K, int cin, int cout,
+                      void* ws, size_t ws_bytes, osn_stream_t stream);
+
 /* Which kernel instance / launch shape osn_spconv_fwd() uses for a problem (host helper, for
  * profiling): plan6 = {WM, WN, TN, BK, S (offset splits), workgroups};
  * the kernel symbol is spconv_fwd_kernel<WM, WN, TN, BK>.                          */

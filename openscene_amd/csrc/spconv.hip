@@ -407,6 +407,271 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_pipe_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Split-bf16 variant of the pipelined kernel: identical tiling / pipeline / units logic, but the
+// contraction runs on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  Each fp32 operand is
+// split into three bf16 pieces (x = x1 + x2 + x3) and the six significant cross products are
+// accumulated in fp32 ("bf16x6"): fp32-level accuracy at 2.7x the fp32 MFMA throughput.  The
+// weights arrive pre-split and k-contiguous (osn_weight_prep_x6); the gathered rows stay fp32 in
+// LDS and are split in registers right before the MFMAs (VALU work that overlaps the matrix pipe).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int WM, int WN, int TN>
+__global__ __launch_bounds__(256, 2) void spconv_fwd_x6_kernel(const float* __restrict__ in, const __bf16* __restrict__ Wp,
+                                                              const int32_t* __restrict__ nbr,
+                                                              const int32_t* __restrict__ out_rows,
+                                                              const uint32_t* __restrict__ gmask,
+                                                              int32_t* __restrict__ tile_parts,
+                                                              float* __restrict__ out, float* __restrict__ extra,
+                                                              int n_out, int K, int cin, int cinp, int cout,
+                                                              int k_per_split, int to_partial, int unit_k) {
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * TN * WN;
+    constexpr int BK = 32;
+    constexpr int KC = 32;                       // offsets per block (k_per_split <= KC)
+    constexpr int NA = BM / 32;                  // A float4 per thread per stage
+    constexpr int NBV = 3 * BN * 4;              // B: 3 planes x BN rows x 4 x (8 bf16 = 16 bytes)
+    constexpr int NB = (NBV + 255) / 256;        // B 16-byte pieces per thread per stage
+    constexpr int LDA = BK + 4;                  // fp32 A rows of 144 B: aligned + conflict-free ds_read_b128
+    constexpr int LDB = BK + 8;                  // bf16 B rows of 80 B:  aligned + conflict-free ds_read_b128
+    __shared__ __attribute__((aligned(16))) float As[BM][LDA];
+    __shared__ __attribute__((aligned(16))) __bf16 Bp[3][BN][LDB];
+    __shared__ int ridx[2][BM];                  // row indices of the next two stages (by stage parity)
+    __shared__ unsigned char gbits[KC][2];
+    __shared__ int klist[KC];
+    __shared__ int kgm[KC];
+    __shared__ int nact_s;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int row0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    // Two ways to cut the offset loop across blockIdx.z:
+    //  * units mode (gmask given): part z takes the z-th group of `unit_k` ACTIVE offsets of this tile
+    //    (work per block is bounded and even; parts > 0 go to `extra`, summed in order by a fix-up pass);
+    //  * uniform mode: part z takes offsets [z*k_per_split, (z+1)*k_per_split) (small maps).
+    const bool units = gmask != nullptr;
+    const int part = blockIdx.z;
+    const int k_begin = units ? 0 : part * k_per_split;
+    const int nk = units ? K : min(K, k_begin + k_per_split) - k_begin;     // <= KC
+    const int my_row = row0 + tid;                               // meaningful for tid < BM
+    const bool row_ok = tid < BM && my_row < n_out;
+    __shared__ uint32_t gm_s[4];
+
+    if (units) {
+        // ---- prologue from the precomputed 32-row group masks: no table scan
+        if (tid < 4) {
+            const int64_t g = int64_t(blockIdx.x) * WM + tid;
+            gm_s[tid] = (tid < WM && g * 32 < n_out) ? gmask[g] : 0u;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t tm = gm_s[0] | gm_s[1] | gm_s[2] | gm_s[3];
+            int i = 0, n = 0;
+            for (int kk = 0; kk < nk; ++kk) {
+                if (!((tm >> kk) & 1u)) continue;
+                if (i >= part * unit_k && i < (part + 1) * unit_k) {
+                    klist[n] = kk;
+                    kgm[n] = int((gm_s[0] >> kk) & 1u) | (int((gm_s[1] >> kk) & 1u) << 1) |
+                             (int((gm_s[2] >> kk) & 1u) << 2) | (int((gm_s[3] >> kk) & 1u) << 3);
+                    ++n;
+                }
+                ++i;
+            }
+            nact_s = n;
+            if (part == 0 && blockIdx.y == 0) tile_parts[blockIdx.x] = (i + unit_k - 1) / unit_k;
+        }
+        __syncthreads();
+        if (part > 0 && nact_s == 0) return;     // this tile has no offsets left for part z
+    } else {
+    // ---- prologue: which offsets does this tile use, and which of its 32-row groups
+    for (int kk0 = 0; kk0 < nk; kk0 += 8) {
+        int idx[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            idx[j] = -1;
+            if (row_ok && kk0 + j < nk) idx[j] = nbr ? nbr[int64_t(k_begin + kk0 + j) * n_out + my_row] : my_row;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned long long b = __ballot(idx[j] >= 0);
+            if (lane == 0 && wave < 2 && kk0 + j < nk)
+                gbits[kk0 + j][wave] = (unsigned char)(((b & 0xFFFFFFFFull) != 0 ? 1 : 0) | ((b >> 32) != 0 ? 2 : 0));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int kk = 0; kk < nk; ++kk) {
+            const int gm = int(gbits[kk][0]) | (int(gbits[kk][1]) << 2);
+            if (gm) { klist[n] = kk; kgm[n] = gm; ++n; }
+        }
+        nact_s = n;
+    }
+    __syncthreads();
+    }   // !units
+    const int nact = nact_s;
+    const int nchunk = (cin + BK - 1) / BK;
+    const int nstage = nact * nchunk;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float4 pa[NA];
+    uint4 pb[NB];
+    const int a_sub = tid & 7, a_r = tid >> 3;
+
+    // All loads below are UNCONDITIONAL (invalid lanes read a clamped, valid address and the value
+    // is zeroed when it is written to LDS): straight-line code, so the compiler keeps the loads in
+    // flight across the MFMA block instead of draining them at a control-flow join.
+    unsigned pa_ok = 0, pb_ok = 0;
+    auto fetch = [&](int slot, int c0, int par) {
+        const int kk = klist[slot], gm = kgm[slot];
+        const int c = c0 + a_sub * 4;
+        pa_ok = 0;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const int i = ridx[par][p * 32 + a_r];
+            const bool ok = ((gm >> p) & 1) && i >= 0 && c < cin;
+            pa[p] = *reinterpret_cast<const float4*>(in + (ok ? int64_t(i) * cin + c : 0));
+            pa_ok |= (ok ? 1u : 0u) << p;
+        }
+        // weights: pre-split bf16 planes, k-contiguous rows  Wp[plane][K][cout][cinp]
+        pb_ok = 0;
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+            const int f = tid + h * 256;
+            const int pl = f / (BN * 4), rem = f - pl * (BN * 4);
+            const int nn = rem >> 2, j = rem & 3;
+            const int n = n0 + nn;
+            const bool ok = f < NBV && n < cout && c0 + 8 * j < cinp;
+            const __bf16* src = Wp + ((int64_t(pl) * K + (k_begin + kk)) * cout + n) * cinp + c0 + 8 * j;
+            pb[h] = *reinterpret_cast<const uint4*>(ok ? src : Wp);
+            pb_ok |= (ok ? 1u : 0u) << h;
+        }
+    };
+    auto stash = [&](int slot) {
+        const int gm = kgm[slot];
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            if ((gm >> p) & 1) {
+                const bool ok = (pa_ok >> p) & 1;
+                float4 v = pa[p];
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&As[p * 32 + a_r][a_sub * 4]) = v;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+            const int f = tid + h * 256;
+            const int pl = f / (BN * 4), rem = f - pl * (BN * 4);
+            const int nn = rem >> 2, j = rem & 3;
+            if (f < NBV) {
+                uint4 v = pb[h];
+                if (!((pb_ok >> h) & 1)) v = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(&Bp[pl][nn][8 * j]) = v;
+            }
+        }
+    };
+
+    if (nstage > 0) {
+        // stage s = (slot, chunk ch).  Gathered rows + weights are fetched one stage ahead into
+        // registers; the row indices of stage s+2 are fetched during stage s.  That index load is
+        // issued through inline asm: hipcc's waitcnt pass otherwise drains every load in flight
+        // around a loop-carried load destination (vmcnt is in-order), which serialises the prefetch.
+        // The value is consumed in the same iteration, after an explicit vmcnt(0).
+        auto advance = [&](int& sl, int& c) { if (++c == nchunk) { c = 0; ++sl; } };
+        int slot = 0, ch = 0;
+        int slot1 = 0, ch1 = 0; advance(slot1, ch1);
+        int slot2 = slot1, ch2 = ch1; advance(slot2, ch2);
+        auto idx_ptr = [&](int sl) -> const int32_t* {
+            return nbr + (row_ok ? int64_t(k_begin + klist[sl]) * n_out + my_row : 0);
+        };
+        if (tid < BM) ridx[0][tid] = row_ok ? (nbr ? *idx_ptr(0) : my_row) : -1;
+        __syncthreads();
+        fetch(0, 0, 0);
+        const int i1 = nbr ? *idx_ptr(nstage > 1 ? slot1 : 0) : my_row;
+        stash(0);
+        if (tid < BM) ridx[1][tid] = row_ok ? i1 : -1;
+        __syncthreads();
+        for (int s = 0; s < nstage; ++s) {
+            const bool more = s + 1 < nstage, more2 = s + 2 < nstage;
+            if (more) fetch(slot1, ch1 * BK, (s + 1) & 1);            // loads in flight during the MFMAs
+            int i2 = my_row;
+            if (nbr) {
+                const int32_t* p2 = idx_ptr(more2 ? slot2 : slot);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(i2) : "v"(p2) : "memory");
+            }
+            if ((kgm[slot] >> wm) & 1) {
+                // fp32-equivalent product from six bf16 MFMAs: x = x1 + x2 + x3 (8 mantissa bits each),
+                // a*b ~= a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1  (dropped terms <= 2^-24 relative)
+                const int arow = wm * 32 + (lane & 31);
+                const int kq = 8 * (lane >> 5);
+                const int bcol = wn * TN * 32 + (lane & 31);
+#pragma unroll
+                for (int ks = 0; ks < BK / 16; ++ks) {
+                    const float4 f0 = *reinterpret_cast<const float4*>(&As[arow][ks * 16 + kq]);
+                    const float4 f1 = *reinterpret_cast<const float4*>(&As[arow][ks * 16 + kq + 4]);
+                    const float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                    bf16x8 a1, a2, a3;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const __bf16 h1 = (__bf16)fv[e];
+                        const float r1 = fv[e] - (float)h1;
+                        const __bf16 h2 = (__bf16)r1;
+                        const float r2 = r1 - (float)h2;
+                        a1[e] = h1; a2[e] = h2; a3[e] = (__bf16)r2;
+                    }
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) {
+                        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bp[0][bcol + t * 32][ks * 16 + kq]);
+                        const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(&Bp[1][bcol + t * 32][ks * 16 + kq]);
+                        const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(&Bp[2][bcol + t * 32][ks * 16 + kq]);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();                  // stage s consumed; ridx[s&1] is free (its fetch ran an iteration ago)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // covers the asm index load above
+            if (more) stash(slot1);
+            if (more2 && tid < BM) ridx[s & 1][tid] = row_ok ? i2 : -1;       // stage s+2 reuses stage s' slot
+            __syncthreads();
+            slot = slot1; ch = ch1;
+            slot1 = slot2; ch1 = ch2;
+            advance(slot2, ch2);
+        }
+    }
+
+    float* dst = out;
+    bool direct = !to_partial;                   // rows go to their final place (through out_rows)
+    if (units) {
+        if (part > 0) { dst = extra + int64_t(part - 1) * n_out * cout; direct = false; }
+    } else if (to_partial) {
+        dst = out + int64_t(blockIdx.z) * n_out * cout;
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int col = n0 + (wn * TN + t) * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < n_out && col < cout) {
+                const int orow = (direct && out_rows) ? out_rows[row] : row;
+                dst[int64_t(orow) * cout + col] = acc[t][r];
+            }
+        }
+    }
+}
+
 __global__ void reduce_partial_rows_kernel(const float* __restrict__ partial, int S, int64_t n_out, int cout,
                                            const int32_t* __restrict__ out_rows, float* __restrict__ out) {
     const int64_t total = n_out * cout;
@@ -436,6 +701,30 @@ __global__ void fixup_units_kernel(const float* __restrict__ extra, const int32_
         float s = out[o];
         for (int p = 1; p < np; ++p) s += extra[int64_t(p - 1) * total + e];
         out[o] = s;
+    }
+}
+
+// Wp[plane][k][n][c] (bf16, c padded to cp with zeros) = piece `plane` of the weight that multiplies input
+// channel c into output channel n at offset k:  forward  W[k][c][n];  input gradient  W[flip ? K-1-k : k][n][c].
+__global__ void weight_prep_x6_kernel(const float* __restrict__ W, int K, int cin, int cout, int flip, int for_dgrad,
+                                      int nn, int nc, int cp, __bf16* __restrict__ Wp) {
+    const int64_t per_plane = int64_t(K) * nn * cp;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < per_plane; e += int64_t(gridDim.x) * blockDim.x) {
+        const int c = int(e % cp);
+        const int n = int((e / cp) % nn);
+        const int k = int(e / (int64_t(cp) * nn));
+        float v = 0.f;
+        if (c < nc) {
+            const int ks = flip ? K - 1 - k : k;
+            v = for_dgrad ? W[(int64_t(ks) * cin + n) * cout + c] : W[(int64_t(ks) * cin + c) * cout + n];
+        }
+        const __bf16 h1 = (__bf16)v;
+        const float r1 = v - (float)h1;
+        const __bf16 h2 = (__bf16)r1;
+        const float r2 = r1 - (float)h2;
+        Wp[e] = h1;
+        Wp[per_plane + e] = h2;
+        Wp[2 * per_plane + e] = (__bf16)r2;
     }
 }
 
@@ -849,6 +1138,16 @@ static void launch_fwd_pipe(const FwdPlan& p, hipStream_t st, const float* in, c
                        (!u.gmask && p.S > 1) ? 1 : 0, p.unit_k);
 }
 
+template <int WM, int WN, int TN>
+static void launch_fwd_x6(const FwdPlan& p, hipStream_t st, const float* in, const __bf16* Wp, const int32_t* nbr,
+                          const int32_t* out_rows, float* dst, int n_out, int K, int cin, int cinp, int cout,
+                          const UnitsArgs& u) {
+    const int gz = u.gmask ? p.unit_parts : p.S;
+    hipLaunchKernelGGL((spconv_fwd_x6_kernel<WM, WN, TN>), dim3(p.gx, p.gy, gz), dim3(256), 0, st, in, Wp, nbr,
+                       out_rows, u.gmask, u.tile_parts, dst, u.extra, n_out, K, cin, cinp, cout, p.kps,
+                       (!u.gmask && p.S > 1) ? 1 : 0, p.unit_k);
+}
+
 template <int WM, int WN, int TN, int BK>
 static void launch_fwd(const FwdPlan& p, hipStream_t st, const float* in, const float* W, const int32_t* nbr,
                        const int32_t* out_rows, float* dst, int n_out, int K, int cin, int cout) {
@@ -927,6 +1226,82 @@ extern "C" int osn_spconv_fwd(const float* in, const float* W, const int32_t* nb
         const int64_t total = n_out * cout;
         int g = int(cdiv(total, 256));
         if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(reduce_partial_rows_kernel, dim3(g), dim3(256), 0, st, dst, p.S, n_out, cout, out_rows, out);
+        OSN_LAUNCH_CHECK();
+    }
+    return OSN_OK;
+}
+
+extern "C" size_t osn_weight_prep_x6_bytes(int K, int cin, int cout, int for_dgrad) {
+    const int nn = for_dgrad ? cin : cout, nc = for_dgrad ? cout : cin;
+    const int cp = (nc + 31) / 32 * 32;
+    return size_t(3) * size_t(K) * size_t(nn) * size_t(cp) * 2;
+}
+
+extern "C" int osn_weight_prep_x6(const float* W, int K, int cin, int cout, int flip, int for_dgrad, void* Wp,
+                                  osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(W && Wp && K >= 1 && cin >= 1 && cout >= 1, OSN_E_ARG, "osn_weight_prep_x6: bad arguments");
+    const int nn = for_dgrad ? cin : cout, nc = for_dgrad ? cout : cin;
+    const int cp = (nc + 31) / 32 * 32;
+    const int64_t per_plane = int64_t(K) * nn * cp;
+    int g = int(cdiv(per_plane, 256));
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(weight_prep_x6_kernel, dim3(g), dim3(256), 0, st, W, K, cin, cout, flip, for_dgrad, nn, nc, cp,
+                       static_cast<__bf16*>(Wp));
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}
+
+extern "C" int osn_spconv_fwd_x6(const float* in, const void* Wp, const int32_t* nbr, const int32_t* out_rows,
+                                 const uint32_t* gmask, float* out, int64_t n_out, int K, int cin, int cout, void* ws,
+                                 size_t ws_bytes, osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_spconv_fwd_x6: n_out out of range");
+    OSN_REQUIRE(K >= 1 && cin >= 4 && (cin & 3) == 0 && cout >= 1, OSN_E_ARG,
+                "osn_spconv_fwd_x6: needs cin %% 4 == 0 (K=%d cin=%d cout=%d)", K, cin, cout);
+    if (n_out == 0) return OSN_OK;
+    OSN_REQUIRE(in && Wp && out, OSN_E_ARG, "osn_spconv_fwd_x6: null pointer");
+    OSN_REQUIRE(nbr || K == 1, OSN_E_ARG, "osn_spconv_fwd_x6: nbr may be null only for K == 1");
+    OSN_REQUIRE(aligned16(in) && aligned16(Wp) && aligned16(out), OSN_E_ARG, "osn_spconv_fwd_x6: pointers must be 16-byte aligned");
+    FwdPlan p = plan_fwd(n_out, K, cin, cout);
+    OSN_REQUIRE(p.kps <= 32, OSN_E_ARG, "osn_spconv_fwd_x6: more than 32 offsets per block (K=%d)", K);
+    float* dst = out;
+    UnitsArgs ua = {nullptr, nullptr, nullptr};
+    const bool use_units = gmask && nbr && K > p.unit_k && K <= 32 && p.S == 1;
+    if (use_units) {
+        p.unit_parts = int(cdiv(K, p.unit_k));
+        const size_t need = units_ws_bytes(p, n_out, cout);
+        OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_spconv_fwd_x6: workspace %zu < %zu", ws_bytes, need);
+        ua.gmask = gmask;
+        ua.tile_parts = static_cast<int32_t*>(ws);
+        ua.extra = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up(size_t(p.gx) * 4, 256));
+    } else if (p.S > 1) {
+        const size_t need = size_t(p.S) * size_t(n_out) * size_t(cout) * 4;
+        OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_spconv_fwd_x6: workspace %zu < %zu", ws_bytes, need);
+        dst = static_cast<float*>(ws);
+    }
+    const int n = int(n_out);
+    const int cinp = (cin + 31) / 32 * 32;
+    const __bf16* wp = static_cast<const __bf16*>(Wp);
+    switch (p.cfg * 10 + p.tn) {
+        case 1: launch_fwd_x6<4, 1, 1>(p, st, in, wp, nbr, out_rows, dst, n, K, cin, cinp, cout, ua); break;
+        case 2: launch_fwd_x6<4, 1, 2>(p, st, in, wp, nbr, out_rows, dst, n, K, cin, cinp, cout, ua); break;
+        case 3: launch_fwd_x6<4, 1, 3>(p, st, in, wp, nbr, out_rows, dst, n, K, cin, cinp, cout, ua); break;
+        case 4: launch_fwd_x6<4, 1, 4>(p, st, in, wp, nbr, out_rows, dst, n, K, cin, cinp, cout, ua); break;
+        case 11: launch_fwd_x6<2, 2, 1>(p, st, in, wp, nbr, out_rows, dst, n, K, cin, cinp, cout, ua); break;
+        case 12: launch_fwd_x6<2, 2, 2>(p, st, in, wp, nbr, out_rows, dst, n, K, cin, cinp, cout, ua); break;
+        default: launch_fwd_x6<1, 4, 1>(p, st, in, wp, nbr, out_rows, dst, n, K, cin, cinp, cout, ua); break;
+    }
+    OSN_LAUNCH_CHECK();
+    const int64_t total = n_out * cout;
+    int g = int(cdiv(total, 256));
+    if (g > 4096) g = 4096;
+    if (use_units) {
+        hipLaunchKernelGGL(fixup_units_kernel, dim3(g), dim3(256), 0, st, ua.extra, ua.tile_parts, p.bm, n_out, cout,
+                           out_rows, out);
+        OSN_LAUNCH_CHECK();
+    } else if (p.S > 1) {
         hipLaunchKernelGGL(reduce_partial_rows_kernel, dim3(g), dim3(256), 0, st, dst, p.S, n_out, cout, out_rows, out);
         OSN_LAUNCH_CHECK();
     }

@@ -1,10 +1,18 @@
 """Autograd glue: each Function's forward/backward is one or two C-ABI calls on
 the current HIP stream (backward runs on autograd's thread; the library is
 stateless so that is safe)."""
+import os
+
 import torch
 from torch.autograd import Function
 
 from . import ops
+
+# Arithmetic of the forward / input-gradient convolutions:
+#   "fp32"   v_mfma_f32_32x32x2_f32 (exact fp32 products, 157 TF peak)
+#   "bf16x6" three-way bf16 split of both operands, six bf16 MFMAs per product block, fp32 accumulate:
+#            fp32-level accuracy at 2.7x the MFMA throughput (osn_spconv_fwd_x6)
+CONV_MODE = os.environ.get("OSN_CONV_MODE", "fp32")
 
 
 class SparseConvFunction(Function):
@@ -16,9 +24,12 @@ class SparseConvFunction(Function):
         ctx.save_for_backward(feats, kernel)
         ctx.maps = (nbr_fwd, nbr_bwd, bool(flip), tiles_bwd, counts)
         ctx.n_in = feats.shape[0]
-        if tiles_fwd is not None:            # (order, row-permuted table): same result, tile-friendly order
-            return ops.spconv_fwd(feats, kernel, tiles_fwd[1], n_out, out_rows=tiles_fwd[0], gmask=tiles_fwd[2])
-        return ops.spconv_fwd(feats, kernel, nbr_fwd, n_out)
+        K = 1 if kernel.dim() == 2 else kernel.shape[0]
+        cin, cout = kernel.shape[-2], kernel.shape[-1]
+        tbl, rows, gm = (tiles_fwd[1], tiles_fwd[0], tiles_fwd[2]) if tiles_fwd is not None else (nbr_fwd, None, None)
+        if CONV_MODE == "bf16x6" and ops.x6_eligible(K, cin, cout, n_out):
+            return ops.spconv_fwd_x6(feats, ops.weight_prep_x6(kernel), tbl, n_out, out_rows=rows, gmask=gm)
+        return ops.spconv_fwd(feats, kernel, tbl, n_out, out_rows=rows, gmask=gm)
 
     @staticmethod
     def backward(ctx, gout):
@@ -28,11 +39,13 @@ class SparseConvFunction(Function):
         gin = gk = None
         K = 1 if kernel.dim() == 2 else kernel.shape[0]
         if ctx.needs_input_grad[0]:
-            wt = ops.weight_transpose(kernel, flip)
-            if tiles_bwd is not None:
-                gin = ops.spconv_fwd(gout, wt, tiles_bwd[1], ctx.n_in, out_rows=tiles_bwd[0], gmask=tiles_bwd[2])
+            cin, cout = kernel.shape[-2], kernel.shape[-1]
+            tbl, rows, gm = (tiles_bwd[1], tiles_bwd[0], tiles_bwd[2]) if tiles_bwd is not None else (nbr_bwd, None, None)
+            if CONV_MODE == "bf16x6" and ops.x6_eligible(K, cout, cin, ctx.n_in):
+                wp = ops.weight_prep_x6(kernel, flip=flip, for_dgrad=True)
+                gin = ops.spconv_fwd_x6(gout, wp, tbl, ctx.n_in, out_rows=rows, gmask=gm)
             else:
-                gin = ops.spconv_fwd(gout, wt, nbr_bwd, ctx.n_in)
+                gin = ops.spconv_fwd(gout, ops.weight_transpose(kernel, flip), tbl, ctx.n_in, out_rows=rows, gmask=gm)
         if ctx.needs_input_grad[1]:
             gk = ops.spconv_wgrad(feats, gout, nbr_fwd, K, counts).reshape(kernel.shape)
         return gin, gk, None, None, None, None, None, None, None

@@ -181,6 +181,58 @@ def spconv_fwd(feats, weight, nbr, n_out, out_rows=None, gmask=None):
     return out
 
 
+def weight_prep_x6(weight, flip=False, for_dgrad=False):
+    """bf16 [3, K, n, c_pad] pre-split weights for spconv_fwd_x6 (n = output channels of the conv that will run)."""
+    dev = weight.device
+    lib = _prep(dev)
+    w = _f32c(_w3(weight), "weight")
+    K, cin, cout = w.shape
+    nn, nc = (cin, cout) if for_dgrad else (cout, cin)
+    cp = (nc + 31) // 32 * 32
+    wp = torch.empty((3, K, nn, cp), dtype=torch.bfloat16, device=dev)
+    with _Dev(dev):
+        check(lib.osn_weight_prep_x6(_p(w), K, cin, cout, int(bool(flip)), int(bool(for_dgrad)), _p(wp), _stream(dev)),
+              "osn_weight_prep_x6")
+    return wp
+
+
+def spconv_fwd_x6(feats, wp, nbr, n_out, out_rows=None, gmask=None):
+    """Split-bf16 convolution: out[o] = sum_k feats[nbr[k,o]] @ B[k], B given as weight_prep_x6 planes."""
+    dev = feats.device
+    lib = _prep(dev)
+    feats = _f32c(feats, "features")
+    _three, K, cout, cp = wp.shape
+    cin = feats.shape[1]
+    if (cin + 31) // 32 * 32 != cp:
+        raise ValueError("features have %d channels, prepared weights expect <= %d" % (cin, cp))
+    if nbr is not None:
+        if nbr.dtype != torch.int32 or nbr.shape != (K, n_out):
+            raise ValueError("nbr must be int32 [%d, %d], got %s %s" % (K, n_out, nbr.dtype, tuple(nbr.shape)))
+        nbr = nbr.contiguous()
+    elif K != 1 or feats.shape[0] != n_out:
+        raise ValueError("nbr=None is the identity map and needs K == 1 and n_in == n_out")
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    wsb = lib.osn_spconv_fwd_ws_bytes(n_out, K, cin, cout)
+    ws = _ws(wsb, dev) if wsb else None
+    tok = _profiler.start("spconv_fwd_x6", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
+        if _profiler is not None else None
+    with _Dev(dev):
+        check(lib.osn_spconv_fwd_x6(_p(feats), _p(wp), _p(nbr), _p(out_rows), _p(gmask), _p(out), n_out, K, cin, cout,
+                                    _p(ws), int(wsb), _stream(dev)), "osn_spconv_fwd_x6")
+    if tok is not None:
+        _profiler.stop(tok)
+    return out
+
+
+def x6_eligible(K, cin, cout, n_out):
+    """The split-bf16 kernel handles every conv of the U-Net except the 3-channel stem."""
+    if cin % 4 or cin < 8:
+        return False
+    plan = spconv_fwd_plan(n_out, K, cin, cout)
+    S = plan[4]
+    return -(-K // S) <= 32
+
+
 def weight_transpose(weight, flip):
     dev = weight.device
     lib = _prep(dev)

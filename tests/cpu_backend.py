@@ -81,6 +81,21 @@ def spconv_fwd(feats, weight, nbr, n_out, out_rows=None, gmask=None):
     return out
 
 
+def weight_prep_x6(weight, flip=False, for_dgrad=False):
+    w = _w3(weight)
+    if flip:
+        w = torch.flip(w, dims=[0])
+    return ("x6", w if not for_dgrad else w.transpose(1, 2).contiguous())
+
+
+def spconv_fwd_x6(feats, wp, nbr, n_out, out_rows=None, gmask=None):
+    return spconv_fwd(feats, wp[1], nbr, n_out, out_rows=out_rows)
+
+
+def x6_eligible(K, cin, cout, n_out):
+    return cin % 4 == 0 and cin >= 8
+
+
 def weight_transpose(weight, flip):
     w = _w3(weight)
     if flip:
@@ -163,7 +178,7 @@ def fnv_hash(grid):
     return torch.from_numpy(ov.fnv_keys(_np(grid)).view(np.int64))
 
 
-_NAMES = ["HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_transpose",
+_NAMES = ["HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
           "spconv_wgrad", "bn_stats", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
           "fnv_hash"]
 

@@ -24,8 +24,11 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert lib.osn_version() == 1
     assert lib.osn_hash_capacity(1000) == 2048 and lib.osn_hash_capacity(0) == 1024
     assert lib.osn_bn_ws_bytes(10, 32) > 0 and lib.osn_coords_unique_ws_bytes(1000) > 0
-    assert lib.osn_spconv_fwd_ws_bytes(100999, 27, 96, 96) == 0          # big maps: no offset split
+    # big maps: room for the (K/8 - 1) partial buffers of the units mode; 1x1 convs need no scratch
+    assert lib.osn_spconv_fwd_ws_bytes(100999, 27, 96, 96) >= 3 * 100999 * 96 * 4
+    assert lib.osn_spconv_fwd_ws_bytes(100999, 1, 96, 768) == 0
     assert lib.osn_spconv_fwd_ws_bytes(700, 27, 256, 256) > 0            # deep level: split + reduce buffer
+    assert lib.osn_weight_prep_x6_bytes(27, 96, 128, 0) == 3 * 27 * 128 * 96 * 2
 
 
 def test_header_cites_reference_lines():

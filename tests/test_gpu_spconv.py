@@ -72,9 +72,13 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x6"])
 @pytest.mark.parametrize("kind,key,cin,cout", CASES)
-def test_forward_and_gradients(kind, key, cin, cout):
+def test_forward_and_gradients(kind, key, cin, cout, mode, monkeypatch):
+    """Both arithmetic modes of the forward / input-gradient kernels meet the SAME tolerance: the
+    split-bf16 mode (three bf16 pieces per operand, six MFMAs per product block) is fp32-accurate."""
     from openscene_amd import functional as F_
+    monkeypatch.setattr(F_, "CONV_MODE", mode)
     cm = cloud(kind)
     si, so_, k = key
     K = k ** 3
@@ -172,3 +176,21 @@ def test_empty_and_bad_arguments():
                        torch.zeros((27, 4), dtype=torch.int32, device=d), 4)
     with pytest.raises(ValueError):
         ops.spconv_fwd(torch.zeros((4, 32), device=d), torch.zeros((27, 32, 32), device=d), None, 4)
+
+
+def test_weight_prep_x6_is_an_exact_three_way_split():
+    """hi + mid + lo reproduces the fp32 weight to <= 2^-24 relative, in both layouts."""
+    from openscene_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(27, 40, 24, generator=g).to(d)
+    for flip, dgrad in ((False, False), (True, True), (False, True)):
+        wp = ops.weight_prep_x6(w, flip=flip, for_dgrad=dgrad).float()
+        assert wp.shape == (3, 27, 40 if dgrad else 24, 32 if dgrad else 64)
+        rec = wp.sum(0)
+        ref = torch.flip(w, dims=[0]) if flip else w
+        ref = ref if dgrad else ref.transpose(1, 2)
+        nc = ref.shape[2]
+        assert torch.all(rec[:, :, nc:] == 0)
+        err = (rec[:, :, :nc] - ref).abs().max().item()
+        assert err <= 2 ** -23 * ref.abs().max().item()

@@ -49,6 +49,13 @@ def main():
             cnt = ops.kmap_count(nbr)
             print("wgrad(balanced) %.1f us" % timed(lambda: ops.spconv_wgrad(x, g, nbr, 27, cnt), reps))
             continue
+        wp = ops.weight_prep_x6(w)
+        t_x6 = timed(lambda: ops.spconv_fwd_x6(x, wp, tbl, n, out_rows=order, gmask=gm), reps)
+        t_prep = timed(lambda: ops.weight_prep_x6(w), reps)
+        ref = ops.spconv_fwd(x, w, tbl, n, out_rows=order, gmask=gm)
+        got = ops.spconv_fwd_x6(x, wp, tbl, n, out_rows=order, gmask=gm)
+        print("   bf16x6 fwd %.1f us (+ weight prep %.1f us), max|d| vs fp32 kernel = %.2e of max" % (
+            t_x6, t_prep, (got - ref).abs().max().item() / ref.abs().max().item()))
         t_fwd_sorted = timed(lambda: ops.spconv_fwd(x, w, tbl, n, out_rows=order, gmask=gm), reps)
         t_fwd_plain = timed(lambda: ops.spconv_fwd(x, w, nbr, n), reps)
         cnt = ops.kmap_count(nbr)
