@@ -97,9 +97,9 @@ class LaunchProfiler:
         return groups
 
 
-def build_scene(seed, device):
+def build_scene(seed, device, n_pts=120000):
     from openscene_amd import synthetic as syn
-    vox = syn.shuffled(syn.grid_voxels(syn.room_points(seed), 0.02), seed)
+    vox = syn.shuffled(syn.grid_voxels(syn.room_points(seed, n_pts=n_pts), 0.02), seed)
     coords = syn.batch_coords([vox])
     return torch.from_numpy(coords).to(device)
 
@@ -224,6 +224,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--arch", default="MinkUNet18A")
     ap.add_argument("--feature", default="openseg", help="openseg (768-d) | lseg (512-d)")
+    ap.add_argument("--scene-points", type=int, default=120000, help="surface samples of the synthetic scene "
+                    "(120000 = S100k, the headline workload; smaller values are for overhead studies only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -267,7 +269,7 @@ def main():
     except (TypeError, RuntimeError):
         optim = torch.optim.Adam(net.parameters(), lr=1e-4)
 
-    coords0 = build_scene(rank, device)             # one scene per GPU (batch 8 over 8 GPUs), seed = rank
+    coords0 = build_scene(rank, device, args.scene_points)             # one scene per GPU (batch 8 over 8 GPUs), seed = rank
     n_vox = coords0.shape[0]
     feats = torch.ones(n_vox, 3, device=device)     # input_color: False -> constant ones (feature_loader.py:183-184)
     g = torch.Generator().manual_seed(100 + rank)
