@@ -89,6 +89,7 @@ class MinkUNetBase(nn.Module):
             return self._forward(x)
 
     def _forward(self, x):
+        x.coordinate_manager.prebuild()       # all level syncs first, then the host runs ahead of the GPU
         out = self._conv_bn_relu(x, self.conv0p1s1, self.bn0)
         skips = [out]
         for i in range(4):

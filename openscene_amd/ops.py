@@ -28,8 +28,33 @@ def _stream(dev):
     return _vp(torch.cuda.current_stream(dev).cuda_stream)
 
 
+# Scratch for the C-ABI calls: ONE growing buffer per (device, stream).  Every call's scratch is only
+# live while that call's kernels run, and calls on one stream execute in order (autograd's backward
+# thread launches on the same stream), so sharing is safe and saves a torch.empty per launch.
+_ws_pool = {}
+
+
 def _ws(nbytes, dev):
-    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+    nbytes = max(int(nbytes), 16)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _ws_pool.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
+        _ws_pool[key] = buf
+    return buf
+
+
+_size_cache = {}
+
+
+def _cached(fn_name, *args):
+    """ws-size / plan helpers are pure functions of their integer arguments: memoise the ctypes call."""
+    key = (fn_name,) + args
+    v = _size_cache.get(key)
+    if v is None:
+        v = getattr(_lib.load(), fn_name)(*args)
+        _size_cache[key] = v
+    return v
 
 
 def _prep(dev):
@@ -83,7 +108,7 @@ def coords_unique(coords4, stride=1):
     out = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
     inverse = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     first = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    wsb = lib.osn_coords_unique_ws_bytes(n)
+    wsb = _cached("osn_coords_unique_ws_bytes", n)
     ws = _ws(wsb, dev)
     nu = ctypes.c_int64(0)
     with _Dev(dev):
@@ -130,7 +155,7 @@ def kmap_sort(nbr):
     out = torch.empty_like(nbr)
     gmask = torch.empty((n_out + 31) // 32, dtype=torch.int32, device=dev)
     with _Dev(dev):
-        wsb = lib.osn_kmap_sort_ws_bytes(n_out)
+        wsb = _cached("osn_kmap_sort_ws_bytes", n_out)
         ws = _ws(wsb, dev)
         check(lib.osn_kmap_sort(_p(nbr), n_out, K, _p(order), _p(out), _p(gmask), _p(ws), ws.numel(), _stream(dev)),
               "osn_kmap_sort")
@@ -169,7 +194,7 @@ def spconv_fwd(feats, weight, nbr, n_out, out_rows=None, gmask=None):
     elif K != 1 or feats.shape[0] != n_out:
         raise ValueError("nbr=None is the identity map and needs K == 1 and n_in == n_out")
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
-    wsb = lib.osn_spconv_fwd_ws_bytes(n_out, K, cin, cout)
+    wsb = _cached("osn_spconv_fwd_ws_bytes", n_out, K, cin, cout)
     ws = _ws(wsb, dev) if wsb else None
     tok = _profiler.start("spconv_fwd", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
         if _profiler is not None else None
@@ -212,7 +237,7 @@ def spconv_fwd_x6(feats, wp, nbr, n_out, out_rows=None, gmask=None):
     elif K != 1 or feats.shape[0] != n_out:
         raise ValueError("nbr=None is the identity map and needs K == 1 and n_in == n_out")
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
-    wsb = lib.osn_spconv_fwd_ws_bytes(n_out, K, cin, cout)
+    wsb = _cached("osn_spconv_fwd_ws_bytes", n_out, K, cin, cout)
     ws = _ws(wsb, dev) if wsb else None
     tok = _profiler.start("spconv_fwd_x6", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
         if _profiler is not None else None
@@ -257,7 +282,7 @@ def spconv_wgrad(feats, gout, nbr, K, counts=None):
         if nbr.shape != (K, n_out):
             raise ValueError("nbr shape %s does not match (K=%d, n_out=%d)" % (tuple(nbr.shape), K, n_out))
     gw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
-    wsb = lib.osn_spconv_wgrad_ws_bytes(n_out, K, cin, cout)
+    wsb = _cached("osn_spconv_wgrad_ws_bytes", n_out, K, cin, cout)
     ws = _ws(wsb, dev) if wsb else None
     tok = _profiler.start("spconv_wgrad", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
         if _profiler is not None else None
@@ -269,11 +294,18 @@ def spconv_wgrad(feats, gout, nbr, K, counts=None):
     return gw
 
 
+_plan_cache = {}
+
+
 def spconv_fwd_plan(n_out, K, cin, cout):
     """(WM, WN, TN, BK, S, workgroups) of the kernel instance osn_spconv_fwd picks."""
-    plan = (ctypes.c_int32 * 6)()
-    check(_lib.load().osn_spconv_fwd_plan(int(n_out), int(K), int(cin), int(cout), plan), "osn_spconv_fwd_plan")
-    return tuple(plan)
+    key = (int(n_out), int(K), int(cin), int(cout))
+    v = _plan_cache.get(key)
+    if v is None:
+        plan = (ctypes.c_int32 * 6)()
+        check(_lib.load().osn_spconv_fwd_plan(key[0], key[1], key[2], key[3], plan), "osn_spconv_fwd_plan")
+        v = _plan_cache[key] = tuple(plan)
+    return v
 
 
 # ------------------------------------------------------------------ batch norm
@@ -284,7 +316,7 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1):
     n, c = x.shape
     mean = torch.empty(c, dtype=torch.float32, device=dev)
     var = torch.empty(c, dtype=torch.float32, device=dev)
-    wsb = lib.osn_bn_ws_bytes(n, c)
+    wsb = _cached("osn_bn_ws_bytes", n, c)
     ws = _ws(wsb, dev)
     with _Dev(dev):
         check(lib.osn_bn_stats(_p(x), n, c, _p(mean), _p(var), _p(running_mean), _p(running_var), float(momentum),
@@ -317,7 +349,7 @@ def bn_backward(x, y, gy, mean, var, gamma, eps, relu, training, want_gres):
     gres = torch.empty_like(x) if want_gres else None
     ggamma = torch.empty(c, dtype=torch.float32, device=dev)
     gbeta = torch.empty(c, dtype=torch.float32, device=dev)
-    wsb = lib.osn_bn_ws_bytes(n, c)
+    wsb = _cached("osn_bn_ws_bytes", n, c)
     ws = _ws(wsb, dev)
     with _Dev(dev):
         check(lib.osn_bn_backward(_p(x), _p(y), _p(gy), _p(mean), _p(var), _p(gamma), float(eps), int(bool(relu)),

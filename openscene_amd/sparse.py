@@ -102,6 +102,27 @@ class CoordinateManager:
                 self._kmaps[key] = ops.kmap_count(fwd) if fwd is not None else None
         return self._kmaps[key]
 
+    def prebuild(self, strides=(2, 4, 8, 16), kernel_sizes=(3,), stem_kernel=5):
+        """Build the whole coordinate pyramid and every kernel map up front.  Each stride level costs one
+        host<->device sync (the unique count); paying them back to back here, before any heavy kernel is
+        queued, lets the host run ahead of the GPU for the rest of the forward/backward pass instead of
+        draining the queue at every first use of a level."""
+        for s in strides:
+            self.coords(s)
+        levels = (1,) + tuple(strides)
+        if stem_kernel:
+            self.kmap(1, 1, stem_kernel)
+            self.kmap_tiles(1, 1, stem_kernel)
+        for s in levels:
+            for k in kernel_sizes:
+                self.kmap(s, s, k)
+                self.kmap_tiles(s, s, k)
+        for s in levels[:-1]:
+            self.kmap(s, 2 * s, 2)
+            self.kmap_tiles(s, 2 * s, 2)
+            self.kmap(2 * s, s, 2)
+            self.kmap_tiles(2 * s, s, 2)
+
     SORT_MIN_ROWS = 8192      # below this the launch is latency-bound and the sort does not pay
 
     def kmap_tiles(self, in_stride, out_stride, ksize, dilation=1):
