@@ -48,7 +48,10 @@ class LaunchProfiler:
         n = self._names.get(key)
         if n is None:
             from openscene_amd import ops
-            if kind == "spconv_fwd":
+            if kind == "spconv_fwd_x6":
+                wm, wn, tn, bk, S, wgs = ops.spconv_fwd_plan(m["n_out"], m["K"], m["cin"], m["cout"])
+                n = "spconv_fwd_x6_kernel<%d,%d,%d>" % (wm, wn, tn) + ("+reduce" if S > 1 else "")
+            elif kind == "spconv_fwd":
                 wm, wn, tn, bk, S, wgs = ops.spconv_fwd_plan(m["n_out"], m["K"], m["cin"], m["cout"])
                 pipe = m["cin"] > 4 and m["cin"] % 4 == 0 and m["cout"] % 4 == 0 and -(-m["K"] // S) <= 32
                 n = ("spconv_fwd_pipe_kernel<%d,%d,%d>" % (wm, wn, tn) if pipe else
@@ -443,11 +446,13 @@ def main():
             cpu = {"value": None, "unit": "voxels/s", "cores": None, "kind": "port",
                    "sample": "cpu baseline failed: %s" % (str(e)[:200],)}
 
+    from openscene_amd import functional as _F
+    conv_dtype = "f32 (bf16x6 split-precision MFMA, fp32 accumulate)" if _F.CONV_MODE == "bf16x6" else "f32"
     line = {
         "metric": "active voxels/sec MinkUNet18A fwd+bwd @2cm ScanNet; per-point query ms",
         "value": vox_total * args.steps / dt_max, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": conv_dtype, "data": "synthetic",
         "config": {"workload": "ScanNet distillation step (configs[2]): %s, %d-d head, 1 synthetic S100k scene/GPU "
                                "(%d voxels on rank 0, 2 cm), training-mode BN; timed = coordinate+kernel maps, "
                                "forward, cosine loss, backward, DDP all-reduce, Adam step" % (args.arch, out_dim, n_vox),

@@ -9,10 +9,11 @@ from torch.autograd import Function
 from . import ops
 
 # Arithmetic of the forward / input-gradient convolutions:
+#   "bf16x6" (default) three-way bf16 split of both operands, six bf16 MFMAs per product block, fp32
+#            accumulate: fp32-level accuracy (same test tolerances as "fp32") at 2.7x the MFMA throughput
 #   "fp32"   v_mfma_f32_32x32x2_f32 (exact fp32 products, 157 TF peak)
-#   "bf16x6" three-way bf16 split of both operands, six bf16 MFMAs per product block, fp32 accumulate:
-#            fp32-level accuracy at 2.7x the MFMA throughput (osn_spconv_fwd_x6)
-CONV_MODE = os.environ.get("OSN_CONV_MODE", "fp32")
+# The weight gradient always runs on the fp32 MFMA.
+CONV_MODE = os.environ.get("OSN_CONV_MODE", "bf16x6")
 
 
 class SparseConvFunction(Function):
