@@ -116,6 +116,10 @@ int osn_spconv_fwd(const float* in, const float* W, const int32_t* nbr, const in
 size_t osn_weight_prep_x6_bytes(int K, int cin, int cout, int for_dgrad);
 int osn_weight_prep_x6(const float* W, int K, int cin, int cout, int flip, int for_dgrad, void* Wp,
                        osn_stream_t stream);
+/* Both layouts of one weight in ONE launch (training: the forward planes now, the input-gradient planes
+ * kept for the backward pass): Wp_fwd = prep(flip 0, for_dgrad 0), Wp_dgrad = prep(flip, for_dgrad 1). */
+int osn_weight_prep_x6_pair(const float* W, int K, int cin, int cout, int flip, void* Wp_fwd, void* Wp_dgrad,
+                            osn_stream_t stream);
 int osn_spconv_fwd_x6(const float* in, const void* Wp, const int32_t* nbr, const int32_t* out_rows,
                       const uint32_t* gmask, float* out, int64_t n_out, int K, int cin, int cout,
                       void* ws, size_t ws_bytes, osn_stream_t stream);
@@ -136,10 +140,16 @@ int osn_weight_transpose(const float* W, int K, int cin, int cout, int flip, flo
  * counts (nullable, device int64 [K], = osn_kmap_count of nbr): pair count per offset, used
  * to split each offset's rows into work items of equal pair count on the device (the centre
  * offset of a 3^3 map holds 19 % of the pairs, a corner offset < 1 %).  Deterministic: the
- * split is a pure function of (counts, sizes); partial sums are reduced in item order.     */
+ * split is a pure function of (counts, sizes); partial sums are reduced in item order.
+ * plan_items (nullable): the work-item table osn_spconv_wgrad_plan() wrote for the same
+ * (counts, n_out, K) and a (cin, cout) with the same osn_spconv_wgrad_items_bytes -- the table
+ * depends on the map only, so the convs of one map share it and skip the per-call plan launch. */
 size_t osn_spconv_wgrad_ws_bytes(int64_t n_out, int K, int cin, int cout);
+size_t osn_spconv_wgrad_items_bytes(int64_t n_out, int K, int cin, int cout);
+int osn_spconv_wgrad_plan(const int64_t* counts, int64_t n_out, int K, int cin, int cout,
+                          int32_t* items /* osn_spconv_wgrad_items_bytes */, osn_stream_t stream);
 int osn_spconv_wgrad(const float* in, const float* gout, const int32_t* nbr, const int64_t* counts,
-                     float* gW, int64_t n_out, int K, int cin, int cout,
+                     const int32_t* plan_items, float* gW, int64_t n_out, int K, int cin, int cout,
                      void* ws, size_t ws_bytes, osn_stream_t stream);
 
 /* ---- batch norm (+ReLU, +residual) -------------------------------------- *

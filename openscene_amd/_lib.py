@@ -30,11 +30,14 @@ PROTOTYPES = {
     "osn_spconv_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "osn_weight_prep_x6_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "osn_weight_prep_x6": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "osn_weight_prep_x6_pair": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "osn_spconv_fwd_x6": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "osn_spconv_fwd_plan": (_i32, [_i64, _i32, _i32, _i32, _c.POINTER(_i32)]),
     "osn_weight_transpose": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "osn_spconv_wgrad_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
-    "osn_spconv_wgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "osn_spconv_wgrad_items_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "osn_spconv_wgrad_plan": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "osn_spconv_wgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "osn_bn_ws_bytes": (_sz, [_i64, _i32]),
     "osn_bn_stats": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _sz, _vp]),
     "osn_bn_apply": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _i64, _i32, _vp]),

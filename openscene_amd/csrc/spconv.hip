@@ -706,25 +706,36 @@ __global__ void fixup_units_kernel(const float* __restrict__ extra, const int32_
 
 // Wp[plane][k][n][c] (bf16, c padded to cp with zeros) = piece `plane` of the weight that multiplies input
 // channel c into output channel n at offset k:  forward  W[k][c][n];  input gradient  W[flip ? K-1-k : k][n][c].
-__global__ void weight_prep_x6_kernel(const float* __restrict__ W, int K, int cin, int cout, int flip, int for_dgrad,
-                                      int nn, int nc, int cp, __bf16* __restrict__ Wp) {
+__device__ __forceinline__ void weight_prep_x6_one(const float* __restrict__ W, int K, int cin, int cout, int flip,
+                                                    int for_dgrad, int64_t e, __bf16* __restrict__ Wp) {
+    const int nn = for_dgrad ? cin : cout, nc = for_dgrad ? cout : cin;
+    const int cp = (nc + 31) / 32 * 32;
     const int64_t per_plane = int64_t(K) * nn * cp;
-    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < per_plane; e += int64_t(gridDim.x) * blockDim.x) {
-        const int c = int(e % cp);
-        const int n = int((e / cp) % nn);
-        const int k = int(e / (int64_t(cp) * nn));
-        float v = 0.f;
-        if (c < nc) {
-            const int ks = flip ? K - 1 - k : k;
-            v = for_dgrad ? W[(int64_t(ks) * cin + n) * cout + c] : W[(int64_t(ks) * cin + c) * cout + n];
-        }
-        const __bf16 h1 = (__bf16)v;
-        const float r1 = v - (float)h1;
-        const __bf16 h2 = (__bf16)r1;
-        const float r2 = r1 - (float)h2;
-        Wp[e] = h1;
-        Wp[per_plane + e] = h2;
-        Wp[2 * per_plane + e] = (__bf16)r2;
+    const int c = int(e % cp);
+    const int n = int((e / cp) % nn);
+    const int k = int(e / (int64_t(cp) * nn));
+    float v = 0.f;
+    if (c < nc) {
+        const int ks = flip ? K - 1 - k : k;
+        v = for_dgrad ? W[(int64_t(ks) * cin + n) * cout + c] : W[(int64_t(ks) * cin + c) * cout + n];
+    }
+    const __bf16 h1 = (__bf16)v;
+    const float r1 = v - (float)h1;
+    const __bf16 h2 = (__bf16)r1;
+    const float r2 = r1 - (float)h2;
+    Wp[e] = h1;
+    Wp[per_plane + e] = h2;
+    Wp[2 * per_plane + e] = (__bf16)r2;
+}
+
+// One launch fills the forward planes (Wf, nullable) and/or the input-gradient planes (Wb, nullable).
+__global__ void weight_prep_x6_kernel(const float* __restrict__ W, int K, int cin, int cout, int flip_b,
+                                      int64_t per_plane_f, int64_t per_plane_b, __bf16* __restrict__ Wf,
+                                      __bf16* __restrict__ Wb, int flip_f, int dgrad_f) {
+    const int64_t total = per_plane_f + per_plane_b;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        if (e < per_plane_f) weight_prep_x6_one(W, K, cin, cout, flip_f, dgrad_f, e, Wf);
+        else weight_prep_x6_one(W, K, cin, cout, flip_b, 1, e - per_plane_f, Wb);
     }
 }
 
@@ -1247,8 +1258,22 @@ extern "C" int osn_weight_prep_x6(const float* W, int K, int cin, int cout, int 
     const int64_t per_plane = int64_t(K) * nn * cp;
     int g = int(cdiv(per_plane, 256));
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(weight_prep_x6_kernel, dim3(g), dim3(256), 0, st, W, K, cin, cout, flip, for_dgrad, nn, nc, cp,
-                       static_cast<__bf16*>(Wp));
+    hipLaunchKernelGGL(weight_prep_x6_kernel, dim3(g), dim3(256), 0, st, W, K, cin, cout, 0, per_plane, int64_t(0),
+                       static_cast<__bf16*>(Wp), (__bf16*)nullptr, flip, for_dgrad);
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}
+
+extern "C" int osn_weight_prep_x6_pair(const float* W, int K, int cin, int cout, int flip, void* Wp_fwd, void* Wp_dgrad,
+                                       osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(W && Wp_fwd && Wp_dgrad && K >= 1 && cin >= 1 && cout >= 1, OSN_E_ARG, "osn_weight_prep_x6_pair: bad arguments");
+    const int64_t ppf = int64_t(K) * cout * ((cin + 31) / 32 * 32);
+    const int64_t ppb = int64_t(K) * cin * ((cout + 31) / 32 * 32);
+    int g = int(cdiv(ppf + ppb, 256));
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(weight_prep_x6_kernel, dim3(g), dim3(256), 0, st, W, K, cin, cout, flip, ppf, ppb,
+                       static_cast<__bf16*>(Wp_fwd), static_cast<__bf16*>(Wp_dgrad), 0, 0);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
 }
@@ -1326,9 +1351,26 @@ extern "C" size_t osn_spconv_wgrad_ws_bytes(int64_t n_out, int K, int cin, int c
     return p.items_bytes + p.partial_bytes;
 }
 
-extern "C" int osn_spconv_wgrad(const float* in, const float* gout, const int32_t* nbr, const int64_t* counts, float* gW,
-                                int64_t n_out, int K, int cin, int cout, void* ws, size_t ws_bytes,
-                                osn_stream_t stream) {
+extern "C" size_t osn_spconv_wgrad_items_bytes(int64_t n_out, int K, int cin, int cout) {
+    if (n_out <= 0 || K < 1 || cin < 1 || cout < 1) return 0;
+    return plan_wgrad(n_out, K, cin, cout).items_bytes;
+}
+
+extern "C" int osn_spconv_wgrad_plan(const int64_t* counts, int64_t n_out, int K, int cin, int cout, int32_t* items,
+                                     osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n_out > 0 && n_out < (int64_t(1) << 31) && K >= 1 && K <= 125 && cin >= 1 && cout >= 1 && items, OSN_E_ARG,
+                "osn_spconv_wgrad_plan: bad arguments");
+    WgradPlan p = plan_wgrad(n_out, K, cin, cout);
+    hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const long long*>(counts),
+                       int(n_out), K, p.T, p.min_rows, items, items + size_t(p.T) * 4);
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}
+
+extern "C" int osn_spconv_wgrad(const float* in, const float* gout, const int32_t* nbr, const int64_t* counts,
+                                const int32_t* plan_items, float* gW, int64_t n_out, int K, int cin, int cout, void* ws,
+                                size_t ws_bytes, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_spconv_wgrad: n_out out of range");
     OSN_REQUIRE(K >= 1 && K <= 125 && cin >= 1 && cout >= 1 && gW, OSN_E_ARG, "osn_spconv_wgrad: bad arguments");
@@ -1343,11 +1385,12 @@ extern "C" int osn_spconv_wgrad(const float* in, const float* gout, const int32_
     WgradPlan p = plan_wgrad(n_out, K, cin, cout);
     OSN_REQUIRE(ws && ws_bytes >= p.items_bytes + p.partial_bytes, OSN_E_WS, "osn_spconv_wgrad: workspace %zu < %zu",
                 ws_bytes, p.items_bytes + p.partial_bytes);
-    int* items = static_cast<int*>(ws);
-    int* range = items + size_t(p.T) * 4;
+    const int* items = plan_items ? plan_items : static_cast<int*>(ws);
+    const int* range = items + size_t(p.T) * 4;
     float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + p.items_bytes);
-    hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const long long*>(counts),
-                       int(n_out), K, p.T, p.min_rows, items, range);
+    if (!plan_items)
+        hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const long long*>(counts),
+                           int(n_out), K, p.T, p.min_rows, static_cast<int*>(ws), static_cast<int*>(ws) + size_t(p.T) * 4);
     const dim3 grid(p.n_ci * p.n_co, p.T), block(256);
     const bool av = (cin & 3) == 0, gv = (cout & 3) == 0;
 #define OSN_WG(T_, A_, G_)                                                                                          \

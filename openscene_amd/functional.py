@@ -28,8 +28,13 @@ class SparseConvFunction(Function):
         K = 1 if kernel.dim() == 2 else kernel.shape[0]
         cin, cout = kernel.shape[-2], kernel.shape[-1]
         tbl, rows, gm = (tiles_fwd[1], tiles_fwd[0], tiles_fwd[2]) if tiles_fwd is not None else (nbr_fwd, None, None)
+        ctx.wp_dgrad = None
         if CONV_MODE == "bf16x6" and ops.x6_eligible(K, cin, cout, n_out):
-            return ops.spconv_fwd_x6(feats, ops.weight_prep_x6(kernel), tbl, n_out, out_rows=rows, gmask=gm)
+            if ctx.needs_input_grad[0] and ops.x6_eligible(K, cout, cin, ctx.n_in):
+                wp, ctx.wp_dgrad = ops.weight_prep_x6_pair(kernel, flip)     # both layouts, one launch
+            else:
+                wp = ops.weight_prep_x6(kernel)
+            return ops.spconv_fwd_x6(feats, wp, tbl, n_out, out_rows=rows, gmask=gm)
         return ops.spconv_fwd(feats, kernel, tbl, n_out, out_rows=rows, gmask=gm)
 
     @staticmethod
@@ -43,7 +48,8 @@ class SparseConvFunction(Function):
             cin, cout = kernel.shape[-2], kernel.shape[-1]
             tbl, rows, gm = (tiles_bwd[1], tiles_bwd[0], tiles_bwd[2]) if tiles_bwd is not None else (nbr_bwd, None, None)
             if CONV_MODE == "bf16x6" and ops.x6_eligible(K, cout, cin, ctx.n_in):
-                wp = ops.weight_prep_x6(kernel, flip=flip, for_dgrad=True)
+                wp = ctx.wp_dgrad if ctx.wp_dgrad is not None else ops.weight_prep_x6(kernel, flip=flip, for_dgrad=True)
+                ctx.wp_dgrad = None
                 gin = ops.spconv_fwd_x6(gout, wp, tbl, ctx.n_in, out_rows=rows, gmask=gm)
             else:
                 gin = ops.spconv_fwd(gout, ops.weight_transpose(kernel, flip), tbl, ctx.n_in, out_rows=rows, gmask=gm)

@@ -2,6 +2,8 @@
 pass raw device pointers and the current HIP stream.  No autograd here (see
 functional.py) and no CPU fallback."""
 import ctypes
+import os
+import weakref
 
 import torch
 
@@ -221,6 +223,20 @@ def weight_prep_x6(weight, flip=False, for_dgrad=False):
     return wp
 
 
+def weight_prep_x6_pair(weight, flip=False):
+    """(forward planes, input-gradient planes) of one weight from a single launch."""
+    dev = weight.device
+    lib = _prep(dev)
+    w = _f32c(_w3(weight), "weight")
+    K, cin, cout = w.shape
+    wf = torch.empty((3, K, cout, (cin + 31) // 32 * 32), dtype=torch.bfloat16, device=dev)
+    wb = torch.empty((3, K, cin, (cout + 31) // 32 * 32), dtype=torch.bfloat16, device=dev)
+    with _Dev(dev):
+        check(lib.osn_weight_prep_x6_pair(_p(w), K, cin, cout, int(bool(flip)), _p(wf), _p(wb), _stream(dev)),
+              "osn_weight_prep_x6_pair")
+    return wf, wb
+
+
 def spconv_fwd_x6(feats, wp, nbr, n_out, out_rows=None, gmask=None):
     """Split-bf16 convolution: out[o] = sum_k feats[nbr[k,o]] @ B[k], B given as weight_prep_x6 planes."""
     dev = feats.device
@@ -270,6 +286,29 @@ def weight_transpose(weight, flip):
     return wt
 
 
+_wgrad_items = {}      # id(counts tensor of a map) -> (weakref to it, {items_bytes: work-item table})
+
+
+def _wgrad_plan_items(lib, counts, n_out, K, cin, cout, dev):
+    """Work-item table of a map, built once per (map, table size) and shared by every conv on that map."""
+    nbytes = _cached("osn_spconv_wgrad_items_bytes", n_out, K, cin, cout)
+    key = id(counts)
+    hit = _wgrad_items.get(key)
+    if hit is None or hit[0]() is not counts:
+        # entry dies with the map's counts tensor (tensors compare elementwise, so no WeakKeyDictionary)
+        hit = _wgrad_items[key] = (weakref.ref(counts, lambda _r, k=key: _wgrad_items.pop(k, None)), {})
+    per_map = hit[1]
+    # a transposed conv shares its counts tensor with the strided conv it mirrors but has another n_out
+    sub = (int(n_out), int(K), nbytes)
+    items = per_map.get(sub)
+    if items is None:
+        items = per_map[sub] = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
+        with _Dev(dev):
+            check(lib.osn_spconv_wgrad_plan(_p(counts), n_out, K, cin, cout, _p(items), _stream(dev)),
+                  "osn_spconv_wgrad_plan")
+    return items
+
+
 def spconv_wgrad(feats, gout, nbr, K, counts=None):
     dev = feats.device
     lib = _prep(dev)
@@ -286,9 +325,10 @@ def spconv_wgrad(feats, gout, nbr, K, counts=None):
     ws = _ws(wsb, dev) if wsb else None
     tok = _profiler.start("spconv_wgrad", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
         if _profiler is not None else None
+    items = _wgrad_plan_items(lib, counts, n_out, K, cin, cout, dev) if (counts is not None and n_out > 0) else None
     with _Dev(dev):
-        check(lib.osn_spconv_wgrad(_p(feats), _p(gout), _p(nbr), _p(counts), _p(gw), n_out, K, cin, cout, _p(ws),
-                                   int(wsb), _stream(dev)), "osn_spconv_wgrad")
+        check(lib.osn_spconv_wgrad(_p(feats), _p(gout), _p(nbr), _p(counts), _p(items), _p(gw), n_out, K, cin, cout,
+                                   _p(ws), int(wsb), _stream(dev)), "osn_spconv_wgrad")
     if tok is not None:
         _profiler.stop(tok)
     return gw

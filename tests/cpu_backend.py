@@ -178,7 +178,11 @@ def fnv_hash(grid):
     return torch.from_numpy(ov.fnv_keys(_np(grid)).view(np.int64))
 
 
-_NAMES = ["HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
+def weight_prep_x6_pair(weight, flip=False):
+    return weight_prep_x6(weight), weight_prep_x6(weight, flip=flip, for_dgrad=True)
+
+
+_NAMES = ["HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
           "spconv_wgrad", "bn_stats", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
           "fnv_hash"]
 

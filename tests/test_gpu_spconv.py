@@ -140,6 +140,30 @@ def test_out_rows_indirection_and_determinism():
     assert (gc - ga).abs().max().item() <= 1e-5 * ga.abs().max().item()
 
 
+def test_cached_work_items_of_a_strided_conv_and_its_transpose():
+    """A transposed conv shares the pair counts of the strided conv it mirrors but has another row count:
+    the cached weight-gradient work items must not be shared between the two."""
+    from openscene_amd import ops
+    from openscene_amd.sparse import CoordinateManager
+    d = dev()
+    v = syn.shuffled(syn.grid_voxels(syn.room_points(0), 0.02), 0)          # S100k: both directions plan 512 items
+    cm = CoordinateManager(torch.from_numpy(syn.batch_coords([v])).to(d))
+    down = cm.kmap(1, 2, 2)[0]
+    up = cm.kmap(2, 1, 2)[0]
+    cnt_d, cnt_u = cm.kmap_counts(1, 2, 2), cm.kmap_counts(2, 1, 2)
+    assert cnt_d is cnt_u
+    g = torch.Generator().manual_seed(5)
+    fine = torch.randn(cm.size(1), 32, generator=g).to(d)
+    coarse = torch.randn(cm.size(2), 32, generator=g).to(d)
+    for _ in range(2):                                                      # second round hits the cache
+        a = ops.spconv_wgrad(fine, coarse, down, 8, cnt_d)
+        b = ops.spconv_wgrad(coarse, fine, up, 8, cnt_u)
+        assert (a - ops.spconv_wgrad(fine, coarse, down, 8)).abs().max().item() <= 1e-5 * a.abs().max().item()
+        assert (b - ops.spconv_wgrad(coarse, fine, up, 8)).abs().max().item() <= 1e-5 * b.abs().max().item()
+        # the two weight gradients are each other's transposes
+        assert (a - b.transpose(1, 2)).abs().max().item() <= 1e-5 * a.abs().max().item()
+
+
 def test_known_answer_cases():
     """The hand-derivable cases of tests/test_oracle_kat.py, through the HIP kernels."""
     from openscene_amd import ops
