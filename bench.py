@@ -30,6 +30,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3       # f32 MFMA / vector peak, same guide
+BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, same guide
+# bf16x6 kernels issue SIX bf16 MFMAs per fp32-equivalent product block, so their roof in the
+# fp32-equivalent FLOPs this file counts (2 * pairs * cin * cout) is the bf16 peak / 6
+X6_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 6.0
 
 
 class LaunchProfiler:
@@ -57,7 +61,9 @@ class LaunchProfiler:
                 n = ("spconv_fwd_pipe_kernel<%d,%d,%d>" % (wm, wn, tn) if pipe else
                      "spconv_fwd_kernel<%d,%d,%d,%d>" % (wm, wn, tn, bk)) + ("+reduce" if S > 1 else "")
             else:
-                n = "spconv_wgrad_kernel"
+                pad = lambda c: min((c + 31) // 32 * 32, 128)
+                tiles = (pad(m["cin"]) // 32) * (pad(m["cout"]) // 32)
+                n = "spconv_wgrad_kernel<%d>" % ((tiles + 3) // 4,)
             self._names[key] = n
         return n
 
@@ -340,10 +346,33 @@ def main():
     # ---- query timing (per-point feature x text, M2) : eval forward output of this scene
     qres = None
     vox_res = None
+    extra = None
     if rank == 0:
         model.eval()
         with torch.no_grad():
             pred = model(SparseTensor(feats, coords0))
+        # configs[1]: inference forward (eval-mode BN) incl. map construction, and the maps alone
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize(device)
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(device)
+            return (time.perf_counter() - t) * 1e3 / reps
+
+        def infer():
+            with torch.no_grad():
+                return model(SparseTensor(feats, coords0))
+
+        def maps_only():
+            SparseTensor(feats, coords0).coordinate_manager.prebuild()
+
+        fwd_ms = timed(infer, 10)
+        maps_ms = timed(maps_only, 10)
+        extra = {"inference_fwd": {"ms": fwd_ms, "voxels_per_s": n_vox / (fwd_ms * 1e-3),
+                                   "what": "configs[1]: maps + eval-mode forward, %d-d output" % out_dim},
+                 "maps_only": {"ms": maps_ms, "what": "coordinate pyramid + every kernel map + tile ordering of one scene"}}
         gq = torch.Generator().manual_seed(5)
         n_pts = 150000
         inds_reverse = torch.randint(0, n_vox, (n_pts,), generator=gq).to(device)
@@ -425,14 +454,27 @@ def main():
                 pmc = json.load(open(pmc_path)).get(name.split("+")[0])
             except Exception:
                 pmc = None
-        roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc,
-                    "avg_launch_us": 1e3 * gk["ms"] / gk["launches"], "launches_per_step": gk["launches"] / args.steps,
-                    "bytes_per_launch": gk["bytes"] / gk["launches"],
-                    "fp32_tflops": gk["flops"] / (gk["ms"] * 1e-3) / 1e12,
-                    "fp32_frac": gk["flops"] / (gk["ms"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                    "step_hbm_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "step_fp32_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
+        tflops = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
+        mfma_peak = X6_PEAK_TFLOPS if "x6" in name else FP32_PEAK_TFLOPS
+        # which roof binds this kernel: the one whose time-at-peak is larger (arithmetic intensity vs ridge)
+        t_hbm = gk["bytes"] / (HBM_PEAK_GBS * 1e9)
+        t_mfma = gk["flops"] / (mfma_peak * 1e12)
+        common = {"kernel": name, "traffic": pmc,
+                  "avg_launch_us": 1e3 * gk["ms"] / gk["launches"], "launches_per_step": gk["launches"] / args.steps,
+                  "bytes_per_launch": gk["bytes"] / gk["launches"], "flops_per_launch": gk["flops"] / gk["launches"],
+                  "flop_per_byte": gk["flops"] / gk["bytes"], "ridge_flop_per_byte": mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9),
+                  "hbm_GBps": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
+                  "mfma_TFLOPs": tflops, "mfma_peak_TFLOPs": mfma_peak, "mfma_frac": tflops / mfma_peak,
+                  "mfma_peak_note": ("dense bf16 peak / 6 (six bf16 MFMAs per fp32-equivalent product)" if "x6" in name
+                                     else "fp32 MFMA peak"),
+                  "step_hbm_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "step_fp32_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
+        if t_mfma >= t_hbm:
+            roofline = dict({"bound": "mfma", "achieved": tflops, "peak": mfma_peak, "unit": "TFLOP/s",
+                             "frac": tflops / mfma_peak}, **common)
+        else:
+            roofline = dict({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS}, **common)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         # separate process (own thread pool, no GPU context) with a hard time bound
@@ -459,7 +501,7 @@ def main():
                    "arch": args.arch, "feature_dim": out_dim, "voxels_rank0": n_vox,
                    "level_sizes": sizes, "parallelism": "dp%d" % world,
                    "step_algorithmic_GB": step_bytes / 1e9, "step_GFLOP": step_flops / 1e9},
-        "query": qres, "voxelizer": vox_res, "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "loss": float(loss.detach()),
+        "query": qres, "voxelizer": vox_res, "phases": extra, "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "loss": float(loss.detach()),
     }
     print(json.dumps(line))
     if world > 1:

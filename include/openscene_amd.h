@@ -84,9 +84,12 @@ int osn_kmap_transpose(const int32_t* nbr, int64_t n_out, int K, int64_t n_in, i
  * order[j] = output rows sorted (stably) by their offset-occupancy bit mask, and
  * nbr_sorted[k, j] = nbr[k, order[j]].  Feed both to osn_spconv_fwd (nbr_sorted as the
  * table, order as out_rows): rows of one tile then share their offsets and the per-tile
- * offset skip removes the empty work; results are unchanged.  K <= 32.               */
+ * offset skip removes the empty work; results are unchanged.  K <= 32.
+ * counts (nullable, int64 [K] = osn_kmap_count): orders the key bits by rarity (rarest offset = most
+ * significant bit) instead of offset index, so the tiles that pay for a rare offset are few.        */
 size_t osn_kmap_sort_ws_bytes(int64_t n_out);
-int osn_kmap_sort(const int32_t* nbr, int64_t n_out, int K, int32_t* order, int32_t* nbr_sorted,
+int osn_kmap_sort(const int32_t* nbr, int64_t n_out, int K, const int64_t* counts, int32_t* order,
+                  int32_t* nbr_sorted,
                   uint32_t* gmask /* nullable: uint32 [ceil(n_out/32)], OR of the occupancy masks of
                                      each 32-row group of the sorted table */,
                   void* ws, size_t ws_bytes, osn_stream_t stream);

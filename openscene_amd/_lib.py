@@ -24,7 +24,7 @@ PROTOTYPES = {
     "osn_kmap_build": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "osn_kmap_transpose": (_i32, [_vp, _i64, _i32, _i64, _vp, _vp]),
     "osn_kmap_sort_ws_bytes": (_sz, [_i64]),
-    "osn_kmap_sort": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "osn_kmap_sort": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "osn_kmap_count": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "osn_spconv_fwd_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "osn_spconv_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),

@@ -6,6 +6,9 @@
 //
 // On the canonical 2 cm scene (SURVEY.md 8(d), 5.3 of 27 offsets occupied per voxel) a random
 // row order leaves 27.0 active offsets per 128-row tile; mask order leaves 15.0 (11.7 per 32 rows).
+// The sort key puts the RAREST offset in the most significant bit (given the per-offset pair
+// counts): rows that use a rare offset end up together, so few tiles pay for it -- another
+// -10 % active (tile, offset) pairs on that scene (13.5 per tile) compared to offset-index bit order.
 #include "common.h"
 
 #include <string.h>
@@ -14,12 +17,30 @@
 
 namespace osn {
 
-__global__ void kmap_mask_kernel(const int32_t* __restrict__ nbr, int64_t n_out, int K, uint32_t* __restrict__ mask,
+// key bit of offset k: its rank by pair count, most frequent = bit 0 ... rarest = bit K-1 (ties: lower k
+// first); offset-index order when no counts are given.
+__global__ void kmap_mask_kernel(const int32_t* __restrict__ nbr, int64_t n_out, int K,
+                                 const long long* __restrict__ counts, uint32_t* __restrict__ mask,
                                  int32_t* __restrict__ iota) {
+    __shared__ int bitpos[32];
+    if (threadIdx.x < 32) {
+        const int k = threadIdx.x;
+        int pos = k;
+        if (counts && k < K) {
+            const long long c = counts[k];
+            pos = 0;
+            for (int j = 0; j < K; ++j) {
+                const long long cj = counts[j];
+                pos += (j != k && (cj > c || (cj == c && j < k))) ? 1 : 0;
+            }
+        }
+        bitpos[k] = pos;
+    }
+    __syncthreads();
     const int64_t o = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (o >= n_out) return;
     uint32_t m = 0;
-    for (int k = 0; k < K; ++k) m |= (nbr[int64_t(k) * n_out + o] >= 0 ? 1u : 0u) << k;
+    for (int k = 0; k < K; ++k) m |= (nbr[int64_t(k) * n_out + o] >= 0 ? 1u : 0u) << bitpos[k];
     mask[o] = m;
     iota[o] = int(o);
 }
@@ -32,11 +53,13 @@ __global__ void kmap_permute_kernel(const int32_t* __restrict__ nbr, const int32
     out[int64_t(k) * n_out + j] = nbr[int64_t(k) * n_out + order[j]];
 }
 
-// gmask[g] = OR of the occupancy masks of rows 32g .. 32g+31 (in the sorted order)
-__global__ void kmap_group_mask_kernel(const uint32_t* __restrict__ mask_sorted, int64_t n_out,
+// gmask[g] = OR of the occupancy masks (bit k = offset k) of rows 32g .. 32g+31 of the sorted table
+__global__ void kmap_group_mask_kernel(const int32_t* __restrict__ nbr_sorted, int64_t n_out, int K,
                                        uint32_t* __restrict__ gmask) {
     const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    uint32_t m = j < n_out ? mask_sorted[j] : 0u;
+    uint32_t m = 0u;
+    if (j < n_out)
+        for (int k = 0; k < K; ++k) m |= (nbr_sorted[int64_t(k) * n_out + j] >= 0 ? 1u : 0u) << k;
 #pragma unroll
     for (int d = 1; d < 32; d <<= 1) m |= __shfl_xor(m, d, 64);
     if ((threadIdx.x & 31) == 0 && j < n_out) gmask[j >> 5] = m;
@@ -82,8 +105,8 @@ extern "C" size_t osn_kmap_sort_ws_bytes(int64_t n_out) {
     return carve_sort(nullptr, n_out, tb).bytes;
 }
 
-extern "C" int osn_kmap_sort(const int32_t* nbr, int64_t n_out, int K, int32_t* order, int32_t* nbr_sorted,
-                             uint32_t* gmask, void* ws, size_t ws_bytes, osn_stream_t stream) {
+extern "C" int osn_kmap_sort(const int32_t* nbr, int64_t n_out, int K, const int64_t* counts, int32_t* order,
+                             int32_t* nbr_sorted, uint32_t* gmask, void* ws, size_t ws_bytes, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(K >= 1 && K <= 32, OSN_E_ARG, "osn_kmap_sort: K=%d (only K <= 32 offsets fit the 32-bit occupancy mask)", K);
     OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_kmap_sort: n_out out of range");
@@ -94,13 +117,14 @@ extern "C" int osn_kmap_sort(const int32_t* nbr, int64_t n_out, int K, int32_t* 
     SortWs w = carve_sort(ws, n_out, tb);
     OSN_REQUIRE(ws && ws_bytes >= w.bytes, OSN_E_WS, "osn_kmap_sort: workspace %zu < %zu", ws_bytes, w.bytes);
     const int T = 256;
-    hipLaunchKernelGGL(kmap_mask_kernel, dim3(cdiv(n_out, T)), dim3(T), 0, st, nbr, n_out, K, w.mask, w.iota);
+    hipLaunchKernelGGL(kmap_mask_kernel, dim3(cdiv(n_out, T)), dim3(T), 0, st, nbr, n_out, K,
+                       reinterpret_cast<const long long*>(counts), w.mask, w.iota);
     OSN_LAUNCH_CHECK();
     size_t t2 = w.tmp_bytes;
     OSN_HIP(rocprim::radix_sort_pairs(w.tmp, t2, w.mask, w.mask_sorted, w.iota, order, size_t(n_out), 0u, unsigned(K), st));
     hipLaunchKernelGGL(kmap_permute_kernel, dim3(cdiv(n_out, T), K), dim3(T), 0, st, nbr, order, n_out, nbr_sorted);
     if (gmask)
-        hipLaunchKernelGGL(kmap_group_mask_kernel, dim3(cdiv(n_out, T)), dim3(T), 0, st, w.mask_sorted, n_out, gmask);
+        hipLaunchKernelGGL(kmap_group_mask_kernel, dim3(cdiv(n_out, T)), dim3(T), 0, st, nbr_sorted, n_out, K, gmask);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
 }

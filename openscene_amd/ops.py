@@ -146,9 +146,10 @@ def kmap_transpose(nbr, n_in):
     return tbl
 
 
-def kmap_sort(nbr):
+def kmap_sort(nbr, counts=None):
     """-> (order int32 [n_out], nbr_sorted int32 [K, n_out], gmask int32 [ceil(n_out/32)]): rows ordered by
-    offset-occupancy mask; gmask = OR of the masks of each 32-row group of the sorted table."""
+    offset-occupancy mask (key bits ordered by rarity when the per-offset pair `counts` are given);
+    gmask = OR of the masks (bit k = offset k) of each 32-row group of the sorted table."""
     dev = nbr.device
     lib = _prep(dev)
     nbr = nbr.contiguous()
@@ -159,8 +160,8 @@ def kmap_sort(nbr):
     with _Dev(dev):
         wsb = _cached("osn_kmap_sort_ws_bytes", n_out)
         ws = _ws(wsb, dev)
-        check(lib.osn_kmap_sort(_p(nbr), n_out, K, _p(order), _p(out), _p(gmask), _p(ws), ws.numel(), _stream(dev)),
-              "osn_kmap_sort")
+        check(lib.osn_kmap_sort(_p(nbr), n_out, K, _p(counts), _p(order), _p(out), _p(gmask), _p(ws), ws.numel(),
+                                _stream(dev)), "osn_kmap_sort")
     return order, out, gmask
 
 

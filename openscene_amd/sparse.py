@@ -135,11 +135,12 @@ class CoordinateManager:
         if hit is not None:
             return hit
         fwd, bwd, flip = self.kmap(in_stride, out_stride, ksize, dilation)
+        counts = self.kmap_counts(in_stride, out_stride, ksize, dilation)     # same per offset for fwd and bwd tables
 
         def tiles(tbl):
             if tbl is None or tbl.shape[0] > 32 or tbl.shape[1] < self.SORT_MIN_ROWS:
                 return None
-            return ops.kmap_sort(tbl)
+            return ops.kmap_sort(tbl, counts)
 
         tf = tiles(fwd)
         tb = tf if (bwd is fwd) else tiles(bwd)

@@ -48,10 +48,18 @@ def kmap_transpose(nbr, n_in):
     return torch.from_numpy(oc.transpose_table(_np(nbr), int(n_in)))
 
 
-def kmap_sort(nbr):
+def kmap_sort(nbr, counts=None):
+    """Spec of osn_kmap_sort: stable argsort of the occupancy key; key bit of offset k = its rank by pair
+    count (most frequent = bit 0, rarest = bit K-1, ties: lower k first) or k itself without counts."""
     K = nbr.shape[0]
+    bitpos = torch.arange(K)
+    if counts is not None:
+        c = [int(v) for v in counts]
+        bitpos = torch.tensor([sum(1 for j in range(K) if j != k and (c[j] > c[k] or (c[j] == c[k] and j < k)))
+                               for k in range(K)])
+    key = ((nbr >= 0).long() << bitpos.reshape(K, 1)).sum(0)
+    order = torch.from_numpy(np.argsort(key.numpy(), kind="stable").astype(np.int32))
     mask = ((nbr >= 0).long() << torch.arange(K).reshape(K, 1)).sum(0)
-    order = torch.from_numpy(np.argsort(mask.numpy(), kind="stable").astype(np.int32))
     ms = mask[order.long()]
     pad = (-ms.shape[0]) % 32
     g = torch.cat([ms, ms.new_zeros(pad)]).reshape(-1, 32)

@@ -137,17 +137,20 @@ def test_kmap_sort_bit_exact_and_skip_efficiency():
     cm = CoordinateManager(torch.from_numpy(c).to(dev()))
     for (si, so_, k) in [(1, 1, 3), (2, 2, 3), (1, 2, 2), (2, 1, 2)]:
         nbr = cm.kmap(si, so_, k)[0]
-        order, tbl, gm = ops.kmap_sort(nbr)
-        want_order, want_tbl, want_gm = cpu_backend.kmap_sort(nbr.cpu())
-        assert torch.equal(order.cpu(), want_order) and torch.equal(tbl.cpu(), want_tbl) and torch.equal(gm.cpu(), want_gm)
+        for cnt in (None, cm.kmap_counts(si, so_, k)):
+            order, tbl, gm = ops.kmap_sort(nbr, cnt)
+            want_order, want_tbl, want_gm = cpu_backend.kmap_sort(nbr.cpu(), None if cnt is None else cnt.cpu())
+            assert torch.equal(order.cpu(), want_order) and torch.equal(tbl.cpu(), want_tbl) and torch.equal(gm.cpu(), want_gm)
     nbr = cm.kmap(1, 1, 3)[0]
     order, tbl, _ = ops.kmap_sort(nbr)
+    _, tbl_r, _ = ops.kmap_sort(nbr, cm.kmap_counts(1, 1, 3))
 
     def active(t):
         v = (t >= 0).cpu().numpy()
         n = v.shape[1] // 128 * 128
         return v[:, :n].reshape(27, -1, 128).any(2).sum(0).mean()
     assert active(nbr) > 26.5 and active(tbl) <= 16.0
+    assert active(tbl_r) <= 0.93 * active(tbl)            # rarity-ordered key bits: another -10 %
     up = cm.kmap(2, 1, 2)[0]                      # transposed k2s2 table: one offset per row -> one per tile
     _, tup, _ = ops.kmap_sort(up)
     v = (tup >= 0).cpu().numpy()
