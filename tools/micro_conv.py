@@ -37,13 +37,18 @@ def main():
     for stride, cin, cout in shapes:
         n = cm.size(stride)
         nbr = cm.kmap(stride, stride, 3)[0]
-        order, tbl, gm = ops.kmap_sort(nbr)
+        order, tbl, gm = ops.kmap_sort(nbr, cm.kmap_counts(stride, stride, 3))
         pairs = int(ops.kmap_count(nbr).sum())
         x = torch.randn(n, cin, device=dev)
         w = torch.randn(27, cin, cout, device=dev) * 0.05
         g = torch.randn(n, cout, device=dev)
         if only == "fwd":
             print("fwd(tile-ordered) %.1f us" % timed(lambda: ops.spconv_fwd(x, w, tbl, n, out_rows=order, gmask=gm), reps))
+            continue
+        if only == "fwd_x6":
+            wp = ops.weight_prep_x6(w)
+            print("fwd_x6(tile-ordered) %.1f us" % timed(
+                lambda: ops.spconv_fwd_x6(x, wp, tbl, n, out_rows=order, gmask=gm), reps))
             continue
         if only == "wgrad":
             cnt = ops.kmap_count(nbr)
