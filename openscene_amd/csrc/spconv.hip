@@ -528,9 +528,26 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_x6_kernel(const float* __re
     // All loads below are UNCONDITIONAL (invalid lanes read a clamped, valid address and the value
     // is zeroed when it is written to LDS): straight-line code, so the compiler keeps the loads in
     // flight across the MFMA block instead of draining them at a control-flow join.
-    unsigned pa_ok = 0, pb_ok = 0;
+    // Weight staging: everything that depends only on the thread (plane, column, 8-element piece) is
+    // computed once; per stage the source is base + one wave-uniform offset (k, chunk) -> one VALU add.
+    int b_off[NB];                               // element offsets into Wp
+    const int b_lds0 = (tid >> 2) * LDB + 8 * (tid & 3);      // piece f = tid + 256 h lands at b_lds0 + h * 64 * LDB
+    unsigned b_in = 0, b_okm = 0;                // piece exists in the tile / its column exists in the weight
+#pragma unroll
+    for (int h = 0; h < NB; ++h) {
+        const int f = tid + h * 256;
+        const int pl = f / (BN * 4), rem = f - pl * (BN * 4);
+        const int nn = rem >> 2, j = rem & 3;
+        const bool in_tile = f < NBV;
+        const bool ok = in_tile && n0 + nn < cout;
+        b_off[h] = ok ? ((pl * K) * cout + n0 + nn) * cinp + 8 * j : 0;
+        b_in |= (in_tile ? 1u : 0u) << h;
+        b_okm |= (ok ? 1u : 0u) << h;
+    }
+    const int w_k_stride = cout * cinp;
+    unsigned pa_ok = 0;
     auto fetch = [&](int slot, int c0, int par) {
-        const int kk = klist[slot], gm = kgm[slot];
+        const int kk = __builtin_amdgcn_readfirstlane(klist[slot]), gm = kgm[slot];
         const int c = c0 + a_sub * 4;
         pa_ok = 0;
 #pragma unroll
@@ -540,19 +557,13 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_x6_kernel(const float* __re
             pa[p] = *reinterpret_cast<const float4*>(in + (ok ? int64_t(i) * cin + c : 0));
             pa_ok |= (ok ? 1u : 0u) << p;
         }
-        // weights: pre-split bf16 planes, k-contiguous rows  Wp[plane][K][cout][cinp]
-        pb_ok = 0;
+        // weights: pre-split bf16 planes, k-contiguous rows  Wp[plane][K][cout][cinp]  (cinp % 32 == 0, so a
+        // 32-channel chunk never runs off a row; lanes without a piece read plane 0 / column 0: valid memory)
+        const unsigned s_off = unsigned((k_begin + kk) * w_k_stride + c0);
 #pragma unroll
-        for (int h = 0; h < NB; ++h) {
-            const int f = tid + h * 256;
-            const int pl = f / (BN * 4), rem = f - pl * (BN * 4);
-            const int nn = rem >> 2, j = rem & 3;
-            const int n = n0 + nn;
-            const bool ok = f < NBV && n < cout && c0 + 8 * j < cinp;
-            const __bf16* src = Wp + ((int64_t(pl) * K + (k_begin + kk)) * cout + n) * cinp + c0 + 8 * j;
-            pb[h] = *reinterpret_cast<const uint4*>(ok ? src : Wp);
-            pb_ok |= (ok ? 1u : 0u) << h;
-        }
+        for (int h = 0; h < NB; ++h)
+            pb[h] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Wp) +
+                                                    size_t(2u * (unsigned(b_off[h]) + s_off)));
     };
     auto stash = [&](int slot) {
         const int gm = kgm[slot];
@@ -567,13 +578,10 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_x6_kernel(const float* __re
         }
 #pragma unroll
         for (int h = 0; h < NB; ++h) {
-            const int f = tid + h * 256;
-            const int pl = f / (BN * 4), rem = f - pl * (BN * 4);
-            const int nn = rem >> 2, j = rem & 3;
-            if (f < NBV) {
+            if ((b_in >> h) & 1) {
                 uint4 v = pb[h];
-                if (!((pb_ok >> h) & 1)) v = make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4*>(&Bp[pl][nn][8 * j]) = v;
+                if (!((b_okm >> h) & 1)) v = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(&Bp[0][0][0] + b_lds0 + h * 64 * LDB) = v;
             }
         }
     };
@@ -1285,6 +1293,8 @@ extern "C" int osn_spconv_fwd_x6(const float* in, const void* Wp, const int32_t*
     OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_spconv_fwd_x6: n_out out of range");
     OSN_REQUIRE(K >= 1 && cin >= 4 && (cin & 3) == 0 && cout >= 1, OSN_E_ARG,
                 "osn_spconv_fwd_x6: needs cin %% 4 == 0 (K=%d cin=%d cout=%d)", K, cin, cout);
+    OSN_REQUIRE(int64_t(3) * K * cout * ((cin + 31) / 32 * 32) < (int64_t(1) << 30), OSN_E_ARG,
+                "osn_spconv_fwd_x6: prepared weight of %d x %d x %d exceeds the kernel's 32-bit offsets", K, cin, cout);
     if (n_out == 0) return OSN_OK;
     OSN_REQUIRE(in && Wp && out, OSN_E_ARG, "osn_spconv_fwd_x6: null pointer");
     OSN_REQUIRE(nbr || K == 1, OSN_E_ARG, "osn_spconv_fwd_x6: nbr may be null only for K == 1");

@@ -270,6 +270,8 @@ def x6_eligible(K, cin, cout, n_out):
     """The split-bf16 kernel handles every conv of the U-Net except the 3-channel stem."""
     if cin % 4 or cin < 8:
         return False
+    if 3 * K * cout * ((cin + 31) // 32 * 32) >= 1 << 30:        # the kernel indexes the prepared weight with 32 bits
+        return False
     plan = spconv_fwd_plan(n_out, K, cin, cout)
     S = plan[4]
     return -(-K // S) <= 32
