@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_pipe_kernel(const float* __
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int WM, int WN, int TN>
-__global__ __launch_bounds__(256, 2) void spconv_fwd_x6_kernel(const float* __restrict__ in, const __bf16* __restrict__ Wp,
+__global__ __launch_bounds__(256, 3) void spconv_fwd_x6_kernel(const float* __restrict__ in, const __bf16* __restrict__ Wp,
                                                               const int32_t* __restrict__ nbr,
                                                               const int32_t* __restrict__ out_rows,
                                                               const uint32_t* __restrict__ gmask,
@@ -550,11 +550,15 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_x6_kernel(const float* __re
         const int kk = __builtin_amdgcn_readfirstlane(klist[slot]), gm = kgm[slot];
         const int c = c0 + a_sub * 4;
         pa_ok = 0;
+        int ri[NA];
+#pragma unroll
+        for (int p = 0; p < NA; ++p) ri[p] = ridx[par][p * 32 + a_r];      // all LDS reads first: one wait
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
-            const int i = ridx[par][p * 32 + a_r];
-            const bool ok = ((gm >> p) & 1) && i >= 0 && c < cin;
-            pa[p] = *reinterpret_cast<const float4*>(in + (ok ? int64_t(i) * cin + c : 0));
+            const bool ok = ((gm >> p) & 1) && ri[p] >= 0 && c < cin;
+            // select the operands, not the address: one unsigned 32x32->64 multiply-add, no exec-masked branch
+            const unsigned iu = ok ? unsigned(ri[p]) : 0u, cu = ok ? unsigned(c) : 0u;
+            pa[p] = *reinterpret_cast<const float4*>(in + (uint64_t(iu) * unsigned(cin) + cu));
             pa_ok |= (ok ? 1u : 0u) << p;
         }
         // weights: pre-split bf16 planes, k-contiguous rows  Wp[plane][K][cout][cinp]  (cinp % 32 == 0, so a
