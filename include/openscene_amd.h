@@ -217,6 +217,25 @@ int osn_voxelize_fnv(const double* xyz, int64_t n, const double* T12_host,
 /* fnv_hash_vec alone (dataset/voxelization_utils.py:9-22): keys[i] of integral rows. */
 int osn_fnv_hash(const double* grid, int64_t n, int ncol, uint64_t* keys, osn_stream_t stream);
 
+/* ---- loader-side batch assembly --------------------- *
+ * Replaces the index1 / chunk_ind / cumsum chain of FusedFeatureLoader.__getitem__
+ * (dataset/feature_loader.py:124-143; val/test :107-113,:166-171): after the voxeliser kept one
+ * point per voxel (vox_ind = its `inds`), which voxels carry a fused 2-D feature and which row of
+ * the compact feature matrix (one row per True of mask_chunk, in point order) belongs to each:
+ *   mask_vox[v] = mask_chunk[vox_ind[v]]          uint8 [n_vox]
+ *   src_row[v]  = #True in mask_chunk[0 .. vox_ind[v])  if mask_vox[v] else -1     int64 [n_vox]
+ *   indices     = src_row[mask_vox] (voxel order kept; the reference's `indices`)  int64 [<= n_vox]
+ * *n_sel_host = number of selected voxels, on the HOST (one stream sync).           */
+size_t osn_feature_remap_ws_bytes(int64_t n_points, int64_t n_vox);
+int osn_feature_remap(const uint8_t* mask_chunk, const int64_t* vox_ind, int64_t n_points, int64_t n_vox,
+                      uint8_t* mask_vox, int64_t* src_row, int64_t* indices, int64_t* n_sel_host,
+                      void* ws, size_t ws_bytes, osn_stream_t stream);
+/* One scene's rows of the collated coordinate matrix (dataset/feature_loader.py:177-178,204-205):
+ * out_coords4[i] = (batch_index, xyz3[i,0], xyz3[i,1], xyz3[i,2]); the caller passes the row offset
+ * of the scene inside the batch tensor.                                             */
+int osn_batch_coords(const int32_t* xyz3, int64_t n, int batch_index, int32_t* out_coords4,
+                     osn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

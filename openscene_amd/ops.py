@@ -491,3 +491,43 @@ def fnv_hash(grid):
     with _Dev(dev):
         check(lib.osn_fnv_hash(_p(grid), n, ncol, _p(keys), _stream(dev)), "osn_fnv_hash")
     return keys
+
+
+# ------------------------------------------------------------------ loader
+def feature_remap(mask_chunk, vox_ind):
+    """mask_chunk bool/uint8 [N_pts], vox_ind int64 [N_vox] (device) ->
+    (mask_vox bool [N_vox], src_row int64 [N_vox] (-1 = no feature), indices int64 [n_sel])."""
+    dev = vox_ind.device
+    lib = _prep(dev)
+    if mask_chunk.device != dev:
+        raise ValueError("mask_chunk on %s but vox_ind on %s" % (mask_chunk.device, dev))
+    if vox_ind.dtype != torch.int64:
+        raise TypeError("vox_ind must be int64")
+    m8 = mask_chunk.contiguous().view(torch.uint8) if mask_chunk.dtype == torch.bool else mask_chunk.to(torch.uint8).contiguous()
+    vox_ind = vox_ind.contiguous()
+    n_pts, n_vox = m8.shape[0], vox_ind.shape[0]
+    mask_vox = torch.empty(max(n_vox, 1), dtype=torch.uint8, device=dev)
+    src_row = torch.empty(max(n_vox, 1), dtype=torch.int64, device=dev)
+    indices = torch.empty(max(n_vox, 1), dtype=torch.int64, device=dev)
+    with _Dev(dev):
+        wsb = lib.osn_feature_remap_ws_bytes(n_pts, n_vox)
+        ws = _ws(wsb, dev)
+        nsel = ctypes.c_int64(0)
+        check(lib.osn_feature_remap(_p(m8), _p(vox_ind), n_pts, n_vox, _p(mask_vox), _p(src_row), _p(indices),
+                                    ctypes.byref(nsel), _p(ws), ws.numel(), _stream(dev)), "osn_feature_remap")
+    return mask_vox[:n_vox].view(torch.bool), src_row[:n_vox], indices[:int(nsel.value)]
+
+
+def batch_coords(xyz3, batch_index, out):
+    """Write (batch_index, x, y, z) int32 rows of one scene into `out` (a [n, 4] row slice of the batch)."""
+    dev = xyz3.device
+    lib = _prep(dev)
+    if xyz3.dtype != torch.int32 or out.dtype != torch.int32 or not out.is_contiguous():
+        raise TypeError("xyz3 and out must be int32, out contiguous")
+    xyz3 = xyz3.contiguous()
+    n = xyz3.shape[0]
+    if out.shape != (n, 4):
+        raise ValueError("out must be [%d, 4], got %s" % (n, tuple(out.shape)))
+    with _Dev(dev):
+        check(lib.osn_batch_coords(_p(xyz3), n, int(batch_index), _p(out), _stream(dev)), "osn_batch_coords")
+    return out

@@ -186,13 +186,25 @@ def fnv_hash(grid):
     return torch.from_numpy(ov.fnv_keys(_np(grid)).view(np.int64))
 
 
+def feature_remap(mask_chunk, vox_ind):
+    from oracle import loader as ol
+    mv, src, ind = ol.remap(_np(mask_chunk).astype(bool), _np(vox_ind))
+    return torch.from_numpy(mv), torch.from_numpy(src), torch.from_numpy(ind)
+
+
+def batch_coords(xyz3, batch_index, out):
+    out[:, 0] = batch_index
+    out[:, 1:] = xyz3
+    return out
+
+
 def weight_prep_x6_pair(weight, flip=False):
     return weight_prep_x6(weight), weight_prep_x6(weight, flip=flip, for_dgrad=True)
 
 
 _NAMES = ["HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
           "spconv_wgrad", "bn_stats", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
-          "fnv_hash"]
+          "fnv_hash", "feature_remap", "batch_coords"]
 
 
 def install(monkeypatch):

@@ -59,6 +59,65 @@ def voxelize_case(name, seed, n, voxel_size, extent):
                         inverse=np.asarray(inv, np.int64).reshape(-1), feats_sel=f, labels_sel=l)
 
 
+def loader_cases():
+    """Drive the reference's REAL FusedFeatureLoader (dataset/feature_loader.py) on two synthetic scenes
+    written in its on-disk formats, train split and val split (eval_all), and store every input and
+    output.  SharedArray (shared-memory cache, unused with memcache_init=False) is stubbed."""
+    import shutil
+    import tempfile
+    import types
+    import torch
+    sys.modules.setdefault("SharedArray", types.ModuleType("SharedArray"))
+    from dataset import feature_loader as fl
+    # the reference targets torch 1.x, where torch.load unpickled numpy tuples by default
+    real_load = torch.load
+    torch.load = lambda *a, **k: real_load(*a, **dict(k, weights_only=False))
+
+    root = tempfile.mkdtemp(prefix="osn_golden_")
+    try:
+        data = os.path.join(root, "scannet_3d")
+        featdir = os.path.join(root, "feat")
+        rng = np.random.default_rng(21)
+        scenes = {}
+        for split in ("train", "val"):
+            os.makedirs(os.path.join(data, split))
+        os.makedirs(featdir)
+        D = 16
+        for si, n in enumerate((5000, 3500)):
+            xyz = rng.random((n, 3)) * np.asarray((2.0, 1.5, 0.8))
+            xyz[:, 2] = np.round(xyz[:, 2] * 3) / 3 + rng.normal(0, 0.004, n)
+            colors = rng.random((n, 3)).astype(np.float64) * 2 - 1          # [-1, 1] on disk
+            labels = rng.integers(0, 20, n).astype(np.float64)
+            labels[rng.random(n) < 0.05] = -100
+            mask_full = rng.random(n) < 0.6
+            feat = rng.standard_normal((int(mask_full.sum()), D)).astype(np.float16)
+            name = "scene%04d_00" % si
+            for split in ("train", "val"):
+                torch.save((xyz, colors, labels.copy()), os.path.join(data, split, name + "_vh_clean_2.pth"))
+            torch.save({"feat": torch.from_numpy(feat), "mask_full": torch.from_numpy(mask_full)},
+                       os.path.join(featdir, name + "_0.pt"))
+            scenes[name] = dict(xyz=xyz, colors=colors, labels=labels, mask_full=mask_full, feat=feat)
+        out = {}
+        for k, (name, sc) in enumerate(sorted(scenes.items())):
+            for key, v in sc.items():
+                out["s%d_%s" % (k, key)] = v
+        for split, eval_all, input_color, seed in (("train", False, False, 5), ("val", True, True, 6)):
+            ds = fl.FusedFeatureLoader(datapath_prefix=data, datapath_prefix_feat=featdir, voxel_size=0.05,
+                                       split=split, aug=False, memcache_init=False, eval_all=eval_all,
+                                       input_color=input_color)
+            np.random.seed(seed)
+            items = [ds[i] for i in range(len(ds))]
+            batch = (fl.collation_fn_eval_all if eval_all else fl.collation_fn)(items)
+            names = ("coords", "feats", "labels", "feat_3d", "mask", "inds_recons")
+            for nm, t in zip(names, batch):
+                out["%s_%s" % (split, nm)] = t.numpy()
+            out["%s_seed" % split] = seed
+        np.savez_compressed(os.path.join(HERE, "loader_fused.npz"), **out)
+    finally:
+        torch.load = real_load
+        shutil.rmtree(root, ignore_errors=True)
+
+
 if __name__ == "__main__":
     hash_kat()
     rng = np.random.default_rng(3)
@@ -66,4 +125,5 @@ if __name__ == "__main__":
     quantize_case("quantize_frac.npz", rng.random((3000, 3)) * 9.0)
     voxelize_case("voxelize_a.npz", 11, 6000, 0.02, (1.2, 0.9, 0.6))
     voxelize_case("voxelize_b.npz", 12, 20000, 0.05, (8.0, 6.0, 2.5))
+    loader_cases()
     print("golden vectors written to", HERE)

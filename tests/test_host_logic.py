@@ -218,3 +218,12 @@ def test_tile_ordered_maps_do_not_change_results(cpu_ops, monkeypatch):
     assert torch.allclose(res[0][0], res[1][0], atol=1e-12)
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.allclose(a, b, atol=1e-10 * (1 + a.abs().max().item()))
+
+
+@pytest.mark.parametrize("split,eval_all,input_color", [("train", False, False), ("val", True, True)])
+def test_gpu_resident_loader_matches_the_reference_loader(monkeypatch, golden_dir, split, eval_all, input_color):
+    """openscene_amd.loader (host logic, stand-in ops) == the reference's FusedFeatureLoader + collation."""
+    import loader_cases
+    cpu_backend.install(monkeypatch)
+    d = loader_cases.load(golden_dir)
+    loader_cases.check(d, loader_cases.run(d, torch.device("cpu"), split, eval_all, input_color), split, eval_all)
