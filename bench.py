@@ -426,6 +426,20 @@ def main():
         torch.cuda.synchronize(device)
         v_ms = (time.perf_counter() - tv) * 1e3 / 10
         vox_res = {"ms": v_ms, "n_points": 200000, "n_voxels": int(inds_v.shape[0]), "points_per_s": 200000 / (v_ms * 1e-3)}
+        # loader-side batch assembly: voxelise + fused-feature remap + row gathers of one
+        # 200 k-point training scene with 768-d fp16 fused features on 55 % of the points
+        from openscene_amd.loader import FusedScene, fused_feature_item
+        gl = torch.Generator().manual_seed(11)
+        m_full = (torch.rand(200000, generator=gl) < 0.55).to(device)
+        scene = FusedScene(pts, None, torch.zeros(200000, dtype=torch.uint8, device=device),
+                           torch.randn(int(m_full.sum()), out_dim, generator=gl).half().to(device), m_full)
+        np.random.seed(0)
+        item = fused_feature_item(vx, scene, split="train")
+        l_ms = timed(lambda: fused_feature_item(vx, scene, split="train"), 10)
+        extra["loader_item"] = {"ms": l_ms, "n_points": 200000, "n_voxels": int(item[0].shape[0]),
+                                "feature_rows": int(item[3].shape[0]),
+                                "what": "GPU-resident FusedFeatureLoader.__getitem__ (train): voxelise + remap + gathers, "
+                                        "two host syncs (voxel count, selected count)"}
         model.train()
 
     if rank != 0:

@@ -58,7 +58,10 @@ def fused_feature_item(voxelizer, scene, split="train", eval_all=False, input_co
     if input_color:
         if scene.colors is None:
             raise ValueError("input_color=True needs per-point colours")
-        feats = scene.colors[vox_ind].float() / 127.5 - 1.0      # fp32 arithmetic after the cast (:181)
+        # fp32 arithmetic after the cast (:181).  Division by a TENSOR: torch's GPU kernels turn division by a
+        # Python scalar into a multiplication by its reciprocal, which is not the reference's IEEE quotient.
+        div = torch.full((1, 1), 127.5, dtype=torch.float32, device=coords3.device)
+        feats = scene.colors[vox_ind].float() / div - 1.0
     else:
         feats = torch.ones(n_vox, 3, device=coords3.device)      # the reference's constant-one input (:183-184)
     labels = (scene.labels if eval_all else scene.labels[vox_ind]).long()
