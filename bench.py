@@ -235,6 +235,9 @@ def main():
     ap.add_argument("--feature", default="openseg", help="openseg (768-d) | lseg (512-d)")
     ap.add_argument("--scene-points", type=int, default=120000, help="surface samples of the synthetic scene "
                     "(120000 = S100k, the headline workload; smaller values are for overhead studies only)")
+    ap.add_argument("--prefetch-maps", action="store_true", help="build the maps of the NEXT batch on a side stream "
+                    "while a step runs (openscene_amd.sparse.MapPrefetcher) instead of inside the step as "
+                    "MinkowskiEngine does; measured 4 %% SLOWER on S100k (DESIGN.md section 4), off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -261,7 +264,7 @@ def main():
     from openscene_amd import ops
     from openscene_amd.disnet import DisNet
     from openscene_amd.query import query_distill
-    from openscene_amd.sparse import SparseTensor
+    from openscene_amd.sparse import MapPrefetcher, SparseTensor
 
     class Cfg:
         arch_3d = args.arch
@@ -290,16 +293,30 @@ def main():
     shift_rng = np.random.default_rng(rank)
     cos = torch.nn.CosineSimilarity()
 
-    def step():
+    def next_coords():
         coords = coords0.clone()
         shift = torch.from_numpy((shift_rng.random(3) * 100).astype(np.int32)).to(device)
         coords[:, 1:4] += shift                                    # run/distill.py:315
-        sinput = SparseTensor(feats, coords)                       # builds every map (ME does per forward)
+        return coords
+
+    prefetch = args.prefetch_maps
+    pf = MapPrefetcher(device) if prefetch else None
+    pending = [pf.submit(next_coords())] if prefetch else None
+
+    def step():
+        if prefetch:
+            # maps of this batch were built on the side stream while the previous step ran (every step still
+            # builds exactly one set of maps: the one for the batch after it)
+            sinput = SparseTensor(feats, coordinate_manager=pf.take(pending[0]))
+        else:
+            sinput = SparseTensor(feats, next_coords())            # builds every map (ME does per forward)
         out = net(sinput)
         loss = (1 - cos(out[mask], feat_3d)).mean()                # run/distill.py:322-326
         optim.zero_grad(set_to_none=True)
         loss.backward()
         optim.step()
+        if prefetch:
+            pending[0] = pf.submit(next_coords())
         return loss
 
     def sync():

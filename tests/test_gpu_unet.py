@@ -196,3 +196,34 @@ def test_tile_ordered_maps_same_result_and_deterministic():
     # gradients additionally see ReLU sign flips of pre-activations that sit within fp32 rounding of zero
     for a, b in zip(outs[0][1:], outs[1][1:]):
         assert ((a - b).norm() / a.norm()).item() <= 2e-3
+
+
+def test_prefetched_maps_give_the_same_step():
+    """MapPrefetcher (maps built on a side stream one batch ahead) changes nothing but the timing: same maps,
+    bitwise-identical forward output and gradients."""
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import CoordinateManager, MapPrefetcher, SparseTensor
+    d = torch.device("cuda", 0)
+    v = syn.shuffled(syn.grid_voxels(syn.room_points(2, n_pts=40000), 0.03), 2)
+    coords = torch.from_numpy(syn.batch_coords([v])).to(d)
+    feats = torch.rand(coords.shape[0], 3, device=d)
+    torch.manual_seed(0)
+    model = mink_unet(3, 16, 3, "MinkUNet14A").to(d).train()
+    pf = MapPrefetcher(d)
+    handles = [pf.submit(coords + s) for s in (0, 0)]             # two batches in flight on the side stream
+    cm = pf.take(handles[0])
+    ref = CoordinateManager(coords)
+    ref.prebuild()
+    for key in ((1, 1, 3), (1, 2, 2), (2, 1, 2), (4, 4, 3), (1, 1, 5)):
+        a, b = cm.kmap(*key), ref.kmap(*key)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+    outs = []
+    for x in (SparseTensor(feats, coordinate_manager=cm), SparseTensor(feats, coords),
+              SparseTensor(feats, coordinate_manager=pf.take(handles[1]))):
+        model.zero_grad(set_to_none=True)
+        out = model(x)
+        out.square().mean().backward()
+        outs.append((out.detach().clone(), model.conv0p1s1.kernel.grad.clone(), model.final.kernel.grad.clone()))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
