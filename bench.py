@@ -304,6 +304,11 @@ def main():
     pending = [pf.submit(next_coords())] if prefetch else None
 
     def step():
+        # `out[mask]` with a bool mask makes torch read the selected-row count back in the MIDDLE of the step
+        # (host stalls until the forward has drained, then refills an empty queue).  The row indices of the mask
+        # are batch data (openscene_amd.loader hands them out): resolve them here, next to the size read-backs
+        # of the coordinate pyramid, and the rest of the step runs without a host sync.
+        sel = mask.nonzero(as_tuple=False).squeeze(1)
         if prefetch:
             # maps of this batch were built on the side stream while the previous step ran (every step still
             # builds exactly one set of maps: the one for the batch after it)
@@ -311,7 +316,7 @@ def main():
         else:
             sinput = SparseTensor(feats, next_coords())            # builds every map (ME does per forward)
         out = net(sinput)
-        loss = (1 - cos(out[mask], feat_3d)).mean()                # run/distill.py:322-326
+        loss = (1 - cos(out.index_select(0, sel), feat_3d)).mean()  # = out[mask], run/distill.py:322-326
         optim.zero_grad(set_to_none=True)
         loss.backward()
         optim.step()
