@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_pipe_kernel(const float* __
         // around a loop-carried load destination (vmcnt is in-order), which serialises the prefetch.
         // The value is consumed in the same iteration, after an explicit vmcnt(0).
         auto advance = [&](int& sl, int& c) { if (++c == nchunk) { c = 0; ++sl; } };
-        int slot = 0, ch = 0;
+        int slot = 0;
         int slot1 = 0, ch1 = 0; advance(slot1, ch1);
         int slot2 = slot1, ch2 = ch1; advance(slot2, ch2);
         auto idx_ptr = [&](int sl) -> const int32_t* {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_pipe_kernel(const float* __
             if (more) stash(slot1);
             if (more2 && tid < BM) ridx[s & 1][tid] = row_ok ? i2 : -1;       // stage s+2 reuses stage s' slot
             __syncthreads();
-            slot = slot1; ch = ch1;
+            slot = slot1;
             slot1 = slot2; ch1 = ch2;
             advance(slot2, ch2);
         }
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256, 3) void spconv_fwd_x6_kernel(const float* __re
         // around a loop-carried load destination (vmcnt is in-order), which serialises the prefetch.
         // The value is consumed in the same iteration, after an explicit vmcnt(0).
         auto advance = [&](int& sl, int& c) { if (++c == nchunk) { c = 0; ++sl; } };
-        int slot = 0, ch = 0;
+        int slot = 0;
         int slot1 = 0, ch1 = 0; advance(slot1, ch1);
         int slot2 = slot1, ch2 = ch1; advance(slot2, ch2);
         auto idx_ptr = [&](int sl) -> const int32_t* {
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256, 3) void spconv_fwd_x6_kernel(const float* __re
             if (more) stash(slot1);
             if (more2 && tid < BM) ridx[s & 1][tid] = row_ok ? i2 : -1;       // stage s+2 reuses stage s' slot
             __syncthreads();
-            slot = slot1; ch = ch1;
+            slot = slot1;
             slot1 = slot2; ch1 = ch2;
             advance(slot2, ch2);
         }
