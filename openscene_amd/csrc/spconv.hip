@@ -933,16 +933,22 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_kernel(const float* __res
                 if (tile < ntiles) {
                     const int ti = tile / ntj, tj = tile - ti * ntj;
                     const int ca = ti * 32 + (lane & 31), cb = tj * 32 + (lane & 31);
-                    // rolling two-step operand window: LDS reads of step kk+1 overlap the MFMA of step kk
-                    float av[2], bv[2];
-                    av[0] = As[kh][ca];
-                    bv[0] = Gs[kh][cb];
+                    // rolling operand window, WG_LOOK steps deep: the LDS reads of step kk + WG_LOOK - 1 are issued
+                    // before the MFMA of step kk (one 32x32x2 MFMA = 64 cycles; a one-step lookahead left every MFMA
+                    // waiting on lgkmcnt for an LDS round trip of 100+ cycles under load)
+                    constexpr int WG_LOOK = 4;
+                    float av[WG_LOOK], bv[WG_LOOK];
+#pragma unroll
+                    for (int d = 0; d < WG_LOOK - 1; ++d) {
+                        av[d] = As[2 * d + kh][ca];
+                        bv[d] = Gs[2 * d + kh][cb];
+                    }
 #pragma unroll
                     for (int kk = 0; kk < WG_RB / 2; ++kk) {
-                        const int cur = kk & 1, nxt = cur ^ 1;
-                        if (kk + 1 < WG_RB / 2) {
-                            av[nxt] = As[2 * (kk + 1) + kh][ca];
-                            bv[nxt] = Gs[2 * (kk + 1) + kh][cb];
+                        const int cur = kk % WG_LOOK, nxt = (kk + WG_LOOK - 1) % WG_LOOK;
+                        if (kk + WG_LOOK - 1 < WG_RB / 2) {
+                            av[nxt] = As[2 * (kk + WG_LOOK - 1) + kh][ca];
+                            bv[nxt] = Gs[2 * (kk + WG_LOOK - 1) + kh][cb];
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur], acc[t], 0, 0, 0);
