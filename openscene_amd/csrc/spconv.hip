@@ -620,37 +620,83 @@ __global__ __launch_bounds__(256, 3) void spconv_fwd_x6_kernel(const float* __re
             }
             if ((kgm[slot] >> wm) & 1) {
                 // fp32-equivalent product from six bf16 MFMAs: x = x1 + x2 + x3 (8 mantissa bits each),
-                // a*b ~= a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1  (dropped terms <= 2^-24 relative)
+                // a*b ~= a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1  (dropped terms <= 2^-24 relative).
+                // The A rows of BOTH 16-deep k-steps are read up front (the two LDS round trips overlap) and the
+                // VALU split of step 1 is scheduled BETWEEN the MFMAs of step 0 (sched_group_barrier), so the
+                // matrix pipe is fed while the VALU converts instead of idling for ~40 VALU per k-step.
                 const int arow = wm * 32 + (lane & 31);
                 const int kq = 8 * (lane >> 5);
                 const int bcol = wn * TN * 32 + (lane & 31);
+                static_assert(BK == 32, "two k-steps per stage");
+                float fv[2][8];
 #pragma unroll
-                for (int ks = 0; ks < BK / 16; ++ks) {
+                for (int ks = 0; ks < 2; ++ks) {
                     const float4 f0 = *reinterpret_cast<const float4*>(&As[arow][ks * 16 + kq]);
                     const float4 f1 = *reinterpret_cast<const float4*>(&As[arow][ks * 16 + kq + 4]);
-                    const float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-                    bf16x8 a1, a2, a3;
+                    fv[ks][0] = f0.x; fv[ks][1] = f0.y; fv[ks][2] = f0.z; fv[ks][3] = f0.w;
+                    fv[ks][4] = f1.x; fv[ks][5] = f1.y; fv[ks][6] = f1.z; fv[ks][7] = f1.w;
+                }
+                bf16x8 a1[2], a2[2], a3[2];
+                auto split = [&](int ks) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const __bf16 h1 = (__bf16)fv[e];
-                        const float r1 = fv[e] - (float)h1;
+                        const __bf16 h1 = (__bf16)fv[ks][e];
+                        const float r1 = fv[ks][e] - (float)h1;
                         const __bf16 h2 = (__bf16)r1;
                         const float r2 = r1 - (float)h2;
-                        a1[e] = h1; a2[e] = h2; a3[e] = (__bf16)r2;
+                        a1[ks][e] = h1; a2[ks][e] = h2; a3[ks][e] = (__bf16)r2;
                     }
+                };
+                auto mfmas = [&](int ks) {
 #pragma unroll
                     for (int t = 0; t < TN; ++t) {
                         const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bp[0][bcol + t * 32][ks * 16 + kq]);
                         const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(&Bp[1][bcol + t * 32][ks * 16 + kq]);
                         const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(&Bp[2][bcol + t * 32][ks * 16 + kq]);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[ks], b1, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks], b2, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], b3, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks], b1, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], b2, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], b1, acc[t], 0, 0, 0);
                     }
+                };
+                split(0);
+                // k-step 0: after the 2nd MFMA of each column block (and once more) convert one PAIR of step-1
+                // elements; sched_barrier pins the order so the VALU issues in the shadow of the running MFMAs
+                auto split_pair = [&](int pr) {
+#pragma unroll
+                    for (int e = 2 * pr; e < 2 * pr + 2; ++e) {
+                        const __bf16 h1 = (__bf16)fv[1][e];
+                        const float r1 = fv[1][e] - (float)h1;
+                        const __bf16 h2 = (__bf16)r1;
+                        const float r2 = r1 - (float)h2;
+                        a1[1][e] = h1; a2[1][e] = h2; a3[1][e] = (__bf16)r2;
+                    }
+                };
+                int pr = 0;
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bp[0][bcol + t * 32][kq]);
+                    const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(&Bp[1][bcol + t * 32][kq]);
+                    const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(&Bp[2][bcol + t * 32][kq]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b1, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[0], b2, acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pr < 4) split_pair(pr++);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b3, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[0], b1, acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (TN < 4 && t < 4 - TN && pr < 4) split_pair(pr++);      // TN < 4: a second pair in the first blocks
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b2, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b1, acc[t], 0, 0, 0);
                 }
+#pragma unroll
+                for (; pr < 4; ++pr) split_pair(pr);                         // TN = 1 / 2: the rest, not hidden
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(1);
             }
             __syncthreads();                  // stage s consumed; ridx[s&1] is free (its fetch ran an iteration ago)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // covers the asm index load above
