@@ -22,12 +22,25 @@ def set_profiler(p):
     _profiler = p
 
 
+# Host-side cost matters: a training step is ~1200 launches and the deep U-Net levels run kernels of a few
+# microseconds, so every microsecond spent here is a microsecond the GPU may sit idle
+# (tools/host_profile.py measures this layer against a mock library).  Hence raw ints instead of
+# ctypes / torch.cuda.Stream objects and one raw-stream query per helper.
+_raw_stream_of = torch._C._cuda_getCurrentRawStream      # device index -> current hipStream_t as int
+_current_device = torch._C._cuda_getDevice
+
+
 def _p(t):
-    return _vp(t.data_ptr()) if t is not None else None
+    return t.data_ptr() if t is not None else None       # ctypes converts the int to void* (argtypes are set)
+
+
+def _idx(dev):
+    i = dev.index
+    return i if i is not None else _current_device()
 
 
 def _stream(dev):
-    return _vp(torch.cuda.current_stream(dev).cuda_stream)
+    return _raw_stream_of(_idx(dev))
 
 
 # Scratch for the C-ABI calls: ONE growing buffer per (device, stream).  Every call's scratch is only
@@ -38,7 +51,8 @@ _ws_pool = {}
 
 def _ws(nbytes, dev):
     nbytes = max(int(nbytes), 16)
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    i = _idx(dev)
+    key = (i, _raw_stream_of(i))
     buf = _ws_pool.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
@@ -59,17 +73,23 @@ def _cached(fn_name, *args):
     return v
 
 
+_dev_ok = {}
+
+
 def _prep(dev):
-    _lib.require_device(dev)
+    if dev not in _dev_ok:
+        _lib.require_device(dev)          # raises for CPU tensors / other architectures
+        _dev_ok[dev] = True
     return _lib.load()
 
 
 class _Dev:
     """Make `dev` the current HIP device for the duration of a call if it is not already."""
+    __slots__ = ("ctx",)
 
     def __init__(self, dev):
-        idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        self.ctx = None if idx == torch.cuda.current_device() else torch.cuda.device(idx)
+        idx = dev.index
+        self.ctx = None if (idx is None or idx == _current_device()) else torch.cuda.device(idx)
 
     def __enter__(self):
         if self.ctx is not None:
