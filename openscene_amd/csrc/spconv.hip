@@ -1133,8 +1133,9 @@ static FwdPlan plan_fwd(int64_t n_out, int K, int cin, int cout) {
     // units mode pays when the plain launch would not be split and every tile walks many offsets
     static const int tune_U = getenv("OSN_UNIT_K") ? atoi(getenv("OSN_UNIT_K")) : UNIT_K;    // experiment knob
     p.unit_k = tune_U;
-    p.unit_parts = (p.S == 1 && K > tune_U && K <= 32 && cin > 4 && (cin & 3) == 0 && (cout & 3) == 0)
-                       ? int(cdiv(K, tune_U)) : 0;
+    // ONE eligibility rule for both pipelined kernels and for osn_spconv_fwd_ws_bytes (the fp32 pipe kernel
+    // additionally needs cout % 4 == 0 to run at all; when it does not, the simple kernel ignores gmask)
+    p.unit_parts = (p.S == 1 && K > tune_U && K <= 32 && cin > 4 && (cin & 3) == 0) ? int(cdiv(K, tune_U)) : 0;
     return p;
 }
 
@@ -1243,7 +1244,8 @@ extern "C" int osn_spconv_fwd(const float* in, const float* W, const int32_t* nb
     FwdPlan p = plan_fwd(n_out, K, cin, cout);
     float* dst = out;
     UnitsArgs ua = {nullptr, nullptr, nullptr};
-    const bool use_units = gmask && nbr && p.unit_parts > 1;
+    const bool pipe_ok = cin > 4 && (cin & 3) == 0 && (cout & 3) == 0 && p.kps <= 32;
+    const bool use_units = gmask && nbr && p.unit_parts > 1 && pipe_ok;
     if (use_units) {
         const size_t need = units_ws_bytes(p, n_out, cout);
         OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_spconv_fwd: workspace %zu < %zu", ws_bytes, need);
@@ -1256,7 +1258,7 @@ extern "C" int osn_spconv_fwd(const float* in, const float* W, const int32_t* nb
         dst = static_cast<float*>(ws);
     }
     const int n = int(n_out);
-    const bool pipe = cin > 4 && (cin & 3) == 0 && (cout & 3) == 0 && p.kps <= 32;
+    const bool pipe = pipe_ok;
     if (pipe) {
         switch (p.cfg * 10 + p.tn) {
             case 1: launch_fwd_pipe<4, 1, 1>(p, st, in, W, nbr, out_rows, dst, n, K, cin, cout, ua); break;
@@ -1359,9 +1361,8 @@ extern "C" int osn_spconv_fwd_x6(const float* in, const void* Wp, const int32_t*
     OSN_REQUIRE(p.kps <= 32, OSN_E_ARG, "osn_spconv_fwd_x6: more than 32 offsets per block (K=%d)", K);
     float* dst = out;
     UnitsArgs ua = {nullptr, nullptr, nullptr};
-    const bool use_units = gmask && nbr && K > p.unit_k && K <= 32 && p.S == 1;
+    const bool use_units = gmask && nbr && p.unit_parts > 1;        // same rule osn_spconv_fwd_ws_bytes sizes for
     if (use_units) {
-        p.unit_parts = int(cdiv(K, p.unit_k));
         const size_t need = units_ws_bytes(p, n_out, cout);
         OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_spconv_fwd_x6: workspace %zu < %zu", ws_bytes, need);
         ua.gmask = gmask;

@@ -2,6 +2,7 @@
 the current HIP stream (backward runs on autograd's thread; the library is
 stateless so that is safe)."""
 import os
+import threading
 
 import torch
 from torch.autograd import Function
@@ -91,21 +92,38 @@ def sparse_conv(feats, kernel, maps, n_out, tiles=None, counts=None):
     return SparseConvFunction.apply(feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tf, tb, counts)
 
 
+_tls = threading.local()
+
+
 class deferred_bn_counters:
     """Context: collect the `num_batches_tracked += 1` of every BN in a forward pass and apply them as ONE
-    multi-tensor add at exit (48 one-element launches -> 1).  Same final buffer values as nn.BatchNorm1d."""
-    active = None
+    multi-tensor add at exit (48 one-element launches -> 1).  Same final buffer values as nn.BatchNorm1d.
+    The pending list is per thread (two forwards on two threads do not see each other's counters)."""
+
+    @staticmethod
+    def current():
+        return getattr(_tls, "pending", None)
 
     def __enter__(self):
-        self.prev = deferred_bn_counters.active
-        deferred_bn_counters.active = self.pending = []
+        self.prev = getattr(_tls, "pending", None)
+        _tls.pending = self.pending = []
         return self
 
     def __exit__(self, *exc):
-        deferred_bn_counters.active = self.prev
+        _tls.pending = self.prev
         if self.pending:
             torch._foreach_add_(self.pending, 1)
         return False
+
+
+_relu_observer = None
+
+
+def set_relu_observer(fn):
+    """Test hook: `fn(y)` is called with the output of every fused BN(+residual)+ReLU, in call order
+    (None switches it off).  Parity tests record the run's activation pattern through it."""
+    global _relu_observer
+    _relu_observer = fn
 
 
 def batch_norm_act(x, bn, residual=None, relu=False):
@@ -117,8 +135,8 @@ def batch_norm_act(x, bn, residual=None, relu=False):
         if bn.momentum is None:                       # cumulative average: needs the count now (host sync)
             bn.num_batches_tracked.add_(1)
             momentum = 1.0 / float(bn.num_batches_tracked)
-        elif deferred_bn_counters.active is not None:
-            deferred_bn_counters.active.append(bn.num_batches_tracked)
+        elif deferred_bn_counters.current() is not None:
+            deferred_bn_counters.current().append(bn.num_batches_tracked)
         else:
             bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if bn.track_running_stats else None
@@ -127,4 +145,7 @@ def batch_norm_act(x, bn, residual=None, relu=False):
         raise RuntimeError("eval-mode batch norm needs running statistics")
     gamma = bn.weight if bn.weight is not None else torch.ones(bn.num_features, device=x.device)
     beta = bn.bias if bn.bias is not None else torch.zeros(bn.num_features, device=x.device)
-    return BatchNormActFunction.apply(x, gamma, beta, rm, rv, residual, training, momentum, bn.eps, relu)
+    y = BatchNormActFunction.apply(x, gamma, beta, rm, rv, residual, training, momentum, bn.eps, relu)
+    if relu and _relu_observer is not None:
+        _relu_observer(y)
+    return y

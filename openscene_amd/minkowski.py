@@ -70,7 +70,10 @@ class MinkowskiConvolutionBase(nn.Module):
         cm, s_in = x.coordinate_manager, x.tensor_stride
         if self.TRANSPOSED:
             if self.stride == 1:
-                s_out = s_in
+                # ME swaps the in/out maps of EVERY transposed conv (odd kernels: mirrored offsets); the reference
+                # only builds stride-2 transposed convs (models/mink_unet.py:76-99), so refuse rather than return
+                # the un-mirrored convolution silently
+                raise NotImplementedError("MinkowskiConvolutionTranspose with stride 1 is outside the reference path")
             else:
                 if s_in % self.stride:
                     raise ValueError("cannot up-sample a tensor of stride %d by %d" % (s_in, self.stride))

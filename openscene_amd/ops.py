@@ -106,6 +106,15 @@ def _f32c(t, name):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _query_feats(t, name):
+    """Query features: float32 (network output) or float16 (fused 2-D features as the reference stores them,
+    scripts/feature_fusion/fusion_util.py:87).  The kernel reads fp32 rows; an fp16 matrix is widened once here
+    (half -> float -> half is the identity, so `feats.half() @ text` is unchanged; costs one pass over it)."""
+    if t.dtype == torch.float16:
+        t = t.float()
+    return _f32c(t, name)
+
+
 # ----------------------------------------------------------------- coordinates
 class HashTable:
     """Open-addressing table keys[cap] u64 / vals[cap] i32 living in HBM."""
@@ -322,7 +331,7 @@ def _wgrad_plan_items(lib, counts, n_out, K, cin, cout, dev):
         hit = _wgrad_items[key] = (weakref.ref(counts, lambda _r, k=key: _wgrad_items.pop(k, None)), {})
     per_map = hit[1]
     # a transposed conv shares its counts tensor with the strided conv it mirrors but has another n_out
-    sub = (int(n_out), int(K), nbytes)
+    sub = (int(n_out), int(K), int(cin), int(cout))         # the plan depends on the channel tiling, not only on its size
     items = per_map.get(sub)
     if items is None:
         items = per_map[sub] = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
@@ -426,7 +435,7 @@ def cosine_query(feats, text_half, gather=None, want_scores=True):
     """(scores fp16 [n, C] or None, argmax int64 [n]) of feats[gather].half() @ text.t()."""
     dev = feats.device
     lib = _prep(dev)
-    feats = _f32c(feats, "features")
+    feats = _query_feats(feats, "features")
     if text_half.dtype != torch.float16:
         raise TypeError("text features must be float16 (util/util.py:41-44 produces fp16)")
     text_half = text_half.contiguous()
@@ -451,8 +460,8 @@ def cosine_query(feats, text_half, gather=None, want_scores=True):
 def query_ensemble(feat_distill, feat_fusion, text_half, gather_distill=None, gather_fusion=None, want_scores=True):
     dev = feat_distill.device
     lib = _prep(dev)
-    fd = _f32c(feat_distill, "distill features")
-    ff = _f32c(feat_fusion, "fusion features")
+    fd = _query_feats(feat_distill, "distill features")
+    ff = _query_feats(feat_fusion, "fusion features")
     text_half = text_half.contiguous()
     c, d = text_half.shape
 

@@ -112,19 +112,25 @@ def init_params(arch="MinkUNet18A", in_channels=3, out_channels=20, seed=0, dtyp
     return p
 
 
-def unet_forward(p, feats, coords4, arch="MinkUNet18A", train=False, cm=None, relu_masks=None):
+def unet_forward(p, feats, coords4, arch="MinkUNet18A", train=False, cm=None, relu_masks=None, record_masks=None):
     """models/mink_unet.py:116-174 on (feats [N,Cin], coords4 int32 [N,4]) -> [N, out].
 
     relu_masks (optional): list of bool tensors, one per ReLU in call order.  When given, ReLU i
     is evaluated as ``y * relu_masks[i]`` -- i.e. with a PRESCRIBED activation pattern.  Tests use
     it to compare gradients of an fp32 run against this float64 oracle on the same pattern: a
     pre-activation within fp32 rounding of zero legitimately flips its ReLU between precisions,
-    and one flipped element already moves a gradient's relative L2 error by ~1/sqrt(#elements)."""
+    and one flipped element already moves a gradient's relative L2 error by ~1/sqrt(#elements).
+
+    record_masks (optional): a list that receives this evaluation's OWN activation pattern
+    (bool tensor ``y > 0`` per ReLU, call order) -- tests count how many elements of the fp32
+    run's pattern differ from the float64 one."""
     cm = cm or CoordinateManager(np.asarray(coords4))
     plan = layer_plan(arch)
     masks = list(relu_masks) if relu_masks is not None else None
 
     def act(y):
+        if record_masks is not None:
+            record_masks.append(y.detach() > 0)
         if masks is None:
             return F.relu(y)
         m = masks.pop(0)
