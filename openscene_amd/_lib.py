@@ -33,6 +33,12 @@ PROTOTYPES = {
     "osn_weight_prep_x6_pair": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "osn_spconv_fwd_x6": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "osn_spconv_fwd_plan": (_i32, [_i64, _i32, _i32, _i32, _c.POINTER(_i32)]),
+    "osn_tile_rows": (_i32, [_i64]),
+    "osn_tile_lists_bytes": (_sz, [_i64, _i32, _i32]),
+    "osn_tile_lists_build": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "osn_weight_prep_tl_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "osn_weight_prep_tl": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "osn_spconv_fwd_tl": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "osn_weight_transpose": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "osn_spconv_wgrad_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "osn_spconv_wgrad_items_bytes": (_sz, [_i64, _i32, _i32, _i32]),

@@ -9,12 +9,15 @@ from torch.autograd import Function
 
 from . import ops
 
-# Arithmetic of the forward / input-gradient convolutions:
-#   "bf16x6" (default) three-way bf16 split of both operands, six bf16 MFMAs per product block, fp32
-#            accumulate: fp32-level accuracy (same test tolerances as "fp32") at 2.7x the MFMA throughput
-#   "fp32"   v_mfma_f32_32x32x2_f32 (exact fp32 products, 157 TF peak)
-# The weight gradient always runs on the fp32 MFMA.
-CONV_MODE = os.environ.get("OSN_CONV_MODE", "bf16x6")
+# Kernels / arithmetic of the forward and input-gradient convolutions:
+#   "tl"     (default) second-generation kernel: per-tile compacted pair lists, weights in registers, output
+#            tile in LDS, split-bf16 arithmetic (spconv_tl.hip); maps too small for it (and the 3-channel
+#            stem) take the "bf16x6" path
+#   "bf16x6" output-stationary kernel over the dense neighbour table, three-way bf16 split of both operands,
+#            six bf16 MFMAs per product block, fp32 accumulate: fp32-level accuracy
+#   "fp32"   the same kernel on v_mfma_f32_32x32x2_f32 (exact fp32 products, 157 TF peak)
+# The weight gradient runs on the fp32 MFMA.
+CONV_MODE = os.environ.get("OSN_CONV_MODE", "tl")
 
 
 class SparseConvFunction(Function):
@@ -22,7 +25,8 @@ class SparseConvFunction(Function):
     MinkowskiConvolutionTransposeFunction).  kernel: [K, cin, cout], or [cin, cout] when K == 1."""
 
     @staticmethod
-    def forward(ctx, feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tiles_fwd=None, tiles_bwd=None, counts=None):
+    def forward(ctx, feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tiles_fwd=None, tiles_bwd=None, counts=None,
+                lists_fwd=None, lists_bwd=None):
         ctx.save_for_backward(feats, kernel)
         ctx.maps = (nbr_fwd, nbr_bwd, bool(flip), tiles_bwd, counts)
         ctx.n_in = feats.shape[0]
@@ -30,8 +34,20 @@ class SparseConvFunction(Function):
         cin, cout = kernel.shape[-2], kernel.shape[-1]
         tbl, rows, gm = (tiles_fwd[1], tiles_fwd[0], tiles_fwd[2]) if tiles_fwd is not None else (nbr_fwd, None, None)
         ctx.wp_dgrad = None
-        if CONV_MODE == "bf16x6" and ops.x6_eligible(K, cin, cout, n_out):
-            if ctx.needs_input_grad[0] and ops.x6_eligible(K, cout, cin, ctx.n_in):
+        ctx.tl_bwd = None
+        mode = "bf16x6" if CONV_MODE == "tl" else CONV_MODE
+        if CONV_MODE == "tl" and ops.tl_eligible(K, cin, cout):
+            # K == 1 needs no lists; otherwise the map must be large enough to have them
+            fwd_ok = K == 1 or lists_fwd is not None
+            bwd_ok = ctx.needs_input_grad[0] and ops.tl_eligible(K, cout, cin) and (K == 1 or lists_bwd is not None)
+            if fwd_ok or bwd_ok:
+                wf, wb = ops.weight_prep_tl(kernel, flip, want_fwd=fwd_ok, want_dgrad=bwd_ok)
+                if bwd_ok:
+                    ctx.wp_dgrad, ctx.tl_bwd = wb, (lists_bwd if K > 1 else "identity")
+                if fwd_ok:
+                    return ops.spconv_fwd_tl(feats, wf, lists_fwd if K > 1 else None, n_out, K, cout)
+        if mode == "bf16x6" and ops.x6_eligible(K, cin, cout, n_out):
+            if ctx.needs_input_grad[0] and ctx.tl_bwd is None and ops.x6_eligible(K, cout, cin, ctx.n_in):
                 wp, ctx.wp_dgrad = ops.weight_prep_x6_pair(kernel, flip)     # both layouts, one launch
             else:
                 wp = ops.weight_prep_x6(kernel)
@@ -48,7 +64,12 @@ class SparseConvFunction(Function):
         if ctx.needs_input_grad[0]:
             cin, cout = kernel.shape[-2], kernel.shape[-1]
             tbl, rows, gm = (tiles_bwd[1], tiles_bwd[0], tiles_bwd[2]) if tiles_bwd is not None else (nbr_bwd, None, None)
-            if CONV_MODE == "bf16x6" and ops.x6_eligible(K, cout, cin, ctx.n_in):
+            mode = "bf16x6" if CONV_MODE == "tl" else CONV_MODE
+            if ctx.tl_bwd is not None:
+                tl = None if isinstance(ctx.tl_bwd, str) else ctx.tl_bwd
+                gin = ops.spconv_fwd_tl(gout, ctx.wp_dgrad, tl, ctx.n_in, K, cin)
+                ctx.wp_dgrad = ctx.tl_bwd = None
+            elif mode == "bf16x6" and ops.x6_eligible(K, cout, cin, ctx.n_in):
                 wp = ctx.wp_dgrad if ctx.wp_dgrad is not None else ops.weight_prep_x6(kernel, flip=flip, for_dgrad=True)
                 ctx.wp_dgrad = None
                 gin = ops.spconv_fwd_x6(gout, wp, tbl, ctx.n_in, out_rows=rows, gmask=gm)
@@ -56,7 +77,7 @@ class SparseConvFunction(Function):
                 gin = ops.spconv_fwd(gout, ops.weight_transpose(kernel, flip), tbl, ctx.n_in, out_rows=rows, gmask=gm)
         if ctx.needs_input_grad[1]:
             gk = ops.spconv_wgrad(feats, gout, nbr_fwd, K, counts).reshape(kernel.shape)
-        return gin, gk, None, None, None, None, None, None, None
+        return gin, gk, None, None, None, None, None, None, None, None, None
 
 
 class BatchNormActFunction(Function):
@@ -85,11 +106,13 @@ class BatchNormActFunction(Function):
         return gx, ggamma, gbeta, None, None, gres, None, None, None, None
 
 
-def sparse_conv(feats, kernel, maps, n_out, tiles=None, counts=None):
-    """maps = CoordinateManager.kmap(...); tiles = .kmap_tiles(...) or None; counts = .kmap_counts(...) or None."""
+def sparse_conv(feats, kernel, maps, n_out, tiles=None, counts=None, lists=None):
+    """maps = CoordinateManager.kmap(...); tiles = .kmap_tiles(...) or None; counts = .kmap_counts(...) or None;
+    lists = .kmap_lists(...) or None."""
     nbr_fwd, nbr_bwd, flip = maps
     tf, tb = tiles if tiles is not None else (None, None)
-    return SparseConvFunction.apply(feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tf, tb, counts)
+    lf, lb = lists if lists is not None else (None, None)
+    return SparseConvFunction.apply(feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tf, tb, counts, lf, lb)
 
 
 _tls = threading.local()

@@ -85,7 +85,11 @@ class MinkowskiConvolutionBase(nn.Module):
         maps = cm.kmap(s_in, s_out, self.kernel_size, self.dilation)
         tiles = cm.kmap_tiles(s_in, s_out, self.kernel_size, self.dilation)
         counts = cm.kmap_counts(s_in, s_out, self.kernel_size, self.dilation) if self.kernel.requires_grad else None
-        out = F_.sparse_conv(x.F, self.kernel, maps, cm.size(s_out), tiles, counts)
+        lists = None
+        if F_.CONV_MODE == "tl" and self.kernel_volume > 1 and F_.ops.tl_eligible(self.kernel_volume, self.in_channels,
+                                                                                  self.out_channels):
+            lists = cm.kmap_lists(s_in, s_out, self.kernel_size, self.dilation)
+        out = F_.sparse_conv(x.F, self.kernel, maps, cm.size(s_out), tiles, counts, lists)
         if self.bias is not None:
             out = out + self.bias
         return SparseTensor(out, tensor_stride=s_out, coordinate_manager=cm)

@@ -295,6 +295,96 @@ def spconv_fwd_x6(feats, wp, nbr, n_out, out_rows=None, gmask=None):
     return out
 
 
+# ------------------------------------------------- second-generation convolution (tile lists)
+class TileLists:
+    """Per-tile compacted pair lists of one neighbour table (osn_tile_lists_build): `buf` holds
+    cnt int32 [n_tiles, K] and lst int2 [n_tiles, K, bm]; `out_rows` is the row permutation of a
+    tile-ordered table (None = table rows are tensor rows)."""
+    __slots__ = ("buf", "bm", "n_out", "K", "out_rows")
+
+    def __init__(self, buf, bm, n_out, K, out_rows):
+        self.buf, self.bm, self.n_out, self.K, self.out_rows = buf, bm, n_out, K, out_rows
+
+    @property
+    def n_tiles(self):
+        return -(-self.n_out // self.bm)
+
+    def counts(self):
+        """int32 [n_tiles, K] view of the pair counts."""
+        return self.buf[:self.n_tiles * self.K * 4].view(torch.int32).view(self.n_tiles, self.K)
+
+    def lists(self):
+        """int32 [n_tiles, K, bm, 2] view: (input row, local output row); only the first cnt entries are defined."""
+        off = (self.n_tiles * self.K * 4 + 255) // 256 * 256
+        return self.buf[off:off + self.n_tiles * self.K * self.bm * 8].view(torch.int32).view(self.n_tiles, self.K, self.bm, 2)
+
+
+def tile_rows(n_out):
+    return int(_cached("osn_tile_rows", int(n_out)))
+
+
+def tile_lists(nbr, out_rows=None, bm=None):
+    """TileLists of an int32 [K, n_out] table (rows possibly tile-ordered; then pass its `out_rows`)."""
+    dev = nbr.device
+    lib = _prep(dev)
+    nbr = nbr.contiguous()
+    K, n_out = nbr.shape
+    bm = tile_rows(n_out) if bm is None else int(bm)
+    nbytes = int(lib.osn_tile_lists_bytes(n_out, K, bm))
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with _Dev(dev):
+        check(lib.osn_tile_lists_build(_p(nbr), n_out, K, bm, _p(buf), _stream(dev)), "osn_tile_lists_build")
+    return TileLists(buf, bm, n_out, K, out_rows)
+
+
+def tl_eligible(K, cin, cout):
+    """Shapes the tile-list kernel takes (everything of the U-Net but the 3-channel stem)."""
+    return cin % 4 == 0 and cin >= 8 and cout % 4 == 0 and K <= 128
+
+
+def weight_prep_tl(weight, flip=False, want_fwd=True, want_dgrad=True):
+    """(forward image, input-gradient image) of one weight, MFMA-fragment layout, one launch."""
+    dev = weight.device
+    lib = _prep(dev)
+    w = _f32c(_w3(weight), "weight")
+    K, cin, cout = w.shape
+    wf = torch.empty(_cached("osn_weight_prep_tl_bytes", K, cin, cout, 0), dtype=torch.uint8, device=dev) if want_fwd else None
+    wb = torch.empty(_cached("osn_weight_prep_tl_bytes", K, cin, cout, 1), dtype=torch.uint8, device=dev) if want_dgrad else None
+    with _Dev(dev):
+        check(lib.osn_weight_prep_tl(_p(w), K, cin, cout, int(bool(flip)), _p(wf), _p(wb), _stream(dev)),
+              "osn_weight_prep_tl")
+    return wf, wb
+
+
+def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
+    """out[o] = sum_k feats[list rows] @ B[k] with B given as a weight_prep_tl image; tl None <=> K == 1 identity.
+    bn_partial: optional float64 [n_tiles, 2, cout] receiving per-tile column sums / sums of squares of out."""
+    dev = feats.device
+    lib = _prep(dev)
+    feats = _f32c(feats, "features")
+    cin = feats.shape[1]
+    if tl is not None:
+        if tl.n_out != n_out or tl.K != K:
+            raise ValueError("tile lists are for a [%d, %d] table, conv wants [%d, %d]" % (tl.K, tl.n_out, K, n_out))
+        bm, buf, rows = tl.bm, tl.buf, tl.out_rows
+    else:
+        if K != 1 or feats.shape[0] != n_out:
+            raise ValueError("tl=None is the identity map and needs K == 1 and n_in == n_out")
+        bm, buf, rows = tile_rows(n_out), None, None
+    need = _cached("osn_weight_prep_tl_bytes", K, cin, cout, 0)
+    if wp.numel() != need:
+        raise ValueError("prepared weight has %d bytes, a [%d, %d, %d] conv needs %d" % (wp.numel(), K, cin, cout, need))
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    tok = _profiler.start("spconv_fwd_tl", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
+        if _profiler is not None else None
+    with _Dev(dev):
+        check(lib.osn_spconv_fwd_tl(_p(feats), _p(wp), _p(buf), _p(rows), _p(out), _p(bn_partial), n_out, K, cin, cout,
+                                    bm, _stream(dev)), "osn_spconv_fwd_tl")
+    if tok is not None:
+        _profiler.stop(tok)
+    return out
+
+
 def x6_eligible(K, cin, cout, n_out):
     """The split-bf16 kernel handles every conv of the U-Net except the 3-channel stem."""
     if cin % 4 or cin < 8:

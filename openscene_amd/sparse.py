@@ -117,11 +117,14 @@ class CoordinateManager:
             for k in kernel_sizes:
                 self.kmap(s, s, k)
                 self.kmap_tiles(s, s, k)
+                self.kmap_lists(s, s, k)
         for s in levels[:-1]:
             self.kmap(s, 2 * s, 2)
             self.kmap_tiles(s, 2 * s, 2)
+            self.kmap_lists(s, 2 * s, 2)
             self.kmap(2 * s, s, 2)
             self.kmap_tiles(2 * s, s, 2)
+            self.kmap_lists(2 * s, s, 2)
 
     def tensors(self):
         """Every device tensor this manager owns (coordinates, hash tables, parent maps, kernel maps, tile
@@ -136,6 +139,8 @@ class CoordinateManager:
                     walk(u)
             elif isinstance(v, ops.HashTable):
                 walk((v.keys, v.vals))
+            elif isinstance(v, ops.TileLists):
+                walk((v.buf, v.out_rows))
         for d in (self._coords, self._tables, self._parent, self._kmaps):
             for v in d.values():
                 walk(v)
@@ -168,6 +173,37 @@ class CoordinateManager:
         tf = tiles(fwd)
         tb = tf if (bwd is fwd) else tiles(bwd)
         res = (tf, tb)
+        self._kmaps[key] = res
+        return res
+
+
+    TL_MIN_ROWS = 4096        # below this the tile-list kernel's serial (offset, chunk) chain loses to the split launch
+
+    def kmap_lists(self, in_stride, out_stride, ksize, dilation=1):
+        """Per-tile compacted pair lists (ops.TileLists) of the forward table and of the input-gradient
+        table of a map: (tl_fwd or None, tl_bwd or None).  Built from the tile-ordered tables where those
+        exist, so a tile's rows share their offsets; None for K == 1 and for maps below TL_MIN_ROWS rows."""
+        key = ("lists", in_stride, out_stride, ksize, dilation)
+        hit = self._kmaps.get(key)
+        if hit is not None:
+            return hit
+        if out_stride < in_stride:                # transposed conv: the strided conv's lists, roles swapped
+            lf, lb = self.kmap_lists(out_stride, in_stride, ksize, dilation)
+            res = self._kmaps[key] = (lb, lf)
+            return res
+        fwd, bwd, flip = self.kmap(in_stride, out_stride, ksize, dilation)
+        tf, tb = self.kmap_tiles(in_stride, out_stride, ksize, dilation)
+
+        def lists(tbl, tiles):
+            if tbl is None or tbl.shape[0] > 128 or tbl.shape[1] < self.TL_MIN_ROWS:
+                return None
+            if tiles is not None:
+                return ops.tile_lists(tiles[1], out_rows=tiles[0])
+            return ops.tile_lists(tbl)
+
+        lf = lists(fwd, tf)
+        lb = lf if (bwd is fwd) else lists(bwd, tb)
+        res = (lf, lb)
         self._kmaps[key] = res
         return res
 

@@ -100,6 +100,93 @@ def spconv_fwd_x6(feats, wp, nbr, n_out, out_rows=None, gmask=None):
     return spconv_fwd(feats, wp[1], nbr, n_out, out_rows=out_rows)
 
 
+class TileLists:
+    """Spec of osn_tile_lists_build: per tile of `bm` consecutive table rows and per offset, the valid
+    (input row, local output row) pairs in ascending local row."""
+
+    def __init__(self, cnt, lst, bm, n_out, K, out_rows):
+        self.cnt, self.lst, self.bm, self.n_out, self.K, self.out_rows = cnt, lst, bm, n_out, K, out_rows
+
+    @property
+    def n_tiles(self):
+        return -(-self.n_out // self.bm)
+
+    def counts(self):
+        return self.cnt
+
+    def lists(self):
+        return self.lst
+
+
+def tile_rows(n_out):
+    """Spec of osn_tile_rows: whole rounds of 512 workgroups, at most 112 rows, at least 32, multiple of 4."""
+    if n_out <= 0:
+        return 32
+    rounds = -(-n_out // (512 * 112))
+    bm = -(-n_out // (512 * rounds))
+    bm = (bm + 3) // 4 * 4
+    return max(32, min(112, bm))
+
+
+def tile_lists(nbr, out_rows=None, bm=None):
+    t = _np(nbr)
+    K, n_out = t.shape
+    bm = tile_rows(n_out) if bm is None else int(bm)
+    nt = -(-n_out // bm)
+    cnt = np.zeros((nt, K), np.int32)
+    lst = np.full((nt, K, bm, 2), -7, np.int32)            # entries past cnt are undefined in the product
+    for ti in range(nt):
+        blk = t[:, ti * bm:(ti + 1) * bm]
+        for k in range(K):
+            j = np.nonzero(blk[k] >= 0)[0]
+            cnt[ti, k] = j.size
+            lst[ti, k, :j.size, 0] = blk[k, j]
+            lst[ti, k, :j.size, 1] = j
+    return TileLists(torch.from_numpy(cnt), torch.from_numpy(lst), bm, n_out, K, out_rows)
+
+
+def tl_eligible(K, cin, cout):
+    return cin % 4 == 0 and cin >= 8 and cout % 4 == 0 and K <= 128
+
+
+def weight_prep_tl(weight, flip=False, want_fwd=True, want_dgrad=True):
+    w = _w3(weight)
+    wb = torch.flip(w, dims=[0]) if flip else w
+    return (("tl", w) if want_fwd else None), (("tl", wb.transpose(1, 2).contiguous()) if want_dgrad else None)
+
+
+def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
+    """Evaluated FROM THE LISTS (not from the table), so host-logic tests exercise the list semantics."""
+    w = wp[1]
+    out = feats.new_zeros((n_out, cout))
+    if tl is None:
+        res = feats @ w[0]
+    else:
+        cnt, lst = tl.counts().numpy(), tl.lists().numpy()
+        tab = feats.new_zeros((n_out, cout))
+        for ti in range(tl.n_tiles):
+            for k in range(K):
+                c = int(cnt[ti, k])
+                if c:
+                    rows_in = torch.from_numpy(lst[ti, k, :c, 0].astype(np.int64))
+                    rows_out = torch.from_numpy(lst[ti, k, :c, 1].astype(np.int64)) + ti * tl.bm
+                    tab[rows_out] += feats[rows_in] @ w[k]
+        if tl.out_rows is not None:
+            res = torch.zeros_like(tab)
+            res[tl.out_rows.long()] = tab
+        else:
+            res = tab
+    out = res
+    if bn_partial is not None:
+        bm = tl.bm if tl is not None else tile_rows(n_out)
+        table_rows = out if (tl is None or tl.out_rows is None) else out[tl.out_rows.long()]
+        for ti in range(-(-n_out // bm)):
+            blk = table_rows[ti * bm:(ti + 1) * bm].double()
+            bn_partial[ti, 0] = blk.sum(0)
+            bn_partial[ti, 1] = (blk * blk).sum(0)
+    return out
+
+
 def x6_eligible(K, cin, cout, n_out):
     return cin % 4 == 0 and cin >= 8
 
@@ -202,7 +289,7 @@ def weight_prep_x6_pair(weight, flip=False):
     return weight_prep_x6(weight), weight_prep_x6(weight, flip=flip, for_dgrad=True)
 
 
-_NAMES = ["HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
+_NAMES = ["TileLists", "tile_rows", "tile_lists", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
           "spconv_wgrad", "bn_stats", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
           "fnv_hash", "feature_remap", "batch_coords"]
 

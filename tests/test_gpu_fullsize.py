@@ -75,8 +75,8 @@ def test_s100k_minkunet18a_768_training_step_vs_oracle():
     cm = oc.CoordinateManager(coords)
     own = []
     with torch.no_grad():
-        free = so.unet_forward({k: v.detach() for k, v in p.items()}, feats.double(), coords, "MinkUNet18A",
-                               train=True, cm=cm, record_masks=own)
+        free = so.unet_forward({k: v.detach().clone() for k, v in p.items()}, feats.double(), coords, "MinkUNet18A",
+                               train=True, cm=cm, record_masks=own)     # clones: BN updates running stats in place
 
     model = model.to(dev())
     masks = _observe_relu()

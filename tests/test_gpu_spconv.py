@@ -72,13 +72,17 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "tl"])
 @pytest.mark.parametrize("kind,key,cin,cout", CASES)
 def test_forward_and_gradients(kind, key, cin, cout, mode, monkeypatch):
-    """Both arithmetic modes of the forward / input-gradient kernels meet the SAME tolerance: the
-    split-bf16 mode (three bf16 pieces per operand, six MFMAs per product block) is fp32-accurate."""
+    """All kernel generations / arithmetic modes of the forward / input-gradient convolution meet the SAME
+    tolerance: the split-bf16 arithmetic (three bf16 pieces per operand, six MFMAs per product block) is
+    fp32-accurate.  "tl" = the tile-list kernel (spconv_tl.hip), fed with lists built from the oracle's table."""
     from openscene_amd import functional as F_
+    from openscene_amd import ops
     monkeypatch.setattr(F_, "CONV_MODE", mode)
+    if mode == "tl" and not ops.tl_eligible(key[2] ** 3, cin, cout):
+        pytest.skip("shape outside the tile-list kernel (takes the bf16x6 path, tested above)")
     cm = cloud(kind)
     si, so_, k = key
     K = k ** 3
@@ -106,7 +110,12 @@ def test_forward_and_gradients(kind, key, cin, cout, mode, monkeypatch):
             maps = (nbr, torch.from_numpy(oc.transpose_table(nbr_np, n_in)).to(d), False)
     fg = feats.to(d).requires_grad_(True)
     wg = w.to(d).requires_grad_(True)
-    out = F_.sparse_conv(fg, wg, maps, n_out)
+    lists = None
+    if mode == "tl" and K > 1:
+        lists = (ops.tile_lists(maps[0]), ops.tile_lists(maps[1]) if maps[1] is not maps[0] else None)
+        if lists[1] is None:
+            lists = (lists[0], lists[0])
+    out = F_.sparse_conv(fg, wg, maps, n_out, lists=lists)
     close(out, ref, "forward")
     out.backward(gout.to(d))
     close(fg.grad, f64.grad, "input gradient")
@@ -138,6 +147,63 @@ def test_out_rows_indirection_and_determinism():
     gd = ops.spconv_wgrad(feats, a, nbr, 27, cnt)
     assert torch.equal(gc, gd), "balanced weight gradient is not bitwise reproducible"
     assert (gc - ga).abs().max().item() <= 1e-5 * ga.abs().max().item()
+
+
+@pytest.mark.parametrize("kind,key,bm", [("big", (1, 1, 3), None), ("big", (1, 2, 2), 112), ("mid", (1, 1, 3), 36),
+                                         ("small", (2, 1, 2), 32), ("mid", (1, 1, 5), 100)])
+def test_tile_lists_match_the_spec(kind, key, bm):
+    """osn_tile_lists_build is bit-exact against its numpy specification (tests/cpu_backend.tile_lists),
+    also on a tile-ordered table."""
+    from openscene_amd import ops
+    cm = cloud(kind)
+    nbr_np = cm.kmap(*key)
+    d = dev()
+    nbr = torch.from_numpy(nbr_np).to(d)
+    for table in (nbr, ops.kmap_sort(nbr, ops.kmap_count(nbr))[1] if nbr.shape[0] <= 32 else None):
+        if table is None:
+            continue
+        got = ops.tile_lists(table, bm=bm)
+        ref = cpu_backend.tile_lists(table.cpu(), bm=bm)
+        assert got.bm == ref.bm and got.n_tiles == ref.n_tiles
+        cnt, lst = got.counts().cpu(), got.lists().cpu()
+        assert torch.equal(cnt, ref.counts())
+        valid = torch.arange(got.bm).reshape(1, 1, -1) < cnt.unsqueeze(-1)
+        assert torch.equal(lst[valid], ref.lists()[valid])
+        assert int(cnt.sum()) == int((table >= 0).sum())
+
+
+def test_tile_list_kernel_rows_partials_and_determinism():
+    """The tile-list kernel on a tile-ordered S100k-class map: features come back in tensor row order through
+    `out_rows`, the per-tile batch-norm partial sums add up to the column sums of the output, the result is
+    bitwise reproducible, and it agrees with the first-generation kernel to fp32 round-off."""
+    from openscene_amd import ops
+    cm = cloud("big")
+    nbr_np = cm.kmap(1, 1, 3)
+    n = nbr_np.shape[1]
+    d = dev()
+    g = torch.Generator().manual_seed(0)
+    feats = torch.randn(n, 128, generator=g).to(d)
+    w = (torch.randn(27, 128, 96, generator=g) * 0.05).to(d)
+    nbr = torch.from_numpy(nbr_np).to(d)
+    order, tbl, gm = ops.kmap_sort(nbr, ops.kmap_count(nbr))
+    tl = ops.tile_lists(tbl, out_rows=order)
+    wf, wb = ops.weight_prep_tl(w, flip=True)
+    part = torch.zeros(tl.n_tiles, 2, 96, dtype=torch.float64, device=d)
+    a = ops.spconv_fwd_tl(feats, wf, tl, n, 27, 96, bn_partial=part)
+    b = ops.spconv_fwd_tl(feats, wf, tl, n, 27, 96)
+    assert torch.equal(a, b), "tile-list forward is not bitwise reproducible"
+    ref = ops.spconv_fwd_x6(feats, ops.weight_prep_x6(w), tbl, n, out_rows=order, gmask=gm)
+    assert (a - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    plain = ops.spconv_fwd_tl(feats, wf, ops.tile_lists(nbr), n, 27, 96)           # unordered table: other tiles, same sums
+    assert (a - plain).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    s1, s2 = part[:, 0].sum(0), part[:, 1].sum(0)
+    assert (s1 - a.double().sum(0)).abs().max().item() <= 1e-9 * a.double().abs().sum(0).max().item()
+    assert (s2 - (a.double() ** 2).sum(0)).abs().max().item() <= 1e-9 * (a.double() ** 2).sum(0).max().item()
+    # input gradient through the same lists (odd stride-1 kernel: the map is its own mirror, weights flipped)
+    gout = torch.randn(n, 96, generator=g).to(d)
+    gi = ops.spconv_fwd_tl(gout, wb, tl, n, 27, 128)
+    gi_ref = ops.spconv_fwd_x6(gout, ops.weight_prep_x6(w, flip=True, for_dgrad=True), tbl, n, out_rows=order, gmask=gm)
+    assert (gi - gi_ref).abs().max().item() <= 2e-6 * gi_ref.abs().max().item()
 
 
 def test_cached_work_items_of_a_strided_conv_and_its_transpose():

@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Micro-benchmark: first-generation split-bf16 kernel vs the tile-list kernel on the S100k scene's dominant
+convolutions (HIP-event times, back-to-back launches), plus the list-build cost.  REPS=n, SHAPES=all|hot."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from openscene_amd import ops, synthetic as syn  # noqa: E402
+from openscene_amd.sparse import CoordinateManager  # noqa: E402
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def main():
+    reps = int(os.environ.get("REPS", "5"))
+    dev = torch.device("cuda", 0)
+    vox = syn.shuffled(syn.grid_voxels(syn.room_points(0), 0.02), 0)
+    cm = CoordinateManager(torch.from_numpy(syn.batch_coords([vox])).to(dev))
+    res = []
+    # (in stride, out stride, ksize, cin, cout)
+    shapes = [(1, 1, 3, 96, 96), (1, 1, 3, 128, 96), (1, 1, 3, 96, 128), (2, 2, 3, 96, 96), (2, 2, 3, 128, 96),
+              (2, 2, 3, 32, 32), (4, 4, 3, 64, 64), (4, 4, 3, 128, 128), (4, 4, 3, 192, 128),
+              (1, 1, 1, 96, 768), (1, 1, 1, 128, 96), (2, 1, 2, 96, 96), (1, 2, 2, 32, 32), (1, 2, 2, 96, 96)]
+    if os.environ.get("SHAPES", "all") == "hot":
+        shapes = shapes[:2]
+    for si, so, ks, cin, cout in shapes:
+        K = ks ** 3
+        n_in, n_out = cm.size(si), cm.size(so)
+        x = torch.randn(n_in, cin, device=dev)
+        w = torch.randn(K, cin, cout, device=dev) * 0.05
+        row = {"shape": "s%d->s%d k%d %d->%d" % (si, so, ks, cin, cout), "n_out": n_out}
+        if K > 1:
+            nbr = cm.kmap(si, so, ks)[0]
+            pairs = int(ops.kmap_count(nbr).sum())
+            tiles = cm.kmap_tiles(si, so, ks)[0]
+            tbl, rows, gm = (tiles[1], tiles[0], tiles[2]) if tiles is not None else (nbr, None, None)
+            t_list = timed(lambda: ops.tile_lists(tbl, out_rows=rows), reps)
+            tl = ops.tile_lists(tbl, out_rows=rows)
+            row["bm"] = tl.bm
+        else:
+            nbr = tbl = rows = gm = tl = None
+            pairs = n_out
+            t_list = 0.0
+        wp6 = ops.weight_prep_x6(w)
+        wf, _ = ops.weight_prep_tl(w, want_dgrad=False)
+        t_old = timed(lambda: ops.spconv_fwd_x6(x, wp6, tbl, n_out, out_rows=rows, gmask=gm), reps)
+        t_new = timed(lambda: ops.spconv_fwd_tl(x, wf, tl, n_out, K, cout), reps)
+        a = ops.spconv_fwd_x6(x, wp6, tbl, n_out, out_rows=rows, gmask=gm)
+        b = ops.spconv_fwd_tl(x, wf, tl, n_out, K, cout)
+        fl = 2.0 * pairs * cin * cout
+        row.update({"pairs": pairs, "x6_us": t_old, "tl_us": t_new, "tl_TF": fl / t_new / 1e6, "x6_TF": fl / t_old / 1e6,
+                    "lists_us": t_list, "prep_tl_us": timed(lambda: ops.weight_prep_tl(w, want_dgrad=False), reps),
+                    "max_rel_diff": (a - b).abs().max().item() / a.abs().max().item()})
+        res.append(row)
+        print(json.dumps(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()
