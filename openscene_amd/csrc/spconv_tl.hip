@@ -32,8 +32,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TL_BMAX = 112;      // rows per tile (LDS budget of the widest instance at 2 workgroups per CU)
-constexpr int TL_PMAX = 128;      // TL_BMAX rounded up to whole 32-pair iterations
+constexpr int TL_BMAX = 104;      // rows per tile (LDS budget of the widest instance at 2 workgroups per CU)
+constexpr int TL_LCAP = 1536;     // packed list entries resident in LDS per batch of offsets
 constexpr int TL_KMAX = 128;      // kernel offsets a list-mode launch can take (5^3 = 125)
 
 // ------------------------------------------------------------------------------------------- lists
@@ -106,6 +106,20 @@ __global__ void weight_prep_tl_kernel(const float* __restrict__ W, int K, int ci
 // ------------------------------------------------------------------------------------------ conv
 // NB16: 16-column blocks per wave (workgroup = 2 * NB16 * 16 output columns); KS: 32-deep k-steps per channel
 // chunk (B fragments of a chunk live in NB16 * KS * 12 VGPRs).
+//
+// Latency structure (measured: the first version paid three dependent global-memory latencies per
+// (tile, offset) -- list, gather, weights -- and ran at the speed of the round-1 kernel): the pair lists of a
+// whole BATCH of the tile's offsets are brought into LDS with one round of loads, and the (offset, chunk,
+// 32-pair iteration) steps of the batch then run as ONE flat software pipeline whose gathers are issued two
+// steps ahead, across offset boundaries; only the B-fragment load of a new (offset, chunk) is exposed, and it
+// hits L2.
+struct TlIter {
+    int a;        // offset index in klist
+    int s0;       // first 32-deep k-step of the channel chunk
+    int g;        // 32-pair iteration within the offset
+    int niter;    // iterations of offset a
+};
+
 template <int NB16, int KS>
 __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restrict__ in, const bf16x8* __restrict__ Wp,
                                                            const int32_t* __restrict__ cnt, const int2* __restrict__ lst,
@@ -118,14 +132,18 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
     constexpr int LDA = CK + 8;               // bf16 row stride of a staged plane (16-byte aligned rows)
     constexpr int QR = CK / 4;                // 4-channel quads per staged row
     constexpr int NQ = KS;                    // quads per thread per iteration (32 rows * QR / 256)
+    constexpr int NL = TL_LCAP / 256;         // list entries per thread per batch
     __shared__ __attribute__((aligned(16))) float otile[(TL_BMAX + 1) * S];     // + one dump row for padded pairs
     __shared__ __attribute__((aligned(16))) __bf16 stage[3][32][LDA];
-    __shared__ int2 plist[TL_PMAX];
+    __shared__ uint32_t plist[TL_LCAP];       // (local output row << 24) | input row, 32-padded per offset
     __shared__ int klist[TL_KMAX];
     __shared__ int kcnt[TL_KMAX];
-    __shared__ int nact_s;
+    __shared__ int lstart[TL_KMAX + 1];       // first plist slot of each offset of the current batch
+    __shared__ unsigned char gowner[TL_LCAP / 32];
+    __shared__ int nact_s, bend_s;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform => scalar registers
     const int ph = wave & 1, cg = wave >> 1;
     const int tile = blockIdx.x;
     const int row0 = tile * bm;
@@ -159,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
         nact_s = 1;
     }
     __syncthreads();
-    const int nact = nact_s;
+    const int nact = __builtin_amdgcn_readfirstlane(nact_s);
 
     // loop-invariant staging coordinates of this thread's quads
     int q_row[NQ], q_col[NQ];
@@ -169,115 +187,197 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
         q_row[j] = idx / QR;
         q_col[j] = (idx - q_row[j] * QR) * 4;
     }
+    const int nchunk = (ns + KS - 1) / KS;
 
     bf16x8 B[KS][NB16][3];
-    float4 pa[NQ];
+    float4 P0[NQ], P1[NQ];
 
-    for (int a = 0; a < nact; ++a) {
-        const int k = klist[a];
-        const int c = kcnt[a];
-        const int npad = (c + 31) & ~31;
-        __syncthreads();                                   // the previous offset's last iteration is done with plist
-        for (int p = tid; p < npad; p += 256) {
-            int2 e = make_int2(0, TL_BMAX);                // padded pair: valid address, dump row
-            if (p < c) e = cnt ? lst[(int64_t(tile) * K + k) * bm + p] : make_int2(row0 + p, p);
-            plist[p] = e;
+    int a0 = 0;
+    while (a0 < nact) {
+        // ---- batch [a0, a1): as many consecutive offsets as fit the LDS list buffer
+        if (tid == 0) {
+            int tot = 0, a = a0;
+            while (a < nact) {
+                const int np = (kcnt[a] + 31) & ~31;
+                if (tot + np > TL_LCAP) break;             // a single offset (<= 128 entries) always fits
+                lstart[a] = tot;
+                tot += np;
+                ++a;
+            }
+            lstart[a] = tot;
+            bend_s = a;
+        }
+        __syncthreads();                                   // (also: the previous batch is done with plist / lstart)
+        const int a1 = __builtin_amdgcn_readfirstlane(bend_s);
+        const int E = __builtin_amdgcn_readfirstlane(lstart[a1]);
+        if (tid < a1 - a0) {
+            const int a = a0 + tid;
+            for (int g = lstart[a] >> 5; g < (lstart[a + 1] >> 5); ++g) gowner[g] = (unsigned char)a;
         }
         __syncthreads();
-        const int niter = npad >> 5;
-        for (int c0 = 0, s0 = 0; c0 < cin; c0 += CK, s0 += KS) {
-            // ---- B fragments of (offset, chunk, this wave's columns): one coalesced 1 KB load each
+        if (cnt) {
+            // all loads first (unconditional, clamped addresses), then the selects and the LDS writes: one
+            // exposed memory latency per batch instead of one per entry
+            int2 x[NL];
+            bool okv[NL];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
+            for (int j = 0; j < NL; ++j) {
+                const int e = tid + 256 * j;
+                const int ec = e < E ? e : 0;
+                const int a = gowner[ec >> 5];
+                const int p = ec - lstart[a];
+                okv[j] = e < E && p < kcnt[a];
+                x[j] = lst[(int64_t(tile) * K + klist[a]) * bm + (okv[j] ? p : 0)];
+            }
 #pragma unroll
-                for (int nb = 0; nb < NB16; ++nb) {
-                    const bool on = s0 + ks < ns && cb0 + nb < ncb;
-                    const int sb = on ? s0 + ks : 0, cb = on ? cb0 + nb : 0;
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        bf16x8 v = Wp[((int64_t(pl * K + k) * ns + sb) * ncb + cb) * 64 + lane];
-                        if (!on)
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-                        B[ks][nb][pl] = v;
-                    }
+            for (int j = 0; j < NL; ++j) {
+                // padded pair: input row 0 (valid address), dump row
+                const uint32_t v = okv[j] ? ((uint32_t(x[j].y) << 24) | uint32_t(x[j].x)) : (uint32_t(TL_BMAX) << 24);
+                if (tid + 256 * j < E) plist[tid + 256 * j] = v;
+            }
+        } else {
+            for (int e = tid; e < E; e += 256)
+                plist[e] = e < rows ? ((uint32_t(e) << 24) | uint32_t(row0 + e)) : (uint32_t(TL_BMAX) << 24);
+        }
+        __syncthreads();
+
+        // ---- flat pipeline over the (offset, chunk, iteration) steps of the batch
+        auto first = [&](int a) {
+            TlIter it;
+            it.a = a; it.s0 = 0; it.g = 0;
+            it.niter = a < a1 ? (__builtin_amdgcn_readfirstlane(kcnt[a]) + 31) >> 5 : 0;
+            return it;
+        };
+        auto advance = [&](TlIter& it) {
+            if (++it.g == it.niter) {
+                it.g = 0;
+                it.s0 += KS;
+                if (it.s0 >= ns) {
+                    it.s0 = 0;
+                    ++it.a;
+                    it.niter = it.a < a1 ? (__builtin_amdgcn_readfirstlane(kcnt[it.a]) + 31) >> 5 : 0;
                 }
-            // gather of iteration g: 32 list entries x CK channels, one 16-byte load per quad (unconditional,
-            // clamped address; masked at conversion time)
-            auto fetch = [&](int g) {
+            }
+        };
+        // gather of one step: 32 list entries x CK channels, one 16-byte load per quad (unconditional, clamped
+        // address; masked at conversion time)
+        auto fetch = [&](const TlIter& it, float4 (&P)[NQ]) {
+            const int base = __builtin_amdgcn_readfirstlane(lstart[it.a]) + 32 * it.g;
 #pragma unroll
-                for (int j = 0; j < NQ; ++j) {
-                    const int row = plist[g * 32 + q_row[j]].x;
-                    const int ch = c0 + q_col[j];
-                    const unsigned cu = ch < cin ? unsigned(ch) : 0u;
-                    pa[j] = *reinterpret_cast<const float4*>(in + (uint64_t(unsigned(row)) * unsigned(cin) + cu));
+            for (int j = 0; j < NQ; ++j) {
+                const unsigned row = plist[base + q_row[j]] & 0xFFFFFFu;
+                const int ch = 32 * it.s0 + q_col[j];
+                const unsigned cu = ch < cin ? unsigned(ch) : 0u;
+                P[j] = *reinterpret_cast<const float4*>(in + (uint64_t(row) * unsigned(cin) + cu));
+            }
+        };
+        auto step = [&](const TlIter& it, float4 (&P)[NQ], const TlIter& nf) {
+            // ---- split the fetched quads into three bf16 pieces (registers)
+            bf16x4 p1[NQ], p2[NQ], p3[NQ];
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const bool ok = 32 * it.s0 + q_col[j] < cin;
+                const float x[4] = {P[j].x, P[j].y, P[j].z, P[j].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = ok ? x[e] : 0.f;
+                    const __bf16 h1 = (__bf16)v;
+                    const float r1 = v - (float)h1;
+                    const __bf16 h2 = (__bf16)r1;
+                    const float r2 = r1 - (float)h2;
+                    p1[j][e] = h1; p2[j][e] = h2; p3[j][e] = (__bf16)r2;
                 }
-            };
-            fetch(0);
-            for (int g = 0; g < niter; ++g) {
-                // ---- split the fetched quads into three bf16 pieces (registers)
-                bf16x4 p1[NQ], p2[NQ], p3[NQ];
+            }
+            // ---- new (offset, chunk): B fragments of this wave's columns, one coalesced 1 KB load each
+            if (it.g == 0) {
+                const int k = __builtin_amdgcn_readfirstlane(klist[it.a]);        // wave-uniform: scalar address math
 #pragma unroll
-                for (int j = 0; j < NQ; ++j) {
-                    const bool ok = c0 + q_col[j] < cin;
-                    const float x[4] = {pa[j].x, pa[j].y, pa[j].z, pa[j].w};
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = ok ? x[e] : 0.f;
-                        const __bf16 h1 = (__bf16)v;
-                        const float r1 = v - (float)h1;
-                        const __bf16 h2 = (__bf16)r1;
-                        const float r2 = r1 - (float)h2;
-                        p1[j][e] = h1; p2[j][e] = h2; p3[j][e] = (__bf16)r2;
-                    }
-                }
-                __syncthreads();                           // every wave is done reading the previous stage
+                    for (int nb = 0; nb < NB16; ++nb) {
+                        // k-steps past the last chunk are never multiplied and column blocks past the weight feed
+                        // output columns that are never stored: load block 0 instead (valid memory), and do NOT touch
+                        // the loaded value here -- any use would make the compiler wait for the loads before the barrier
+                        const bool on = it.s0 + ks < ns && cb0 + nb < ncb;
+                        const unsigned sb = on ? unsigned(it.s0 + ks) : 0u, cb = on ? unsigned(cb0 + nb) : 0u;
 #pragma unroll
-                for (int j = 0; j < NQ; ++j) {
-                    *reinterpret_cast<bf16x4*>(&stage[0][q_row[j]][q_col[j]]) = p1[j];
-                    *reinterpret_cast<bf16x4*>(&stage[1][q_row[j]][q_col[j]]) = p2[j];
-                    *reinterpret_cast<bf16x4*>(&stage[2][q_row[j]][q_col[j]]) = p3[j];
-                }
-                if (g + 1 < niter) fetch(g + 1);           // in flight during the MFMAs below
-                __syncthreads();                           // stage ready
-                // ---- 16 pairs x NB16 * 16 columns per wave
-                f32x4 acc[NB16];
-#pragma unroll
-                for (int nb = 0; nb < NB16; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const int arow = ph * 16 + (lane & 15);
-                const int akq = 8 * (lane >> 4);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    if (s0 + ks < ns) {
-                        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&stage[0][arow][ks * 32 + akq]);
-                        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&stage[1][arow][ks * 32 + akq]);
-                        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(&stage[2][arow][ks * 32 + akq]);
-#pragma unroll
-                        for (int nb = 0; nb < NB16; ++nb) {
-                            f32x4 t = acc[nb];
-                            t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, B[ks][nb][0], t, 0, 0, 0);
-                            t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, B[ks][nb][1], t, 0, 0, 0);
-                            t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, B[ks][nb][2], t, 0, 0, 0);
-                            t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, B[ks][nb][0], t, 0, 0, 0);
-                            t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, B[ks][nb][1], t, 0, 0, 0);
-                            t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, B[ks][nb][0], t, 0, 0, 0);
-                            acc[nb] = t;
+                        for (int pl = 0; pl < 3; ++pl) {
+                            const unsigned blk = ((unsigned(pl * K + k) * unsigned(ns) + sb) * unsigned(ncb) + cb);   // 1 KB blocks
+                            B[ks][nb][pl] = (Wp + (size_t(blk) << 6))[lane];
                         }
                     }
-                }
-                // ---- add the result block into the output tile: C row = 4 (lane >> 4) + r, col = lane & 15
-                int orow[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) orow[r] = plist[g * 32 + ph * 16 + 4 * (lane >> 4) + r].y;
-#pragma unroll
-                for (int nb = 0; nb < NB16; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float* p = &otile[orow[r] * S + (cg * NB16 + nb) * 16 + (lane & 15)];
-                        *p += acc[nb][r];
-                    }
             }
+            __syncthreads();                               // every wave is done reading the previous stage
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                *reinterpret_cast<bf16x4*>(&stage[0][q_row[j]][q_col[j]]) = p1[j];
+                *reinterpret_cast<bf16x4*>(&stage[1][q_row[j]][q_col[j]]) = p2[j];
+                *reinterpret_cast<bf16x4*>(&stage[2][q_row[j]][q_col[j]]) = p3[j];
+            }
+            if (nf.a < a1) fetch(nf, P);                   // two steps ahead; in flight during the MFMAs below
+            __syncthreads();                               // stage ready
+            // ---- 16 pairs x NB16 * 16 columns per wave
+            f32x4 acc[NB16];
+#pragma unroll
+            for (int nb = 0; nb < NB16; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int arow = ph * 16 + (lane & 15);
+            const int akq = 8 * (lane >> 4);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (it.s0 + ks < ns) {
+                    const bf16x8 a1f = *reinterpret_cast<const bf16x8*>(&stage[0][arow][ks * 32 + akq]);
+                    const bf16x8 a2f = *reinterpret_cast<const bf16x8*>(&stage[1][arow][ks * 32 + akq]);
+                    const bf16x8 a3f = *reinterpret_cast<const bf16x8*>(&stage[2][arow][ks * 32 + akq]);
+#pragma unroll
+                    for (int nb = 0; nb < NB16; ++nb) {
+                        f32x4 t = acc[nb];
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3f, B[ks][nb][0], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2f, B[ks][nb][1], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1f, B[ks][nb][2], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2f, B[ks][nb][0], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1f, B[ks][nb][1], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1f, B[ks][nb][0], t, 0, 0, 0);
+                        acc[nb] = t;
+                    }
+                }
+            }
+            // ---- add the result block into the output tile: C row = 4 (lane >> 4) + r, col = lane & 15
+            // (all reads first, then all writes: the 4 * NB16 cells of a lane are distinct -- one output row per
+            // pair within an offset -- but the compiler cannot know, and a read-add-write chain per cell would
+            // serialise 4 * NB16 LDS round trips)
+            const int pbase = __builtin_amdgcn_readfirstlane(lstart[it.a]) + 32 * it.g + ph * 16 + 4 * (lane >> 4);
+            int orow[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) orow[r] = int(plist[pbase + r] >> 24);
+            float cur[NB16][4];
+#pragma unroll
+            for (int nb = 0; nb < NB16; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cur[nb][r] = otile[orow[r] * S + (cg * NB16 + nb) * 16 + (lane & 15)];
+#pragma unroll
+            for (int nb = 0; nb < NB16; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    otile[orow[r] * S + (cg * NB16 + nb) * 16 + (lane & 15)] = cur[nb][r] + acc[nb][r];
+        };
+
+        TlIter cur = first(a0);
+        TlIter n1 = cur;
+        advance(n1);
+        TlIter n2 = n1;
+        if (n1.a < a1) advance(n2);
+        fetch(cur, P0);
+        if (n1.a < a1) fetch(n1, P1);
+        while (cur.a < a1) {
+            step(cur, P0, n2);
+            cur = n1; n1 = n2;
+            if (n2.a < a1) advance(n2);
+            if (cur.a >= a1) break;
+            step(cur, P1, n2);
+            cur = n1; n1 = n2;
+            if (n2.a < a1) advance(n2);
         }
+        a0 = a1;
     }
     __syncthreads();
 
@@ -381,14 +481,16 @@ extern "C" int osn_weight_prep_tl(const float* W, int K, int cin, int cout, int 
     return OSN_OK;
 }
 
-extern "C" int osn_spconv_fwd_tl(const float* in, const void* Wp, const void* tl, const int32_t* out_rows, float* out,
-                                 double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm,
+extern "C" int osn_spconv_fwd_tl(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
+                                 float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm,
                                  osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_spconv_fwd_tl: n_out out of range");
     OSN_REQUIRE(K >= 1 && K <= TL_KMAX && cin >= 4 && (cin & 3) == 0 && cout >= 4 && (cout & 3) == 0, OSN_E_ARG,
                 "osn_spconv_fwd_tl: needs K <= %d, cin %% 4 == 0, cout %% 4 == 0 (K=%d cin=%d cout=%d)", TL_KMAX, K, cin, cout);
     OSN_REQUIRE(bm >= 1 && bm <= TL_BMAX, OSN_E_ARG, "osn_spconv_fwd_tl: bm=%d (at most %d rows per tile)", bm, TL_BMAX);
+    OSN_REQUIRE(n_in >= 0 && n_in <= (int64_t(1) << 24), OSN_E_RANGE,
+                "osn_spconv_fwd_tl: %lld input rows (the kernel packs an input row into 24 bits; use osn_spconv_fwd_x6)", (long long)n_in);
     if (n_out == 0) return OSN_OK;
     OSN_REQUIRE(in && Wp && out, OSN_E_ARG, "osn_spconv_fwd_tl: null pointer");
     OSN_REQUIRE(tl || (K == 1 && !out_rows), OSN_E_ARG, "osn_spconv_fwd_tl: tile lists may be null only for K == 1 (identity map)");

@@ -337,9 +337,9 @@ def tile_lists(nbr, out_rows=None, bm=None):
     return TileLists(buf, bm, n_out, K, out_rows)
 
 
-def tl_eligible(K, cin, cout):
-    """Shapes the tile-list kernel takes (everything of the U-Net but the 3-channel stem)."""
-    return cin % 4 == 0 and cin >= 8 and cout % 4 == 0 and K <= 128
+def tl_eligible(K, cin, cout, n_in=0):
+    """Shapes the tile-list kernel takes (everything of the U-Net but the 3-channel stem; up to 2^24 input rows)."""
+    return cin % 4 == 0 and cin >= 8 and cout % 4 == 0 and K <= 128 and n_in <= (1 << 24)
 
 
 def weight_prep_tl(weight, flip=False, want_fwd=True, want_dgrad=True):
@@ -378,8 +378,8 @@ def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
     tok = _profiler.start("spconv_fwd_tl", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
         if _profiler is not None else None
     with _Dev(dev):
-        check(lib.osn_spconv_fwd_tl(_p(feats), _p(wp), _p(buf), _p(rows), _p(out), _p(bn_partial), n_out, K, cin, cout,
-                                    bm, _stream(dev)), "osn_spconv_fwd_tl")
+        check(lib.osn_spconv_fwd_tl(_p(feats), feats.shape[0], _p(wp), _p(buf), _p(rows), _p(out), _p(bn_partial), n_out,
+                                    K, cin, cout, bm, _stream(dev)), "osn_spconv_fwd_tl")
     if tok is not None:
         _profiler.stop(tok)
     return out

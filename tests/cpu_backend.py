@@ -119,13 +119,13 @@ class TileLists:
 
 
 def tile_rows(n_out):
-    """Spec of osn_tile_rows: whole rounds of 512 workgroups, at most 112 rows, at least 32, multiple of 4."""
+    """Spec of osn_tile_rows: whole rounds of 512 workgroups, at most 104 rows, at least 32, multiple of 4."""
     if n_out <= 0:
         return 32
-    rounds = -(-n_out // (512 * 112))
+    rounds = -(-n_out // (512 * 104))
     bm = -(-n_out // (512 * rounds))
     bm = (bm + 3) // 4 * 4
-    return max(32, min(112, bm))
+    return max(32, min(104, bm))
 
 
 def tile_lists(nbr, out_rows=None, bm=None):
@@ -145,8 +145,8 @@ def tile_lists(nbr, out_rows=None, bm=None):
     return TileLists(torch.from_numpy(cnt), torch.from_numpy(lst), bm, n_out, K, out_rows)
 
 
-def tl_eligible(K, cin, cout):
-    return cin % 4 == 0 and cin >= 8 and cout % 4 == 0 and K <= 128
+def tl_eligible(K, cin, cout, n_in=0):
+    return cin % 4 == 0 and cin >= 8 and cout % 4 == 0 and K <= 128 and n_in <= (1 << 24)
 
 
 def weight_prep_tl(weight, flip=False, want_fwd=True, want_dgrad=True):
