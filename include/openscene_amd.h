@@ -133,9 +133,9 @@ int osn_spconv_fwd_x6(const float* in, const void* Wp, const int32_t* nbr, const
  * bitwise reproducible), other data layout: the kernel map of every tile of `bm` consecutive rows of a
  * neighbour table is stored per offset as a dense list of (input row, local output row) pairs -- what
  * [ME] calls the kernel map's in/out index lists, cut per tile -- so the matrix units only see real
- * pairs, the weights of an offset stay in registers for the whole (tile, offset), and the output tile is
- * accumulated in LDS.
- *   osn_tile_rows(n_out)            rows per tile for a table of n_out rows (host helper, <= 104)
+ * pairs, the weights of an offset stay in registers for a whole (tile, offset), the output tile is
+ * accumulated in LDS, and persistent workgroups draw the tiles from an atomic counter (densest first).
+ *   osn_tile_rows(n_out)            rows per tile for a table of n_out rows (host helper, 32 .. 88)
  *   osn_tile_lists_build(nbr, ..)   tl = { int32 cnt[n_tiles][K] (256-byte aligned), int2 lst[n_tiles][K][bm] }
  *                                   from a (possibly osn_kmap_sort-ordered) table; lists keep row order
  *   osn_weight_prep_tl(W, ..)       MFMA-fragment images of a weight: Wp_fwd for the forward, Wp_dgrad
@@ -145,6 +145,7 @@ int osn_spconv_fwd_x6(const float* in, const void* Wp, const int32_t* nbr, const
  *                                   row j; tl = null <=> K == 1 identity map.  bn_partial (nullable):
  *                                   double [n_tiles][2][cout] per-tile column sums / sums of squares of
  *                                   `out` (the following batch norm's statistics without a pass over out).
+ *                                   ws: osn_spconv_fwd_tl_ws_bytes() bytes (tile counters, zeroed by the call).
  *                                   Needs cin % 4 == 0, cout % 4 == 0 and n_in <= 2^24 (OSN_E_RANGE otherwise).  */
 int osn_tile_rows(int64_t n_out);
 size_t osn_tile_lists_bytes(int64_t n_out, int K, int bm);
@@ -152,9 +153,10 @@ int osn_tile_lists_build(const int32_t* nbr, int64_t n_out, int K, int bm, void*
 size_t osn_weight_prep_tl_bytes(int K, int cin, int cout, int for_dgrad);
 int osn_weight_prep_tl(const float* W, int K, int cin, int cout, int flip, void* Wp_fwd, void* Wp_dgrad,
                        osn_stream_t stream);
+size_t osn_spconv_fwd_tl_ws_bytes(void);
 int osn_spconv_fwd_tl(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
                       float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm,
-                      osn_stream_t stream);
+                      void* ws, size_t ws_bytes, osn_stream_t stream);
 
 /* Which kernel instance / launch shape osn_spconv_fwd() uses for a problem (host helper, for
  * profiling): plan6 = {WM, WN, TN, BK, S (offset splits), workgroups};

@@ -1,0 +1,514 @@
+// Weight gradient of the sparse convolution on gfx950, second generation: per-offset compacted pair arrays,
+// split-bf16 arithmetic on v_mfma_f32_16x16x32_bf16 with LDS transpose reads.
+//
+// Function parity (not a port) with MinkowskiEngine's convolution backward w.r.t. the kernel (SURVEY.md
+// appendix C item 5):  gW[k] = sum over the pairs (i, o) of offset k of  in[i, :]^T (x) gout[o, :].
+//
+// Round 1 measured what held the first kernel (fp32 MFMA, dense neighbour table) at 38 % of its roof: not the
+// matrix pipe and not gather locality, but the per-chunk ballot compaction of the table and two barriers per
+// 32-pair stage.  Here the pairs of every offset are compacted ONCE per map into arrays (input row, output row)
+// in tile order -- MinkowskiEngine's own kernel-map format -- shared by every convolution and every step of the
+// map's life, so the hot loop is gather -> split -> MFMA:
+//   * a work item = (offset, range of <= quota pairs), planned on the device from the per-offset totals (a pure
+//     function of the map => deterministic); partial results are summed in item order by a second launch;
+//   * per 32-pair step the workgroup gathers the pairs' input rows and output-gradient rows (16-byte loads),
+//     splits them into three bf16 pieces and stages them ROW-MAJOR [pair][channel] in LDS;
+//   * the contraction runs over the pairs, i.e. down the LDS rows: operands are fetched with
+//     ds_read_b64_tr_b16 (lane i of a 16-lane group receives channel i of four consecutive pairs; semantics
+//     measured in round 1, tools/probes/probe_gfx950.hip), 2 reads per 16 x 32 operand fragment;
+//   * 4 waves as 2 x 2 over the (input channel, output channel) block, MB x NB accumulator blocks of 16 x 16
+//     per wave, six MFMAs per block and step (a3g1 + a2g2 + a1g3 + a2g1 + a1g2 + a1g1, fp32 accumulate).
+#include "common.h"
+
+namespace osn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PL_KMAX = 128;          // offsets per map (5^3 = 125)
+constexpr int PL_ITEMS = 512;         // work items per map: one round of 2 workgroups per CU
+constexpr int PL_MIN_QUOTA = 256;     // pairs per item at least (bounds the partial-sum traffic of small maps)
+
+// ---- layout of a pair-list buffer ("pl")
+constexpr size_t PL_OFF_POFF = 0;                                   // int32 [PL_KMAX + 1] first pair of each offset
+constexpr size_t PL_OFF_TOTAL = 1024;                               // int32 [PL_KMAX]     pairs of each offset
+constexpr size_t PL_OFF_ITEMS = 2048;                               // int4  [PL_ITEMS]    (k, p0, p1, 0), k = -1 unused
+constexpr size_t PL_OFF_RANGE = PL_OFF_ITEMS + size_t(PL_ITEMS) * 16;   // int2 [PL_KMAX]  items of each offset [first, last)
+constexpr size_t PL_OFF_PAIRS = 16384;                              // int32 pin[cap], pout[cap], then the tile-prefix scratch
+
+struct PlView {
+    int32_t *poff, *total;
+    int4* items;
+    int2* range;
+    int32_t *pin, *pout, *pref;
+    size_t bytes;
+};
+
+static PlView pl_view(void* base, int64_t n_out, int K, int bm) {
+    PlView v;
+    char* p = static_cast<char*>(base);
+    const size_t cap = size_t(K) * size_t(n_out > 0 ? n_out : 1);
+    const size_t nt = size_t(cdiv(n_out > 0 ? n_out : 1, bm > 0 ? bm : 1));
+    v.poff = reinterpret_cast<int32_t*>(p + PL_OFF_POFF);
+    v.total = reinterpret_cast<int32_t*>(p + PL_OFF_TOTAL);
+    v.items = reinterpret_cast<int4*>(p + PL_OFF_ITEMS);
+    v.range = reinterpret_cast<int2*>(p + PL_OFF_RANGE);
+    v.pin = reinterpret_cast<int32_t*>(p + PL_OFF_PAIRS);
+    v.pout = v.pin + cap;
+    v.pref = v.pout + cap;
+    v.bytes = PL_OFF_PAIRS + (2 * cap + size_t(K) * nt) * 4;
+    return v;
+}
+
+__device__ inline int wave_incl_scan_i32(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// pref[k][tile] = pairs of offset k in the tiles before `tile`; total[k].  One workgroup per offset.
+__global__ __launch_bounds__(256) void pair_prefix_kernel(const int32_t* __restrict__ cnt, int n_tiles, int K,
+                                                          int32_t* __restrict__ pref, int32_t* __restrict__ total) {
+    __shared__ int wtot[4];
+    __shared__ int carry_s;
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < n_tiles; t0 += 256) {
+        const int t = t0 + tid;
+        const int v = t < n_tiles ? cnt[int64_t(t) * K + k] : 0;
+        const int incl = wave_incl_scan_i32(v, lane);
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) woff += w < wave ? wtot[w] : 0;
+        const int carry = carry_s;
+        if (t < n_tiles) pref[int64_t(k) * n_tiles + t] = carry + woff + incl - v;
+        __syncthreads();
+        if (tid == 255) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) total[k] = carry_s;
+}
+
+// pin / pout of every offset, in (tile, local row) order; workgroup 0 also publishes poff.
+__global__ __launch_bounds__(256) void pair_fill_kernel(const int32_t* __restrict__ cnt, const int2* __restrict__ lst,
+                                                        const int32_t* __restrict__ out_rows,
+                                                        const int32_t* __restrict__ pref, const int32_t* __restrict__ total,
+                                                        int n_tiles, int K, int bm, int32_t* __restrict__ pin,
+                                                        int32_t* __restrict__ pout, int32_t* __restrict__ poff) {
+    __shared__ int poff_s[PL_KMAX + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t tile = blockIdx.x;
+    if (wave == 0) {
+        int carry = 0;
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int k = k0 + lane;
+            const int v = k < K ? total[k] : 0;
+            const int incl = wave_incl_scan_i32(v, lane);
+            if (k < K) poff_s[k] = carry + incl - v;
+            carry += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) poff_s[K] = carry;
+    }
+    __syncthreads();
+    if (tile == 0)
+        for (int k = tid; k <= K; k += 256) poff[k] = poff_s[k];
+    for (int k = wave; k < K; k += 4) {
+        const int c = cnt[tile * K + k];
+        const int base = poff_s[k] + pref[int64_t(k) * n_tiles + tile];
+        const int2* src = lst + (tile * K + k) * bm;
+        for (int p = lane; p < c; p += 64) {
+            const int2 e = src[p];
+            pin[base + p] = e.x;
+            const int64_t r = tile * bm + e.y;
+            pout[base + p] = out_rows ? out_rows[r] : int(r);
+        }
+    }
+}
+
+// Work items: every offset's pairs cut into ranges of `quota` pairs (quota: whole 32-pair steps, at least
+// PL_MIN_QUOTA, such that at most PL_ITEMS items exist).  One workgroup.
+__global__ __launch_bounds__(256) void pair_plan_kernel(const int32_t* __restrict__ total, int K, int4* __restrict__ items,
+                                                        int2* __restrict__ range) {
+    __shared__ int nk[PL_KMAX];
+    __shared__ int start[PL_KMAX + 1];
+    __shared__ int quota_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        long long P = 0;
+        for (int k = 0; k < K; ++k) P += total[k];
+        long long q = (P + (PL_ITEMS - K) - 1) / (PL_ITEMS - K);
+        q = (q + 31) / 32 * 32;
+        if (q < PL_MIN_QUOTA) q = PL_MIN_QUOTA;
+        quota_s = int(q);
+    }
+    __syncthreads();
+    const int quota = quota_s;
+    if (tid < K) nk[tid] = (total[tid] + quota - 1) / quota;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int k = 0; k < K; ++k) { start[k] = acc; acc += nk[k]; }
+        start[K] = acc;
+    }
+    __syncthreads();
+    if (tid < K) range[tid] = make_int2(start[tid], start[tid + 1]);
+    for (int t = tid; t < PL_ITEMS; t += 256) {
+        int4 it = make_int4(-1, 0, 0, 0);
+        if (t < start[K]) {
+            int k = 0;
+            while (k + 1 < K && start[k + 1] <= t) ++k;
+            const int j = t - start[k];
+            it.x = k;
+            it.y = j * quota;
+            it.z = min(it.y + quota, total[k]);
+        }
+        items[t] = it;
+    }
+}
+
+// ------------------------------------------------------------------------------------- the kernel
+// MB / NB: 16 x 16 accumulator blocks per wave along the input / output channels; a workgroup covers
+// (32 MB) x (32 NB) of gW[k].  identity (pin == nullptr): K == 1, pair p = (row p, row p), items cut by rows.
+template <int MB, int NB>
+__global__ __launch_bounds__(256, 2) void wgrad_tl_kernel(const float* __restrict__ rows_a, const float* __restrict__ rows_g,
+                                                          const int32_t* __restrict__ idx_a, const int32_t* __restrict__ idx_g,
+                                                          const int32_t* __restrict__ poff, const int4* __restrict__ items,
+                                                          float* __restrict__ partial, int ca, int cg, int n_cgb,
+                                                          int ident_rows, int ident_quota) {
+    constexpr int CA_T = 32 * MB, CG_T = 32 * NB;
+    constexpr int LDA = CA_T + 8, LDG = CG_T + 8;        // bf16 row pitch (16-byte aligned rows)
+    constexpr int QA = CA_T / 4, QG = CG_T / 4;          // quads per staged row
+    __shared__ __attribute__((aligned(16))) __bf16 Ap[3][32][LDA];
+    __shared__ __attribute__((aligned(16))) __bf16 Gp[3][32][LDG];
+    __shared__ int idxbuf[2][32];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int a0 = (blockIdx.x / n_cgb) * CA_T;          // first input channel of the workgroup's block
+    const int g0 = (blockIdx.x % n_cgb) * CG_T;
+    int k, p0, p1, base;
+    if (idx_a) {
+        const int4 it = items[blockIdx.y];
+        k = it.x; p0 = it.y; p1 = it.z;
+        if (k < 0) return;
+        base = poff[k];
+    } else {
+        k = 0; base = 0;
+        p0 = blockIdx.y * ident_quota;
+        p1 = min(p0 + ident_quota, ident_rows);
+        if (p0 >= p1) return;
+    }
+    (void)k;
+
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging coordinates of this thread's quads (MB of the A rows, NB of the G rows)
+    int ar[MB], ac[MB], gr[NB], gc[NB];
+#pragma unroll
+    for (int j = 0; j < MB; ++j) { const int idx = tid + 256 * j; ar[j] = idx / QA; ac[j] = (idx - ar[j] * QA) * 4; }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { const int idx = tid + 256 * j; gr[j] = idx / QG; gc[j] = (idx - gr[j] * QG) * 4; }
+
+    float4 pa[MB], pg[NB];
+    // the (input row, output row) of pair p0 + s * 32 + (tid & 31): threads 0..31 hold the A index, 32..63 the G index
+    auto load_idx = [&](int p) -> int {
+        const int q = p + (tid & 31);
+        if (tid >= 64) return -1;
+        if (q >= p1) return -1;
+        if (!idx_a) return q;
+        return tid < 32 ? idx_a[base + q] : idx_g[base + q];
+    };
+    auto fetch = [&](int par) {
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int r = idxbuf[0][ar[j]];
+            const int ch = a0 + ac[j];
+            const bool ok = r >= 0 && ch < ca;
+            const unsigned ru = ok ? unsigned(r) : 0u, cu = ok ? unsigned(ch) : 0u;
+            pa[j] = *reinterpret_cast<const float4*>(rows_a + (uint64_t(ru) * unsigned(ca) + cu));
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int r = idxbuf[1][gr[j]];
+            const int ch = g0 + gc[j];
+            const bool ok = r >= 0 && ch < cg;
+            const unsigned ru = ok ? unsigned(r) : 0u, cu = ok ? unsigned(ch) : 0u;
+            pg[j] = *reinterpret_cast<const float4*>(rows_g + (uint64_t(ru) * unsigned(cg) + cu));
+        }
+        (void)par;
+    };
+    auto split4 = [&](const float4& v, bool ok, bf16x4& h1, bf16x4& h2, bf16x4& h3) {
+        const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = ok ? x[e] : 0.f;
+            const __bf16 a = (__bf16)t;
+            const float r1 = t - (float)a;
+            const __bf16 b = (__bf16)r1;
+            const float r2 = r1 - (float)b;
+            h1[e] = a; h2[e] = b; h3[e] = (__bf16)r2;
+        }
+    };
+
+    // prologue: indices of step 0 -> LDS -> rows of step 0 in flight, indices of step 1 in registers
+    int ireg = load_idx(p0);
+    if (tid < 64) idxbuf[tid >> 5][tid & 31] = ireg;
+    __syncthreads();
+    bool ok_a[MB], ok_g[NB];
+    auto valid_now = [&]() {
+#pragma unroll
+        for (int j = 0; j < MB; ++j) ok_a[j] = idxbuf[0][ar[j]] >= 0 && a0 + ac[j] < ca;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) ok_g[j] = idxbuf[1][gr[j]] >= 0 && g0 + gc[j] < cg;
+    };
+    valid_now();
+    fetch(0);
+    ireg = load_idx(p0 + 32);
+
+    for (int p = p0; p < p1; p += 32) {
+        // ---- split the rows of this step (registers)
+        bf16x4 a1[MB], a2[MB], a3[MB], g1[NB], g2[NB], g3[NB];
+#pragma unroll
+        for (int j = 0; j < MB; ++j) split4(pa[j], ok_a[j], a1[j], a2[j], a3[j]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) split4(pg[j], ok_g[j], g1[j], g2[j], g3[j]);
+        __syncthreads();                                   // the previous step's fragments have been read
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            *reinterpret_cast<bf16x4*>(&Ap[0][ar[j]][ac[j]]) = a1[j];
+            *reinterpret_cast<bf16x4*>(&Ap[1][ar[j]][ac[j]]) = a2[j];
+            *reinterpret_cast<bf16x4*>(&Ap[2][ar[j]][ac[j]]) = a3[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            *reinterpret_cast<bf16x4*>(&Gp[0][gr[j]][gc[j]]) = g1[j];
+            *reinterpret_cast<bf16x4*>(&Gp[1][gr[j]][gc[j]]) = g2[j];
+            *reinterpret_cast<bf16x4*>(&Gp[2][gr[j]][gc[j]]) = g3[j];
+        }
+        if (tid < 64) idxbuf[tid >> 5][tid & 31] = ireg;  // indices of the next step
+        __syncthreads();
+        if (p + 32 < p1) {
+            valid_now();
+            fetch(0);                                      // rows of the next step: in flight during the MFMAs
+            ireg = load_idx(p + 64);
+        }
+        // ---- fragments by transpose reads: lane i of a 16-lane group points at (pair 8 g + (i >> 2), channels
+        // 4 (i & 3) .. + 3) of a 16-channel block and receives channel i of pairs 8 g .. 8 g + 3 (then + 4)
+        const int li = lane & 15, lg = lane >> 4;
+        auto frag = [&](const __bf16* plane, int pitch, int c16) -> bf16x8 {
+            const __bf16* q = plane + (8 * lg + (li >> 2)) * pitch + c16 + 4 * (li & 3);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(q));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(q + 4 * pitch));
+            union { s16x4 h[2]; bf16x8 v; } u;
+            u.h[0] = lo; u.h[1] = hi;
+            return u.v;
+        };
+        bf16x8 fa[MB][3], fg[NB][3];
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fa[i][pl] = frag(&Ap[pl][0][0], LDA, (wi * MB + i) * 16);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fg[j][pl] = frag(&Gp[pl][0][0], LDG, (wj * NB + j) * 16);
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                f32x4 t = acc[i][j];
+                t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][2], fg[j][0], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fg[j][1], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fg[j][2], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fg[j][0], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fg[j][1], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fg[j][0], t, 0, 0, 0);
+                acc[i][j] = t;
+            }
+    }
+
+    // ---- partial[item][ca][cg]: C row = 4 (lane >> 4) + r (input channel), col = lane & 15 (output channel)
+    float* d = partial + int64_t(blockIdx.y) * ca * cg;
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int co = g0 + (wj * NB + j) * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = a0 + (wi * MB + i) * 16 + 4 * (lane >> 4) + r;
+                if (ci < ca && co < cg) d[int64_t(ci) * cg + co] = acc[i][j][r];
+            }
+        }
+}
+
+// gW[k] = sum of the partials of offset k's items, in item order (offsets without pairs: zero).
+// transpose: the kernel ran with the operand roles swapped (partials are [cout][cin]).
+__global__ void wgrad_tl_reduce_kernel(const float* __restrict__ partial, const int2* __restrict__ range, int K, int cin,
+                                       int cout, int transpose, int ident_items, float* __restrict__ out) {
+    const int64_t per_k = int64_t(cin) * cout;
+    const int64_t total = int64_t(K) * per_k;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        const int k = int(e / per_k);
+        const int64_t r = e - int64_t(k) * per_k;
+        int64_t src = r;
+        if (transpose) {
+            const int ci = int(r / cout), co = int(r - int64_t(ci) * cout);
+            src = int64_t(co) * cin + ci;
+        }
+        const int t0 = range ? range[k].x : 0, t1 = range ? range[k].y : ident_items;
+        float s = 0.f;
+        for (int t = t0; t < t1; ++t) s += partial[int64_t(t) * per_k + src];
+        out[e] = s;
+    }
+}
+
+}  // namespace osn
+
+using namespace osn;
+
+extern "C" size_t osn_pair_lists_bytes(int64_t n_out, int K, int bm) {
+    if (K < 1 || K > PL_KMAX) return 0;
+    return pl_view(nullptr, n_out, K, bm).bytes;
+}
+
+extern "C" int osn_pair_lists_build(const void* tl, const int32_t* out_rows, int64_t n_out, int K, int bm, void* pl,
+                                    osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_pair_lists_build: n_out out of range");
+    OSN_REQUIRE(K >= 1 && K <= PL_KMAX && bm >= 1, OSN_E_ARG, "osn_pair_lists_build: K=%d bm=%d", K, bm);
+    OSN_REQUIRE(int64_t(K) * n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_pair_lists_build: K * n_out exceeds 32-bit pair indices");
+    OSN_REQUIRE(pl, OSN_E_ARG, "osn_pair_lists_build: null pointer");
+    PlView v = pl_view(pl, n_out, K, bm);
+    if (n_out == 0) {
+        OSN_HIP(hipMemsetAsync(pl, 0, PL_OFF_ITEMS, st));
+        OSN_HIP(hipMemsetAsync(v.items, 0xFF, size_t(PL_ITEMS) * 16, st));
+        OSN_HIP(hipMemsetAsync(v.range, 0, size_t(PL_KMAX) * 8, st));
+        return OSN_OK;
+    }
+    OSN_REQUIRE(tl, OSN_E_ARG, "osn_pair_lists_build: null tile lists");
+    const int64_t nt = cdiv(n_out, bm);
+    const int32_t* cnt = static_cast<const int32_t*>(tl);
+    const int2* lst = reinterpret_cast<const int2*>(static_cast<const char*>(tl) + align_up(size_t(nt) * K * 4, 256));
+    hipLaunchKernelGGL(pair_prefix_kernel, dim3(K), dim3(256), 0, st, cnt, int(nt), K, v.pref, v.total);
+    hipLaunchKernelGGL(pair_plan_kernel, dim3(1), dim3(256), 0, st, v.total, K, v.items, v.range);
+    hipLaunchKernelGGL(pair_fill_kernel, dim3(unsigned(nt)), dim3(256), 0, st, cnt, lst, out_rows, v.pref, v.total, int(nt), K,
+                       bm, v.pin, v.pout, v.poff);
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}
+
+namespace {
+struct WgTlPlan {
+    int mb, nb, n_ab, n_gb;     // blocks per wave, workgroup blocks along the A / G channels
+};
+WgTlPlan plan_wg_tl(int ca, int cg) {
+    auto blocks = [](int c) { int t = (c + 31) / 32; return t > 4 ? 4 : t; };    // 32-channel units per workgroup (<= 128)
+    WgTlPlan p;
+    p.mb = blocks(ca);
+    p.nb = blocks(cg);
+    p.n_ab = int(cdiv(ca, 32 * p.mb));
+    p.n_gb = int(cdiv(cg, 32 * p.nb));
+    return p;
+}
+int ident_quota(int64_t n) {
+    int64_t q = cdiv(n, PL_ITEMS);
+    q = (q + 31) / 32 * 32;
+    if (q < PL_MIN_QUOTA) q = PL_MIN_QUOTA;
+    return int(q);
+}
+}  // namespace
+
+extern "C" size_t osn_spconv_wgrad_tl_ws_bytes(int K, int cin, int cout) {
+    (void)K;
+    return size_t(PL_ITEMS) * size_t(cin) * size_t(cout) * 4;
+}
+
+template <int MB>
+static void launch_wg_tl_nb(int nb, dim3 grid, hipStream_t st, const float* ra, const float* rg, const int32_t* ia,
+                            const int32_t* ig, const int32_t* poff, const int4* items, float* partial, int ca, int cg,
+                            int n_gb, int irows, int iquota) {
+#define OSN_WGTL(NB_)                                                                                              \
+    hipLaunchKernelGGL((wgrad_tl_kernel<MB, NB_>), grid, dim3(256), 0, st, ra, rg, ia, ig, poff, items, partial, ca, cg, \
+                       n_gb, irows, iquota)
+    switch (nb) {
+        case 1: OSN_WGTL(1); break;
+        case 2: OSN_WGTL(2); break;
+        case 3: OSN_WGTL(3); break;
+        default: OSN_WGTL(4); break;
+    }
+#undef OSN_WGTL
+}
+
+extern "C" int osn_spconv_wgrad_tl(const float* in, const float* gout, const void* pl, int swap, float* gW, int64_t n_in,
+                                   int64_t n_out, int K, int cin, int cout, void* ws, size_t ws_bytes,
+                                   osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(K >= 1 && K <= PL_KMAX && cin >= 4 && (cin & 3) == 0 && cout >= 4 && (cout & 3) == 0 && gW, OSN_E_ARG,
+                "osn_spconv_wgrad_tl: needs cin %% 4 == 0 and cout %% 4 == 0 (K=%d cin=%d cout=%d)", K, cin, cout);
+    OSN_REQUIRE(n_in >= 0 && n_out >= 0 && n_in < (int64_t(1) << 31) && n_out < (int64_t(1) << 31), OSN_E_ARG,
+                "osn_spconv_wgrad_tl: row counts out of range");
+    const int64_t wtotal = int64_t(K) * cin * cout;
+    if (n_out == 0 || n_in == 0) {
+        OSN_HIP(hipMemsetAsync(gW, 0, size_t(wtotal) * 4, st));
+        return OSN_OK;
+    }
+    OSN_REQUIRE(in && gout, OSN_E_ARG, "osn_spconv_wgrad_tl: null pointer");
+    OSN_REQUIRE(pl || (K == 1 && n_in == n_out), OSN_E_ARG, "osn_spconv_wgrad_tl: pair lists may be null only for K == 1");
+    OSN_REQUIRE(aligned16(in) && aligned16(gout) && aligned16(gW), OSN_E_ARG, "osn_spconv_wgrad_tl: pointers must be 16-byte aligned");
+    const size_t need = osn_spconv_wgrad_tl_ws_bytes(K, cin, cout);
+    OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_spconv_wgrad_tl: workspace %zu < %zu", ws_bytes, need);
+    float* partial = static_cast<float*>(ws);
+    // operand A = rows contracted against the weight's FIRST channel index.  The pair arrays hold (table input
+    // row, table output row); a transposed conv runs on the strided conv's arrays with the roles swapped.
+    const float* ra = in;
+    const float* rg = gout;
+    const int ca = cin, cg = cout;
+    const int32_t *ia = nullptr, *ig = nullptr, *poff = nullptr;
+    const int4* items = nullptr;
+    const int2* range = nullptr;
+    int n_items = PL_ITEMS, irows = 0, iquota = 0;
+    if (pl) {
+        // the view only needs K and the capacity = K * (rows of the TABLE the lists were built from)
+        const int64_t table_rows = swap ? n_in : n_out;
+        PlView v = pl_view(const_cast<void*>(pl), table_rows, K, 1);
+        ia = swap ? v.pout : v.pin;
+        ig = swap ? v.pin : v.pout;
+        poff = v.poff;
+        items = v.items;
+        range = v.range;
+    } else {
+        irows = int(n_out);
+        iquota = ident_quota(n_out);
+        n_items = int(cdiv(n_out, iquota));
+    }
+    const WgTlPlan p = plan_wg_tl(ca, cg);
+    const dim3 grid(unsigned(p.n_ab * p.n_gb), unsigned(n_items));
+    switch (p.mb) {
+        case 1: launch_wg_tl_nb<1>(p.nb, grid, st, ra, rg, ia, ig, poff, items, partial, ca, cg, p.n_gb, irows, iquota); break;
+        case 2: launch_wg_tl_nb<2>(p.nb, grid, st, ra, rg, ia, ig, poff, items, partial, ca, cg, p.n_gb, irows, iquota); break;
+        case 3: launch_wg_tl_nb<3>(p.nb, grid, st, ra, rg, ia, ig, poff, items, partial, ca, cg, p.n_gb, irows, iquota); break;
+        default: launch_wg_tl_nb<4>(p.nb, grid, st, ra, rg, ia, ig, poff, items, partial, ca, cg, p.n_gb, irows, iquota); break;
+    }
+    OSN_LAUNCH_CHECK();
+    int g = int(cdiv(wtotal, 256));
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(wgrad_tl_reduce_kernel, dim3(g), dim3(256), 0, st, partial, range, K, cin, cout, 0, n_items, gW);
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}

@@ -36,16 +36,17 @@ class SparseConvFunction(Function):
         ctx.wp_dgrad = None
         ctx.tl_bwd = None
         mode = "bf16x6" if CONV_MODE == "tl" else CONV_MODE
-        if CONV_MODE == "tl" and ops.tl_eligible(K, cin, cout):
-            # K == 1 needs no lists; otherwise the map must be large enough to have them
-            fwd_ok = K == 1 or lists_fwd is not None
-            bwd_ok = ctx.needs_input_grad[0] and ops.tl_eligible(K, cout, cin) and (K == 1 or lists_bwd is not None)
+        if CONV_MODE == "tl" and K > 1 and ops.tl_eligible(K, cin, cout, ctx.n_in):
+            # only maps large enough to have tile lists (CoordinateManager.TL_MIN_ROWS); 1x1 convs stay on the
+            # first-generation kernel (measured equal or faster there)
+            fwd_ok = lists_fwd is not None
+            bwd_ok = ctx.needs_input_grad[0] and ops.tl_eligible(K, cout, cin, n_out) and lists_bwd is not None
             if fwd_ok or bwd_ok:
                 wf, wb = ops.weight_prep_tl(kernel, flip, want_fwd=fwd_ok, want_dgrad=bwd_ok)
                 if bwd_ok:
-                    ctx.wp_dgrad, ctx.tl_bwd = wb, (lists_bwd if K > 1 else "identity")
+                    ctx.wp_dgrad, ctx.tl_bwd = wb, lists_bwd
                 if fwd_ok:
-                    return ops.spconv_fwd_tl(feats, wf, lists_fwd if K > 1 else None, n_out, K, cout)
+                    return ops.spconv_fwd_tl(feats, wf, lists_fwd, n_out, K, cout)
         if mode == "bf16x6" and ops.x6_eligible(K, cin, cout, n_out):
             if ctx.needs_input_grad[0] and ctx.tl_bwd is None and ops.x6_eligible(K, cout, cin, ctx.n_in):
                 wp, ctx.wp_dgrad = ops.weight_prep_x6_pair(kernel, flip)     # both layouts, one launch
@@ -66,8 +67,7 @@ class SparseConvFunction(Function):
             tbl, rows, gm = (tiles_bwd[1], tiles_bwd[0], tiles_bwd[2]) if tiles_bwd is not None else (nbr_bwd, None, None)
             mode = "bf16x6" if CONV_MODE == "tl" else CONV_MODE
             if ctx.tl_bwd is not None:
-                tl = None if isinstance(ctx.tl_bwd, str) else ctx.tl_bwd
-                gin = ops.spconv_fwd_tl(gout, ctx.wp_dgrad, tl, ctx.n_in, K, cin)
+                gin = ops.spconv_fwd_tl(gout, ctx.wp_dgrad, ctx.tl_bwd, ctx.n_in, K, cin)
                 ctx.wp_dgrad = ctx.tl_bwd = None
             elif mode == "bf16x6" and ops.x6_eligible(K, cout, cin, ctx.n_in):
                 wp = ctx.wp_dgrad if ctx.wp_dgrad is not None else ops.weight_prep_x6(kernel, flip=flip, for_dgrad=True)

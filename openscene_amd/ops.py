@@ -300,10 +300,11 @@ class TileLists:
     """Per-tile compacted pair lists of one neighbour table (osn_tile_lists_build): `buf` holds
     cnt int32 [n_tiles, K] and lst int2 [n_tiles, K, bm]; `out_rows` is the row permutation of a
     tile-ordered table (None = table rows are tensor rows)."""
-    __slots__ = ("buf", "bm", "n_out", "K", "out_rows")
+    __slots__ = ("buf", "bm", "n_out", "K", "out_rows", "pairs")
 
     def __init__(self, buf, bm, n_out, K, out_rows):
         self.buf, self.bm, self.n_out, self.K, self.out_rows = buf, bm, n_out, K, out_rows
+        self.pairs = None                  # per-offset pair arrays for the weight gradient, built on first use
 
     @property
     def n_tiles(self):
@@ -330,7 +331,7 @@ def tile_lists(nbr, out_rows=None, bm=None):
     nbr = nbr.contiguous()
     K, n_out = nbr.shape
     bm = tile_rows(n_out) if bm is None else int(bm)
-    nbytes = int(lib.osn_tile_lists_bytes(n_out, K, bm))
+    nbytes = int(_cached("osn_tile_lists_bytes", n_out, K, bm))
     buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with _Dev(dev):
         check(lib.osn_tile_lists_build(_p(nbr), n_out, K, bm, _p(buf), _stream(dev)), "osn_tile_lists_build")
@@ -358,7 +359,7 @@ def weight_prep_tl(weight, flip=False, want_fwd=True, want_dgrad=True):
 
 def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
     """out[o] = sum_k feats[list rows] @ B[k] with B given as a weight_prep_tl image; tl None <=> K == 1 identity.
-    bn_partial: optional float64 [n_tiles, 2, cout] receiving per-tile column sums / sums of squares of out."""
+    bn_partial: optional float64 [n_tiles, 2, cout] receiving per-tile column sums / sums of squares."""
     dev = feats.device
     lib = _prep(dev)
     feats = _f32c(feats, "features")
@@ -375,11 +376,12 @@ def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
     if wp.numel() != need:
         raise ValueError("prepared weight has %d bytes, a [%d, %d, %d] conv needs %d" % (wp.numel(), K, cin, cout, need))
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    ws = _ws(256, dev)
     tok = _profiler.start("spconv_fwd_tl", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
         if _profiler is not None else None
     with _Dev(dev):
         check(lib.osn_spconv_fwd_tl(_p(feats), feats.shape[0], _p(wp), _p(buf), _p(rows), _p(out), _p(bn_partial), n_out,
-                                    K, cin, cout, bm, _stream(dev)), "osn_spconv_fwd_tl")
+                                    K, cin, cout, bm, _p(ws), ws.numel(), _stream(dev)), "osn_spconv_fwd_tl")
     if tok is not None:
         _profiler.stop(tok)
     return out

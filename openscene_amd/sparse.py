@@ -177,7 +177,8 @@ class CoordinateManager:
         return res
 
 
-    TL_MIN_ROWS = 4096        # below this the tile-list kernel's serial (offset, chunk) chain loses to the split launch
+    TL_MIN_ROWS = 65536       # measured (tools/micro_tl.py, S100k): the tile-list kernel wins 20-30 % on the 100 k-row maps,
+                              # ties at 48 k rows and loses below (few tiles, serial offset chain per tile)
 
     def kmap_lists(self, in_stride, out_stride, ksize, dilation=1):
         """Per-tile compacted pair lists (ops.TileLists) of the forward table and of the input-gradient

@@ -106,6 +106,7 @@ class TileLists:
 
     def __init__(self, cnt, lst, bm, n_out, K, out_rows):
         self.cnt, self.lst, self.bm, self.n_out, self.K, self.out_rows = cnt, lst, bm, n_out, K, out_rows
+        self.pairs = None
 
     @property
     def n_tiles(self):
@@ -119,13 +120,10 @@ class TileLists:
 
 
 def tile_rows(n_out):
-    """Spec of osn_tile_rows: whole rounds of 512 workgroups, at most 104 rows, at least 32, multiple of 4."""
-    if n_out <= 0:
-        return 32
-    rounds = -(-n_out // (512 * 104))
-    bm = -(-n_out // (512 * rounds))
-    bm = (bm + 3) // 4 * 4
-    return max(32, min(104, bm))
+    """Spec of osn_tile_rows: about two rounds of 512 workgroups, 32 .. 88 rows, a multiple of 8."""
+    bm = -(-max(int(n_out), 1) // 1024)
+    bm = (bm + 7) // 8 * 8
+    return max(32, min(88, bm))
 
 
 def tile_lists(nbr, out_rows=None, bm=None):
@@ -158,33 +156,32 @@ def weight_prep_tl(weight, flip=False, want_fwd=True, want_dgrad=True):
 def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
     """Evaluated FROM THE LISTS (not from the table), so host-logic tests exercise the list semantics."""
     w = wp[1]
-    out = feats.new_zeros((n_out, cout))
     if tl is None:
         res = feats @ w[0]
+        bm = tile_rows(n_out)
+        table_rows = res
     else:
-        cnt, lst = tl.counts().numpy(), tl.lists().numpy()
+        cnt, lst, bm = tl.counts().numpy(), tl.lists().numpy(), tl.bm
         tab = feats.new_zeros((n_out, cout))
         for ti in range(tl.n_tiles):
             for k in range(K):
                 c = int(cnt[ti, k])
                 if c:
                     rows_in = torch.from_numpy(lst[ti, k, :c, 0].astype(np.int64))
-                    rows_out = torch.from_numpy(lst[ti, k, :c, 1].astype(np.int64)) + ti * tl.bm
+                    rows_out = torch.from_numpy(lst[ti, k, :c, 1].astype(np.int64)) + ti * bm
                     tab[rows_out] += feats[rows_in] @ w[k]
+        table_rows = tab
         if tl.out_rows is not None:
             res = torch.zeros_like(tab)
             res[tl.out_rows.long()] = tab
         else:
             res = tab
-    out = res
     if bn_partial is not None:
-        bm = tl.bm if tl is not None else tile_rows(n_out)
-        table_rows = out if (tl is None or tl.out_rows is None) else out[tl.out_rows.long()]
         for ti in range(-(-n_out // bm)):
             blk = table_rows[ti * bm:(ti + 1) * bm].double()
             bn_partial[ti, 0] = blk.sum(0)
             bn_partial[ti, 1] = (blk * blk).sum(0)
-    return out
+    return res
 
 
 def x6_eligible(K, cin, cout, n_out):
