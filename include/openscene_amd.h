@@ -186,6 +186,25 @@ int osn_spconv_wgrad(const float* in, const float* gout, const int32_t* nbr, con
                      const int32_t* plan_items, float* gW, int64_t n_out, int K, int cin, int cout,
                      void* ws, size_t ws_bytes, osn_stream_t stream);
 
+/* Second-generation weight gradient: the pairs of every offset compacted ONCE per map into arrays
+ * (input row, output row) in tile order -- [ME]'s kernel-map in/out index lists -- shared by every
+ * convolution and every step of the map's life; split-bf16 arithmetic on the bf16 MFMA with LDS transpose
+ * reads (fp32-class accuracy, bitwise reproducible: work items are a pure function of the map, partial sums
+ * are reduced in item order).
+ *   osn_pair_lists_build(tl, ..)    pl = per-offset pair arrays + device-planned work items, from the tile
+ *                                   lists `tl` of a table with n_out rows (bm as given to osn_tile_lists_build;
+ *                                   out_rows = the table's row permutation or null); osn_pair_lists_bytes
+ *   osn_spconv_wgrad_tl(..)         gW[k] = sum over the pairs of offset k of in[i]^T (x) gout[o]  ([K, cin, cout]).
+ *                                   swap = 1: the arrays belong to the strided convolution this TRANSPOSED
+ *                                   convolution mirrors (in rows are indexed by the arrays' output rows).
+ *                                   pl = null <=> K == 1 identity map.  Needs cin % 4 == 0 and cout % 4 == 0.   */
+size_t osn_pair_lists_bytes(int64_t n_out, int K, int bm);
+int osn_pair_lists_build(const void* tl, const int32_t* out_rows, int64_t n_out, int K, int bm, void* pl,
+                         osn_stream_t stream);
+size_t osn_spconv_wgrad_tl_ws_bytes(int K, int cin, int cout);
+int osn_spconv_wgrad_tl(const float* in, const float* gout, const void* pl, int swap, float* gW, int64_t n_in,
+                        int64_t n_out, int K, int cin, int cout, void* ws, size_t ws_bytes, osn_stream_t stream);
+
 /* ---- batch norm (+ReLU, +residual) -------------------------------------- *
  * Replaces [ME] MinkowskiBatchNorm (= torch.nn.BatchNorm1d on .F), MinkowskiReLU
  * and the BasicBlock residual add (models/mink_unet.py:50-114, resnet_base.py:98).

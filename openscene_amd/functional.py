@@ -10,14 +10,15 @@ from torch.autograd import Function
 from . import ops
 
 # Kernels / arithmetic of the forward and input-gradient convolutions:
-#   "tl"     (default) second-generation kernel: per-tile compacted pair lists, weights in registers, output
-#            tile in LDS, split-bf16 arithmetic (spconv_tl.hip); maps too small for it (and the 3-channel
-#            stem) take the "bf16x6" path
+#   "tl"     (default) second-generation kernels: forward / input gradient from per-tile compacted pair lists
+#            (weights in registers, output tile in LDS, spconv_tl.hip) on the large maps, weight gradient from
+#            per-offset pair arrays on the bf16 MFMA (wgrad_tl.hip) on every map; smaller maps, 1x1 convs and
+#            the 3-channel stem take the "bf16x6" forward and the fp32-MFMA weight gradient
 #   "bf16x6" output-stationary kernel over the dense neighbour table, three-way bf16 split of both operands,
 #            six bf16 MFMAs per product block, fp32 accumulate: fp32-level accuracy
 #   "fp32"   the same kernel on v_mfma_f32_32x32x2_f32 (exact fp32 products, 157 TF peak)
-# The weight gradient runs on the fp32 MFMA.
 CONV_MODE = os.environ.get("OSN_CONV_MODE", "tl")
+TL_FWD_MIN_ROWS = int(os.environ.get("OSN_TL_FWD_MIN_ROWS", "65536"))
 
 
 class SparseConvFunction(Function):
@@ -26,8 +27,11 @@ class SparseConvFunction(Function):
 
     @staticmethod
     def forward(ctx, feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tiles_fwd=None, tiles_bwd=None, counts=None,
-                lists_fwd=None, lists_bwd=None):
+                lists_fwd=None, lists_bwd=None, transposed=False):
         ctx.save_for_backward(feats, kernel)
+        # weight gradient: the pair arrays of the map (a transposed conv runs on the arrays of the strided conv it
+        # mirrors = its own input-gradient lists, with the operand roles swapped)
+        ctx.wg_lists = (lists_bwd, True) if transposed else (lists_fwd, False)
         ctx.maps = (nbr_fwd, nbr_bwd, bool(flip), tiles_bwd, counts)
         ctx.n_in = feats.shape[0]
         K = 1 if kernel.dim() == 2 else kernel.shape[0]
@@ -37,10 +41,11 @@ class SparseConvFunction(Function):
         ctx.tl_bwd = None
         mode = "bf16x6" if CONV_MODE == "tl" else CONV_MODE
         if CONV_MODE == "tl" and K > 1 and ops.tl_eligible(K, cin, cout, ctx.n_in):
-            # only maps large enough to have tile lists (CoordinateManager.TL_MIN_ROWS); 1x1 convs stay on the
-            # first-generation kernel (measured equal or faster there)
-            fwd_ok = lists_fwd is not None
-            bwd_ok = ctx.needs_input_grad[0] and ops.tl_eligible(K, cout, cin, n_out) and lists_bwd is not None
+            # forward / input gradient: only on maps of at least TL_FWD_MIN_ROWS rows (measured: 20-30 % faster on the
+            # 100 k-row maps, a tie at 48 k rows, slower below); 1x1 convs stay on the first-generation kernel
+            fwd_ok = lists_fwd is not None and n_out >= TL_FWD_MIN_ROWS
+            bwd_ok = (ctx.needs_input_grad[0] and ops.tl_eligible(K, cout, cin, n_out) and lists_bwd is not None
+                      and ctx.n_in >= TL_FWD_MIN_ROWS)
             if fwd_ok or bwd_ok:
                 wf, wb = ops.weight_prep_tl(kernel, flip, want_fwd=fwd_ok, want_dgrad=bwd_ok)
                 if bwd_ok:
@@ -76,8 +81,13 @@ class SparseConvFunction(Function):
             else:
                 gin = ops.spconv_fwd(gout, ops.weight_transpose(kernel, flip), tbl, ctx.n_in, out_rows=rows, gmask=gm)
         if ctx.needs_input_grad[1]:
-            gk = ops.spconv_wgrad(feats, gout, nbr_fwd, K, counts).reshape(kernel.shape)
-        return gin, gk, None, None, None, None, None, None, None, None, None
+            cin, cout = kernel.shape[-2], kernel.shape[-1]
+            tl, swap = ctx.wg_lists
+            if CONV_MODE == "tl" and K > 1 and tl is not None and ops.tl_eligible(K, cin, cout, ctx.n_in):
+                gk = ops.spconv_wgrad_tl(feats, gout, tl, K, swap=swap).reshape(kernel.shape)
+            else:
+                gk = ops.spconv_wgrad(feats, gout, nbr_fwd, K, counts).reshape(kernel.shape)
+        return gin, gk, None, None, None, None, None, None, None, None, None, None
 
 
 class BatchNormActFunction(Function):
@@ -106,13 +116,13 @@ class BatchNormActFunction(Function):
         return gx, ggamma, gbeta, None, None, gres, None, None, None, None
 
 
-def sparse_conv(feats, kernel, maps, n_out, tiles=None, counts=None, lists=None):
+def sparse_conv(feats, kernel, maps, n_out, tiles=None, counts=None, lists=None, transposed=False):
     """maps = CoordinateManager.kmap(...); tiles = .kmap_tiles(...) or None; counts = .kmap_counts(...) or None;
-    lists = .kmap_lists(...) or None."""
+    lists = .kmap_lists(...) or None; transposed: the conv is a MinkowskiConvolutionTranspose."""
     nbr_fwd, nbr_bwd, flip = maps
     tf, tb = tiles if tiles is not None else (None, None)
     lf, lb = lists if lists is not None else (None, None)
-    return SparseConvFunction.apply(feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tf, tb, counts, lf, lb)
+    return SparseConvFunction.apply(feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tf, tb, counts, lf, lb, bool(transposed))
 
 
 _tls = threading.local()

@@ -387,6 +387,63 @@ def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
     return out
 
 
+def pair_lists(tl):
+    """Per-offset pair arrays + weight-gradient work items of a TileLists (built once, cached on it)."""
+    if tl.pairs is None:
+        dev = tl.buf.device
+        lib = _prep(dev)
+        nbytes = int(_cached("osn_pair_lists_bytes", tl.n_out, tl.K, tl.bm))
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with _Dev(dev):
+            check(lib.osn_pair_lists_build(_p(tl.buf), _p(tl.out_rows), tl.n_out, tl.K, tl.bm, _p(buf), _stream(dev)),
+                  "osn_pair_lists_build")
+        tl.pairs = buf
+    return tl.pairs
+
+
+def pair_arrays(tl):
+    """(poff int32 [K+1], pin int32 [P], pout int32 [P]) host-readable views of pair_lists(tl) (tests / tools)."""
+    buf = pair_lists(tl)
+    poff = buf[:(tl.K + 1) * 4].view(torch.int32)
+    cap = tl.K * max(tl.n_out, 1)
+    P = int(poff[tl.K])
+    pin = buf[16384:16384 + cap * 4].view(torch.int32)[:P]
+    pout = buf[16384 + cap * 4:16384 + 2 * cap * 4].view(torch.int32)[:P]
+    return poff, pin, pout
+
+
+def spconv_wgrad_tl(feats, gout, tl, K, swap=False):
+    """gW [K, cin, cout] from the pair arrays of `tl` (None <=> K == 1 identity).  swap: `tl` belongs to the strided
+    convolution that this transposed convolution mirrors."""
+    dev = feats.device
+    lib = _prep(dev)
+    feats = _f32c(feats, "features")
+    gout = _f32c(gout, "grad_output")
+    n_in, cin = feats.shape
+    n_out, cout = gout.shape
+    if tl is not None:
+        table_rows = n_in if swap else n_out
+        if tl.K != K or tl.n_out != table_rows:
+            raise ValueError("pair lists are for a [%d, %d] table, the weight gradient wants [%d, %d]" % (
+                tl.K, tl.n_out, K, table_rows))
+        pl = pair_lists(tl)
+    else:
+        if K != 1 or n_in != n_out:
+            raise ValueError("tl=None is the identity map and needs K == 1 and n_in == n_out")
+        pl = None
+    gw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
+    wsb = _cached("osn_spconv_wgrad_tl_ws_bytes", K, cin, cout)
+    ws = _ws(wsb, dev)
+    tok = _profiler.start("spconv_wgrad_tl", dev, n_in=n_in, n_out=n_out, K=K, cin=cin, cout=cout) \
+        if _profiler is not None else None
+    with _Dev(dev):
+        check(lib.osn_spconv_wgrad_tl(_p(feats), _p(gout), _p(pl), int(bool(swap)), _p(gw), n_in, n_out, K, cin, cout,
+                                      _p(ws), ws.numel(), _stream(dev)), "osn_spconv_wgrad_tl")
+    if tok is not None:
+        _profiler.stop(tok)
+    return gw
+
+
 def x6_eligible(K, cin, cout, n_out):
     """The split-bf16 kernel handles every conv of the U-Net except the 3-channel stem."""
     if cin % 4 or cin < 8:

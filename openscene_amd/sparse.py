@@ -177,13 +177,12 @@ class CoordinateManager:
         return res
 
 
-    TL_MIN_ROWS = 65536       # measured (tools/micro_tl.py, S100k): the tile-list kernel wins 20-30 % on the 100 k-row maps,
-                              # ties at 48 k rows and loses below (few tiles, serial offset chain per tile)
 
     def kmap_lists(self, in_stride, out_stride, ksize, dilation=1):
         """Per-tile compacted pair lists (ops.TileLists) of the forward table and of the input-gradient
         table of a map: (tl_fwd or None, tl_bwd or None).  Built from the tile-ordered tables where those
-        exist, so a tile's rows share their offsets; None for K == 1 and for maps below TL_MIN_ROWS rows."""
+        exist, so a tile's rows share their offsets; None for K == 1.  (The weight gradient uses them on every map;
+        the forward / input gradient only on large maps -- functional.TL_FWD_MIN_ROWS.)"""
         key = ("lists", in_stride, out_stride, ksize, dilation)
         hit = self._kmaps.get(key)
         if hit is not None:
@@ -196,7 +195,7 @@ class CoordinateManager:
         tf, tb = self.kmap_tiles(in_stride, out_stride, ksize, dilation)
 
         def lists(tbl, tiles):
-            if tbl is None or tbl.shape[0] > 128 or tbl.shape[1] < self.TL_MIN_ROWS:
+            if tbl is None or tbl.shape[0] > 128 or tbl.shape[1] == 0:
                 return None
             if tiles is not None:
                 return ops.tile_lists(tiles[1], out_rows=tiles[0])

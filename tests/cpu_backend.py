@@ -184,6 +184,44 @@ def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
     return res
 
 
+def pair_arrays(tl_or_table, out_rows=None):
+    """Spec of osn_pair_lists_build: per offset k, the (input row, output TENSOR row) of every valid table entry in
+    table-row order, offsets concatenated; poff[k] = first pair of offset k."""
+    if isinstance(tl_or_table, TileLists):
+        tl = tl_or_table
+        cnt, lst = tl.counts().numpy(), tl.lists().numpy()
+        pin, pout, poff = [], [], [0]
+        for k in range(tl.K):
+            for ti in range(tl.n_tiles):
+                c = int(cnt[ti, k])
+                rows = lst[ti, k, :c, 1].astype(np.int64) + ti * tl.bm
+                pin.append(lst[ti, k, :c, 0])
+                pout.append(_np(tl.out_rows)[rows] if tl.out_rows is not None else rows)
+            poff.append(poff[-1] + int(cnt[:, k].sum()))
+        return (torch.tensor(poff, dtype=torch.int32), torch.from_numpy(np.concatenate(pin).astype(np.int32)),
+                torch.from_numpy(np.concatenate(pout).astype(np.int32)))
+    raise TypeError("pass a TileLists")
+
+
+def pair_lists(tl):
+    return tl
+
+
+def spconv_wgrad_tl(feats, gout, tl, K, swap=False):
+    cin, cout = feats.shape[1], gout.shape[1]
+    gw = feats.new_zeros((K, cin, cout))
+    if tl is None:
+        gw[0] = feats.t() @ gout
+        return gw
+    poff, pin, pout = pair_arrays(tl)
+    for k in range(K):
+        a, b = int(poff[k]), int(poff[k + 1])
+        if b > a:
+            i, o = pin[a:b].long(), pout[a:b].long()
+            gw[k] = (feats[o].t() @ gout[i]) if swap else (feats[i].t() @ gout[o])
+    return gw
+
+
 def x6_eligible(K, cin, cout, n_out):
     return cin % 4 == 0 and cin >= 8
 
@@ -286,7 +324,7 @@ def weight_prep_x6_pair(weight, flip=False):
     return weight_prep_x6(weight), weight_prep_x6(weight, flip=flip, for_dgrad=True)
 
 
-_NAMES = ["TileLists", "tile_rows", "tile_lists", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
+_NAMES = ["TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
           "spconv_wgrad", "bn_stats", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
           "fnv_hash", "feature_remap", "batch_coords"]
 

@@ -206,6 +206,63 @@ def test_tile_list_kernel_rows_partials_and_determinism():
     assert (gi - gi_ref).abs().max().item() <= 2e-6 * gi_ref.abs().max().item()
 
 
+WG_CASES = [("big", (1, 1, 3), 96, 96), ("big", (1, 1, 3), 128, 96), ("big", (1, 1, 3), 32, 64), ("mid", (1, 1, 3), 192, 128),
+            ("small", (1, 1, 3), 256, 256), ("big", (1, 2, 2), 32, 32), ("big", (2, 1, 2), 96, 96), ("big", (1, 1, 1), 96, 768),
+            ("mid", (1, 1, 3), 64, 20)]
+
+
+@pytest.mark.parametrize("kind,key,cin,cout", WG_CASES)
+def test_wgrad_tile_list_kernel_vs_oracle(kind, key, cin, cout):
+    """Second-generation weight gradient (pair arrays, split-bf16 MFMA with LDS transpose reads) vs the float64
+    oracle: max |delta| <= 3e-5 max |ref| (same bound as the fp32-MFMA kernel); pair arrays bit-exact vs their
+    specification; bitwise reproducible.  Transposed convs run on the strided conv's arrays with swapped roles."""
+    from openscene_amd import ops
+    cm = cloud(kind)
+    si, so_, k = key
+    K = k ** 3
+    n_in, n_out = cm.level(si).shape[0], cm.level(so_).shape[0]
+    g = torch.Generator().manual_seed(cin + 7 * cout + K)
+    feats = torch.randn(n_in, cin, generator=g)
+    gout = torch.randn(n_out, cout, generator=g)
+    d = dev()
+    if K == 1:
+        ref = feats.double().t() @ gout.double()
+        got = ops.spconv_wgrad_tl(feats.to(d), gout.to(d), None, 1)
+        close(got[0], ref, "weight gradient (identity)")
+        return
+    nbr_np = cm.kmap(si, so_, k)
+    ref = torch.zeros(K, cin, cout, dtype=torch.float64)
+    for kk in range(K):
+        o = np.nonzero(nbr_np[kk] >= 0)[0]
+        ref[kk] = feats.double()[nbr_np[kk, o]].t() @ gout.double()[o]
+    swap = so_ < si
+    if swap:      # transposed conv: lists of the strided conv it mirrors (table rows = coarse rows = this conv's INPUT rows)
+        table = torch.from_numpy(cm.kmap(so_, si, k)).to(d)
+    else:
+        table = torch.from_numpy(nbr_np).to(d)
+    for sort in (False, True):
+        if sort and table.shape[1] < 64:
+            continue
+        if sort:
+            order, tbl, _ = ops.kmap_sort(table, ops.kmap_count(table))
+            tl = ops.tile_lists(tbl, out_rows=order)
+        else:
+            tl = ops.tile_lists(table)
+        poff, pin, pout = ops.pair_arrays(tl)
+        spec = cpu_backend.pair_arrays(cpu_backend.tile_lists(tl_table_cpu(table, tl), out_rows=tl.out_rows.cpu() if tl.out_rows is not None else None, bm=tl.bm))
+        assert torch.equal(poff.cpu(), spec[0]) and torch.equal(pin.cpu(), spec[1]) and torch.equal(pout.cpu(), spec[2])
+        got = ops.spconv_wgrad_tl(feats.to(d), gout.to(d), tl, K, swap=swap)
+        again = ops.spconv_wgrad_tl(feats.to(d), gout.to(d), tl, K, swap=swap)
+        assert torch.equal(got, again), "weight gradient is not bitwise reproducible"
+        close(got, ref, "weight gradient (sorted=%s)" % sort)
+
+
+def tl_table_cpu(table, tl):
+    """The table the lists were built from (tile-ordered if the lists carry a permutation)."""
+    t = table.cpu()
+    return t[:, tl.out_rows.cpu().long()] if tl.out_rows is not None else t
+
+
 def test_cached_work_items_of_a_strided_conv_and_its_transpose():
     """A transposed conv shares the pair counts of the strided conv it mirrors but has another row count:
     the cached weight-gradient work items must not be shared between the two."""

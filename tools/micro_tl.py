@@ -69,5 +69,53 @@ def main():
         print(json.dumps(row), flush=True)
 
 
+
+
+def wgrad_main():
+    """MODE=wgrad: fp32-MFMA weight gradient vs the pair-array / split-bf16 kernel."""
+    reps = int(os.environ.get("REPS", "5"))
+    dev = torch.device("cuda", 0)
+    vox = syn.shuffled(syn.grid_voxels(syn.room_points(0), 0.02), 0)
+    cm = CoordinateManager(torch.from_numpy(syn.batch_coords([vox])).to(dev))
+    shapes = [(1, 1, 3, 96, 96), (1, 1, 3, 128, 96), (2, 2, 3, 96, 96), (2, 2, 3, 128, 96), (2, 2, 3, 32, 32),
+              (4, 4, 3, 64, 64), (4, 4, 3, 128, 128), (8, 8, 3, 256, 256), (16, 16, 3, 256, 256), (1, 1, 1, 96, 768),
+              (1, 2, 2, 32, 32), (2, 1, 2, 96, 96)]
+    for si, so, ks, cin, cout in shapes:
+        K = ks ** 3
+        n_in, n_out = cm.size(si), cm.size(so)
+        x = torch.randn(n_in, cin, device=dev)
+        g = torch.randn(n_out, cout, device=dev)
+        row = {"shape": "s%d->s%d k%d %d->%d" % (si, so, ks, cin, cout), "n_out": n_out}
+        if K > 1:
+            nbr = cm.kmap(si, so, ks)[0]
+            cnt = cm.kmap_counts(si, so, ks)
+            swap = so < si
+            if swap:
+                tiles = cm.kmap_tiles(so, si, ks)[0]
+                base = cm.kmap(so, si, ks)[0]
+            else:
+                tiles = cm.kmap_tiles(si, so, ks)[0]
+                base = nbr
+            tl = ops.tile_lists(tiles[1], out_rows=tiles[0]) if tiles is not None else ops.tile_lists(base)
+            row["pairs_build_us"] = timed(lambda: (setattr(tl, "pairs", None), ops.pair_lists(tl)), reps)
+            pairs = int(cnt.sum())
+            t_old = timed(lambda: ops.spconv_wgrad(x, g, nbr, K, cnt), reps)
+            a = ops.spconv_wgrad(x, g, nbr, K, cnt)
+        else:
+            tl, swap, pairs = None, False, n_out
+            t_old = timed(lambda: ops.spconv_wgrad(x, g, None, 1), reps)
+            a = ops.spconv_wgrad(x, g, None, 1)
+        t_new = timed(lambda: ops.spconv_wgrad_tl(x, g, tl, K, swap=swap), reps)
+        b = ops.spconv_wgrad_tl(x, g, tl, K, swap=swap)
+        fl = 2.0 * pairs * cin * cout
+        row.update({"pairs": pairs, "old_us": t_old, "tl_us": t_new, "tl_TF": fl / t_new / 1e6, "old_TF": fl / t_old / 1e6,
+                    "max_rel_diff": (a - b).abs().max().item() / a.abs().max().item()})
+        print(json.dumps(row), flush=True)
+
+
+if os.environ.get("MODE") == "wgrad":
+    main = wgrad_main
+
+
 if __name__ == "__main__":
     main()
