@@ -60,6 +60,16 @@ class LaunchProfiler:
                 pipe = m["cin"] > 4 and m["cin"] % 4 == 0 and m["cout"] % 4 == 0 and -(-m["K"] // S) <= 32
                 n = ("spconv_fwd_pipe_kernel<%d,%d,%d>" % (wm, wn, tn) if pipe else
                      "spconv_fwd_kernel<%d,%d,%d,%d>" % (wm, wn, tn, bk)) + ("+reduce" if S > 1 else "")
+            elif kind == "spconv_fwd_tl":
+                best, pad_best = 1, 1 << 30
+                for nw in (4, 3, 2, 1):                       # osn::tl_waves: least padding, wider on ties
+                    pd = -(-m["cout"] // (32 * nw)) * 32 * nw - m["cout"]
+                    if pd < pad_best:
+                        best, pad_best = nw, pd
+                n = "spconv_tl_kernel<%d>" % best
+            elif kind == "spconv_wgrad_tl":
+                blk = lambda c: min((c + 31) // 32, 4)
+                n = "wgrad_tl_kernel<%d,%d>" % (blk(m["cin"]), blk(m["cout"]))
             else:
                 pad = lambda c: min((c + 31) // 32 * 32, 128)
                 tiles = (pad(m["cin"]) // 32) * (pad(m["cout"]) // 32)
@@ -240,6 +250,8 @@ def main():
                     "MinkowskiEngine does; measured 4 %% SLOWER on S100k (DESIGN.md section 4), off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--train-only", action="store_true", help="skip the query / inference / voxeliser / loader phases "
+                    "(for rocprofv3 runs: every traced kernel then belongs to the training steps)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -369,7 +381,7 @@ def main():
     qres = None
     vox_res = None
     extra = None
-    if rank == 0:
+    if rank == 0 and not args.train_only:
         model.eval()
         with torch.no_grad():
             pred = model(SparseTensor(feats, coords0))
@@ -491,7 +503,7 @@ def main():
             except Exception:
                 pmc = None
         tflops = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
-        mfma_peak = X6_PEAK_TFLOPS if "x6" in name else FP32_PEAK_TFLOPS
+        mfma_peak = X6_PEAK_TFLOPS if ("x6" in name or "_tl_" in name) else FP32_PEAK_TFLOPS
         # which roof binds this kernel: the one whose time-at-peak is larger (arithmetic intensity vs ridge)
         t_hbm = gk["bytes"] / (HBM_PEAK_GBS * 1e9)
         t_mfma = gk["flops"] / (mfma_peak * 1e12)
@@ -501,8 +513,8 @@ def main():
                   "flop_per_byte": gk["flops"] / gk["bytes"], "ridge_flop_per_byte": mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9),
                   "hbm_GBps": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
                   "mfma_TFLOPs": tflops, "mfma_peak_TFLOPs": mfma_peak, "mfma_frac": tflops / mfma_peak,
-                  "mfma_peak_note": ("dense bf16 peak / 6 (six bf16 MFMAs per fp32-equivalent product)" if "x6" in name
-                                     else "fp32 MFMA peak"),
+                  "mfma_peak_note": ("dense bf16 peak / 6 (six bf16 MFMAs per fp32-equivalent product)"
+                                     if ("x6" in name or "_tl_" in name) else "fp32 MFMA peak"),
                   "step_hbm_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   "step_fp32_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
         if t_mfma >= t_hbm:

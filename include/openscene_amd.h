@@ -145,7 +145,9 @@ int osn_spconv_fwd_x6(const float* in, const void* Wp, const int32_t* nbr, const
  *                                   row j; tl = null <=> K == 1 identity map.  bn_partial (nullable):
  *                                   double [n_tiles][2][cout] per-tile column sums / sums of squares of
  *                                   `out` (the following batch norm's statistics without a pass over out).
- *                                   ws: osn_spconv_fwd_tl_ws_bytes() bytes (tile counters, zeroed by the call).
+ *                                   ws: osn_spconv_fwd_tl_ws_bytes(..) bytes: tile counters (zeroed by the call) and, on
+ *                                   small tables, the partial tiles of a launch that splits each tile's offsets over
+ *                                   several workgroups (summed in a fixed order; bn_partial must be null there).
  *                                   Needs cin % 4 == 0, cout % 4 == 0 and n_in <= 2^24 (OSN_E_RANGE otherwise).  */
 int osn_tile_rows(int64_t n_out);
 size_t osn_tile_lists_bytes(int64_t n_out, int K, int bm);
@@ -153,7 +155,7 @@ int osn_tile_lists_build(const int32_t* nbr, int64_t n_out, int K, int bm, void*
 size_t osn_weight_prep_tl_bytes(int K, int cin, int cout, int for_dgrad);
 int osn_weight_prep_tl(const float* W, int K, int cin, int cout, int flip, void* Wp_fwd, void* Wp_dgrad,
                        osn_stream_t stream);
-size_t osn_spconv_fwd_tl_ws_bytes(void);
+size_t osn_spconv_fwd_tl_ws_bytes(int64_t n_out, int K, int cout, int bm);
 int osn_spconv_fwd_tl(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
                       float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm,
                       void* ws, size_t ws_bytes, osn_stream_t stream);
@@ -204,6 +206,16 @@ int osn_pair_lists_build(const void* tl, const int32_t* out_rows, int64_t n_out,
 size_t osn_spconv_wgrad_tl_ws_bytes(int K, int cin, int cout);
 int osn_spconv_wgrad_tl(const float* in, const float* gout, const void* pl, int swap, float* gW, int64_t n_in,
                         int64_t n_out, int K, int cin, int cout, void* ws, size_t ws_bytes, osn_stream_t stream);
+
+/* The 3-channel stem convolution (conv0p1s1: 5^3 kernel, 3 -> 32, models/mink_unet.py:47-50) and its weight
+ * gradient: same contracts as osn_spconv_fwd / osn_spconv_wgrad on the plain (unordered) table, exact fp32
+ * FMA chains in ascending offset order, for cin <= 4 and cout == 32 (there is no contraction worth a matrix
+ * unit; the op streams the 125 x n_out table once).                                                          */
+int osn_stem_conv_fwd(const float* in, const float* W, const int32_t* nbr, float* out, int64_t n_out, int K,
+                      int cin, int cout, osn_stream_t stream);
+size_t osn_stem_conv_wgrad_ws_bytes(int K, int cin);
+int osn_stem_conv_wgrad(const float* in, const float* gout, const int32_t* nbr, float* gW, int64_t n_out, int K,
+                        int cin, int cout, void* ws, size_t ws_bytes, osn_stream_t stream);
 
 /* ---- batch norm (+ReLU, +residual) -------------------------------------- *
  * Replaces [ME] MinkowskiBatchNorm (= torch.nn.BatchNorm1d on .F), MinkowskiReLU

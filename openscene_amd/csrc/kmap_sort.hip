@@ -65,6 +65,11 @@ __global__ void kmap_group_mask_kernel(const int32_t* __restrict__ nbr_sorted, i
     if ((threadIdx.x & 31) == 0 && j < n_out) gmask[j >> 5] = m;
 }
 
+// rocPRIM picks a merge sort (1 block sort + ~8 merge launches) below 1 M items; the tables sorted here have 1e4-1e6
+// rows and 8..27 significant key bits, where the onesweep radix path needs fewer launches (a histogram + one launch
+// per 8-bit digit) -- the sort is launch-bound at these sizes (profiles/r02_s4: 98 merge launches per scene).
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
+
 struct SortWs {
     uint32_t *mask, *mask_sorted;
     int32_t* iota;
@@ -74,7 +79,7 @@ struct SortWs {
 
 static hipError_t sort32_tmp_bytes(int64_t n, size_t* out) {
     size_t b = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr,
+    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr,
                                              (int32_t*)nullptr, size_t(n > 0 ? n : 1), 0u, 32u, (hipStream_t)0);
     *out = b;
     return e;
@@ -121,7 +126,7 @@ extern "C" int osn_kmap_sort(const int32_t* nbr, int64_t n_out, int K, const int
                        reinterpret_cast<const long long*>(counts), w.mask, w.iota);
     OSN_LAUNCH_CHECK();
     size_t t2 = w.tmp_bytes;
-    OSN_HIP(rocprim::radix_sort_pairs(w.tmp, t2, w.mask, w.mask_sorted, w.iota, order, size_t(n_out), 0u, unsigned(K), st));
+    OSN_HIP(rocprim::radix_sort_pairs<SortConfig>(w.tmp, t2, w.mask, w.mask_sorted, w.iota, order, size_t(n_out), 0u, unsigned(K), st));
     hipLaunchKernelGGL(kmap_permute_kernel, dim3(cdiv(n_out, T), K), dim3(T), 0, st, nbr, order, n_out, nbr_sorted);
     if (gmask)
         hipLaunchKernelGGL(kmap_group_mask_kernel, dim3(cdiv(n_out, T)), dim3(T), 0, st, nbr_sorted, n_out, K, gmask);

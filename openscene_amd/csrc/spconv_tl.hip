@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                                                                const int32_t* __restrict__ cnt, const int2* __restrict__ lst,
                                                                const int32_t* __restrict__ out_rows, float* __restrict__ out,
                                                                double* __restrict__ bn_partial, int32_t* __restrict__ counter,
-                                                               int n_out, int K, int cin, int cout, int bm, int n_tiles, int ns,
-                                                               int ncb, long long* __restrict__ prof) {
+                                                               float* __restrict__ partial, int nz, int n_out, int K, int cin,
+                                                               int cout, int bm, int n_tiles, int ns, int ncb,
+                                                               long long* __restrict__ prof) {
     constexpr int NT = 256;
     constexpr int CW = 32 * NW;               // output columns of the workgroup
     constexpr int S = CW + 4;                 // fp32 row stride of the output tile
@@ -199,9 +200,13 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
         // ---- draw the next tile (densest first: a tile-ordered table has the rows with most neighbours last)
         if (tid == 0) tile_s = atomicAdd(&counter[blockIdx.y], 1);
         __syncthreads();
+        // A unit of work = (tile, part z of nz): small tables cut the tile's active offsets into nz contiguous
+        // parts handled by different workgroups (a tile's offsets are a serial chain: weights, then its steps);
+        // part z writes its own partial tile, summed in part order by reduce_partial_rows_kernel.
         const int draw = __builtin_amdgcn_readfirstlane(tile_s);
-        if (draw >= n_tiles) break;
-        const int tile = n_tiles - 1 - draw;
+        if (draw >= n_tiles * nz) break;
+        const int tile = n_tiles - 1 - draw / nz;
+        const int zpart = draw - (draw / nz) * nz;
         const int row0 = tile * bm;
         const int rows = min(bm, n_out - row0);
 
@@ -231,10 +236,11 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
             nact_s = 1;
         }
         __syncthreads();
-        const int nact = __builtin_amdgcn_readfirstlane(nact_s);
+        const int nact_all = __builtin_amdgcn_readfirstlane(nact_s);
+        const int nact = nact_all * (zpart + 1) / nz;      // this part: active offsets [nact_all z / nz, nact_all (z + 1) / nz)
         TL_TICK(0)                                         // 0: tile draw, zeroing, active offsets
 
-        int a0 = 0;
+        int a0 = nact_all * zpart / nz;
         while (a0 < nact) {
             // ---- batch [a0, a1): as many consecutive offsets as fit the LDS list buffer
             if (tid == 0) {
@@ -457,8 +463,13 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
             const int j = idx / V, c4 = idx - j * V;
             const int col = col0 + 4 * c4;
             if (col < cout) {
-                const int64_t orow = out_rows ? out_rows[row0 + j] : row0 + j;
-                *reinterpret_cast<float4*>(out + orow * cout + col) = *reinterpret_cast<const float4*>(&otile[j * S + 4 * c4]);
+                const float4 v = *reinterpret_cast<const float4*>(&otile[j * S + 4 * c4]);
+                if (nz > 1) {                              // partial tile of part z, table row order
+                    *reinterpret_cast<float4*>(partial + (int64_t(zpart) * n_out + row0 + j) * cout + col) = v;
+                } else {
+                    const int64_t orow = out_rows ? out_rows[row0 + j] : row0 + j;
+                    *reinterpret_cast<float4*>(out + orow * cout + col) = v;
+                }
             }
         }
         if (bn_partial) {
@@ -544,7 +555,42 @@ extern "C" int osn_weight_prep_tl(const float* W, int K, int cin, int cout, int 
     return OSN_OK;
 }
 
-extern "C" size_t osn_spconv_fwd_tl_ws_bytes(void) { return 256; }      // the tile counters (one per column group)
+// small tables: parts per tile such that a launch has ~1024 units of work (at most 16, at most K)
+static int tl_split(int64_t n_out, int K, int cout, int bm) {
+    if (K <= 1 || n_out <= 0) return 1;
+    const int64_t units = cdiv(n_out, bm) * cdiv(cout, 32 * tl_waves(cout));
+    int64_t nz = 1024 / (units > 0 ? units : 1);
+    if (nz > 16) nz = 16;
+    if (nz > K) nz = K;
+    if (nz < 1) nz = 1;
+    return int(nz);
+}
+
+// tile counters (one per column group; MUST be zero on entry, left dirty) + the partial tiles of a split launch
+extern "C" size_t osn_spconv_fwd_tl_ws_bytes(int64_t n_out, int K, int cout, int bm) {
+    if (bm < 1) return 256;
+    const int nz = tl_split(n_out, K, cout, bm);
+    return 256 + (nz > 1 ? size_t(nz) * size_t(n_out) * size_t(cout) * 4 : 0);
+}
+
+// out[out_rows ? out_rows[r] : r] = partial[0][r] + partial[1][r] + ...  (fixed order)
+__global__ void tl_reduce_parts_kernel(const float4* __restrict__ partial, int S, int64_t n_out, int c4,
+                                       const int32_t* __restrict__ out_rows, float4* __restrict__ out) {
+    const int64_t total = n_out * c4;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        float4 s = partial[e];
+        for (int z = 1; z < S; ++z) {
+            const float4 v = partial[int64_t(z) * total + e];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (out_rows) {
+            const int64_t r = e / c4, c = e - r * c4;
+            out[int64_t(out_rows[r]) * c4 + c] = s;
+        } else {
+            out[e] = s;
+        }
+    }
+}
 
 static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
                               float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm, void* ws,
@@ -562,9 +608,13 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
     OSN_REQUIRE(aligned16(in) && aligned16(Wp) && aligned16(out), OSN_E_ARG, "osn_spconv_fwd_tl: pointers must be 16-byte aligned");
     const int nw = tl_waves(cout);
     const int gy = int(cdiv(cout, 32 * nw));
-    OSN_REQUIRE(ws && ws_bytes >= 256 && gy <= 64, OSN_E_WS, "osn_spconv_fwd_tl: workspace %zu < 256 (or more than 64 column groups)", ws_bytes);
+    const int nz = tl ? tl_split(n_out, K, cout, bm) : 1;
+    const size_t need = osn_spconv_fwd_tl_ws_bytes(n_out, tl ? K : 1, cout, bm);
+    OSN_REQUIRE(ws && ws_bytes >= need && gy <= 64, OSN_E_WS, "osn_spconv_fwd_tl: workspace %zu < %zu (or more than 64 column groups)", ws_bytes, need);
+    OSN_REQUIRE(!(bn_partial && nz > 1), OSN_E_ARG, "osn_spconv_fwd_tl: bn_partial is not available on split (small-table) launches");
     OSN_HIP(hipMemsetAsync(ws, 0, 256, st));
     int32_t* counter = static_cast<int32_t*>(ws);
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + 256);
     const int32_t* cnt = nullptr;
     const int2* lst = nullptr;
     const int64_t n_tiles = cdiv(n_out, bm);
@@ -573,17 +623,18 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
         cnt = v.cnt; lst = v.lst;
     }
     const int ns = (cin + 31) / 32, ncb = (cout + 15) / 16;
-    const unsigned gx = unsigned(n_tiles < TL_SLOTS ? n_tiles : TL_SLOTS);
+    const int64_t units = n_tiles * nz;
+    const unsigned gx = unsigned(units < TL_SLOTS ? units : TL_SLOTS);
     const dim3 grid(gx, unsigned(gy));
     const bf16x8* wp = static_cast<const bf16x8*>(Wp);
 #define OSN_TL(NW_)                                                                                                        \
     do {                                                                                                                   \
         if (prof)                                                                                                          \
             hipLaunchKernelGGL((spconv_tl_kernel<NW_, true>), grid, dim3(256), 0, st, in, wp, cnt, lst, out_rows, out,   \
-                               bn_partial, counter, int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, prof);            \
+                               bn_partial, counter, partial, nz, int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, prof); \
         else                                                                                                               \
             hipLaunchKernelGGL((spconv_tl_kernel<NW_, false>), grid, dim3(256), 0, st, in, wp, cnt, lst, out_rows, out,  \
-                               bn_partial, counter, int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, prof);            \
+                               bn_partial, counter, partial, nz, int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, prof); \
     } while (0)
     switch (nw) {
         case 4: OSN_TL(4); break;
@@ -593,6 +644,14 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
     }
 #undef OSN_TL
     OSN_LAUNCH_CHECK();
+    if (nz > 1) {
+        const int64_t total4 = n_out * (cout / 4);
+        int g = int(cdiv(total4, 256));
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(tl_reduce_parts_kernel, dim3(g), dim3(256), 0, st, reinterpret_cast<const float4*>(partial), nz, n_out,
+                           cout / 4, out_rows, reinterpret_cast<float4*>(out));
+        OSN_LAUNCH_CHECK();
+    }
     return OSN_OK;
 }
 

@@ -40,6 +40,9 @@ class SparseConvFunction(Function):
         ctx.wp_dgrad = None
         ctx.tl_bwd = None
         mode = "bf16x6" if CONV_MODE == "tl" else CONV_MODE
+        ctx.stem = CONV_MODE != "fp32" and nbr_fwd is not None and ops.stem_eligible(K, cin, cout)
+        if ctx.stem:
+            return ops.stem_conv_fwd(feats, kernel, nbr_fwd, n_out)
         if CONV_MODE == "tl" and K > 1 and ops.tl_eligible(K, cin, cout, ctx.n_in):
             # forward / input gradient: only on maps of at least TL_FWD_MIN_ROWS rows (measured: 20-30 % faster on the
             # 100 k-row maps, a tie at 48 k rows, slower below); 1x1 convs stay on the first-generation kernel
@@ -83,7 +86,9 @@ class SparseConvFunction(Function):
         if ctx.needs_input_grad[1]:
             cin, cout = kernel.shape[-2], kernel.shape[-1]
             tl, swap = ctx.wg_lists
-            if CONV_MODE == "tl" and K > 1 and tl is not None and ops.tl_eligible(K, cin, cout, ctx.n_in):
+            if ctx.stem:
+                gk = ops.stem_conv_wgrad(feats, gout, nbr_fwd, K).reshape(kernel.shape)
+            elif CONV_MODE == "tl" and K > 1 and tl is not None and ops.tl_eligible(K, cin, cout, ctx.n_in):
                 gk = ops.spconv_wgrad_tl(feats, gout, tl, K, swap=swap).reshape(kernel.shape)
             else:
                 gk = ops.spconv_wgrad(feats, gout, nbr_fwd, K, counts).reshape(kernel.shape)

@@ -376,7 +376,7 @@ def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
     if wp.numel() != need:
         raise ValueError("prepared weight has %d bytes, a [%d, %d, %d] conv needs %d" % (wp.numel(), K, cin, cout, need))
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
-    ws = _ws(256, dev)
+    ws = _ws(_cached("osn_spconv_fwd_tl_ws_bytes", n_out, K if tl is not None else 1, cout, bm), dev)
     tok = _profiler.start("spconv_fwd_tl", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
         if _profiler is not None else None
     with _Dev(dev):
@@ -439,6 +439,50 @@ def spconv_wgrad_tl(feats, gout, tl, K, swap=False):
     with _Dev(dev):
         check(lib.osn_spconv_wgrad_tl(_p(feats), _p(gout), _p(pl), int(bool(swap)), _p(gw), n_in, n_out, K, cin, cout,
                                       _p(ws), ws.numel(), _stream(dev)), "osn_spconv_wgrad_tl")
+    if tok is not None:
+        _profiler.stop(tok)
+    return gw
+
+
+def stem_eligible(K, cin, cout):
+    """The dedicated kernels of the U-Net's 3-channel stem conv (any conv with <= 4 input and 32 output channels)."""
+    return cin <= 4 and cout == 32 and 1 < K <= 125
+
+
+def stem_conv_fwd(feats, weight, nbr, n_out):
+    dev = feats.device
+    lib = _prep(dev)
+    feats = _f32c(feats, "features")
+    w = _f32c(_w3(weight), "weight")
+    K, cin, cout = w.shape
+    if nbr.dtype != torch.int32 or nbr.shape != (K, n_out):
+        raise ValueError("nbr must be int32 [%d, %d], got %s %s" % (K, n_out, nbr.dtype, tuple(nbr.shape)))
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    tok = _profiler.start("stem_fwd", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
+        if _profiler is not None else None
+    with _Dev(dev):
+        check(lib.osn_stem_conv_fwd(_p(feats), _p(w), _p(nbr.contiguous()), _p(out), n_out, K, cin, cout, _stream(dev)),
+              "osn_stem_conv_fwd")
+    if tok is not None:
+        _profiler.stop(tok)
+    return out
+
+
+def stem_conv_wgrad(feats, gout, nbr, K):
+    dev = feats.device
+    lib = _prep(dev)
+    feats = _f32c(feats, "features")
+    gout = _f32c(gout, "grad_output")
+    n_out, cout = gout.shape
+    cin = feats.shape[1]
+    gw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
+    wsb = _cached("osn_stem_conv_wgrad_ws_bytes", K, cin)
+    ws = _ws(wsb, dev)
+    tok = _profiler.start("stem_wgrad", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
+        if _profiler is not None else None
+    with _Dev(dev):
+        check(lib.osn_stem_conv_wgrad(_p(feats), _p(gout), _p(nbr.contiguous()), _p(gw), n_out, K, cin, cout, _p(ws),
+                                      ws.numel(), _stream(dev)), "osn_stem_conv_wgrad")
     if tok is not None:
         _profiler.stop(tok)
     return gw

@@ -37,6 +37,12 @@ def main():
               (1, 1, 1, 96, 768), (1, 1, 1, 128, 96), (2, 1, 2, 96, 96), (1, 2, 2, 32, 32), (1, 2, 2, 96, 96)]
     if os.environ.get("SHAPES", "all") == "hot":
         shapes = shapes[:2]
+    if os.environ.get("SHAPES", "all") == "deep":
+        shapes = [(8, 8, 3, 128, 128), (8, 8, 3, 256, 128), (8, 8, 3, 128, 256), (8, 8, 3, 256, 256), (16, 16, 3, 256, 256),
+                  (16, 16, 3, 128, 256), (4, 4, 3, 64, 64), (4, 4, 3, 128, 128), (4, 8, 2, 64, 64), (8, 4, 2, 128, 128),
+                  (8, 16, 2, 128, 128), (16, 8, 2, 256, 128)]
+    if os.environ.get("SHAPES", "all") == "l1":
+        shapes = [s for s in shapes if s[0] == 2 and s[1] == 2]
     for si, so, ks, cin, cout in shapes:
         K = ks ** 3
         n_in, n_out = cm.size(si), cm.size(so)
@@ -48,8 +54,9 @@ def main():
             pairs = int(ops.kmap_count(nbr).sum())
             tiles = cm.kmap_tiles(si, so, ks)[0]
             tbl, rows, gm = (tiles[1], tiles[0], tiles[2]) if tiles is not None else (nbr, None, None)
-            t_list = timed(lambda: ops.tile_lists(tbl, out_rows=rows), reps)
-            tl = ops.tile_lists(tbl, out_rows=rows)
+            bm_env = int(os.environ["BM"]) if "BM" in os.environ else None
+            t_list = timed(lambda: ops.tile_lists(tbl, out_rows=rows, bm=bm_env), reps)
+            tl = ops.tile_lists(tbl, out_rows=rows, bm=bm_env)
             row["bm"] = tl.bm
         else:
             nbr = tbl = rows = gm = tl = None

@@ -34,17 +34,17 @@ def main():
         wf, _ = ops.weight_prep_tl(w, want_dgrad=False)
         out = torch.empty(n, cout, device=dev)
         prof = torch.zeros(512, 10, dtype=torch.int64, device=dev)
-        ws = torch.zeros(256, dtype=torch.uint8, device=dev)
+        ws = torch.zeros(256 + 16 * n * cout * 4, dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream().cuda_stream
         for _ in range(2):
             rc = fn(x.data_ptr(), n, wf.data_ptr(), tl.buf.data_ptr(), tl.out_rows.data_ptr(), out.data_ptr(), n, 27,
-                    cin, cout, tl.bm, ws.data_ptr(), 256, prof.data_ptr(), stream)
+                    cin, cout, tl.bm, ws.data_ptr(), ws.numel(), prof.data_ptr(), stream)
             assert rc == 0, _lib.last_error()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn(x.data_ptr(), n, wf.data_ptr(), tl.buf.data_ptr(), tl.out_rows.data_ptr(), out.data_ptr(), n, 27,
-           cin, cout, tl.bm, ws.data_ptr(), 256, prof.data_ptr(), stream)
+           cin, cout, tl.bm, ws.data_ptr(), ws.numel(), prof.data_ptr(), stream)
         e1.record()
         torch.cuda.synchronize()
         print("kernel with timers: %.1f us" % (e0.elapsed_time(e1) * 1e3))

@@ -1,26 +1,31 @@
 #!/usr/bin/env python
-"""Kernel statistics from a rocprofv3 rocpd SQLite database (the default output format of
-rocprofv3 --kernel-trace in ROCm 7.2) -> the same table `--stats` prints, as CSV/markdown.
-usage: python tools/rocpd_stats.py <results.db> [out.csv] [--per-step N]"""
+"""Per-kernel statistics (calls, total / average duration) from a rocprofv3 rocpd database
+(`rocprofv3 --kernel-trace --stats -d DIR -o NAME -- cmd` writes NAME_results.db on this ROCm), as CSV.
+usage: rocpd_stats.py trace_results.db [steps]   (steps: divide the calls / totals to per-step figures)"""
+import re
 import sqlite3
 import sys
 
 
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*\)$", "", name)
+    return name[:110]
+
+
 def main():
-    db = sys.argv[1]
-    out = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else None
-    con = sqlite3.connect(db)
-    rows = con.execute(
-        "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
-        "from kernels group by name order by sum(duration) desc").fetchall()
-    total = sum(r[2] for r in rows) or 1
-    lines = ["Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs,Percentage"]
-    for n, c, t, a, mn, mx in rows:
-        lines.append('"%s",%d,%d,%.1f,%d,%d,%.2f' % (n, c, t, a, mn, mx, 100.0 * t / total))
-    text = "\n".join(lines)
-    if out:
-        open(out, "w").write(text + "\n")
-    print(text[:6000])
+    db = sqlite3.connect(sys.argv[1])
+    steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+    cur = db.cursor()
+    rows = cur.execute("select s.kernel_name, count(*), sum(d.end - d.start), min(d.end - d.start), max(d.end - d.start) "
+                       "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
+                       "group by s.kernel_name order by 3 desc").fetchall()
+    total = sum(r[2] for r in rows)
+    print("kernel,calls_per_step,ms_per_step,avg_us,min_us,max_us,percent")
+    for name, n, t, lo, hi in rows:
+        print("\"%s\",%.1f,%.4f,%.2f,%.2f,%.2f,%.2f" % (short(name), n / steps, t / steps / 1e6, t / n / 1e3, lo / 1e3, hi / 1e3,
+                                                         100.0 * t / total))
+    print("\"TOTAL\",%.1f,%.4f,,,," % (sum(r[1] for r in rows) / steps, total / steps / 1e6))
 
 
 if __name__ == "__main__":
