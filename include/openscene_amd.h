@@ -207,15 +207,11 @@ size_t osn_spconv_wgrad_tl_ws_bytes(int K, int cin, int cout);
 int osn_spconv_wgrad_tl(const float* in, const float* gout, const void* pl, int swap, float* gW, int64_t n_in,
                         int64_t n_out, int K, int cin, int cout, void* ws, size_t ws_bytes, osn_stream_t stream);
 
-/* The 3-channel stem convolution (conv0p1s1: 5^3 kernel, 3 -> 32, models/mink_unet.py:47-50) and its weight
- * gradient: same contracts as osn_spconv_fwd / osn_spconv_wgrad on the plain (unordered) table, exact fp32
- * FMA chains in ascending offset order, for cin <= 4 and cout == 32 (there is no contraction worth a matrix
- * unit; the op streams the 125 x n_out table once).                                                          */
+/* The 3-channel stem convolution (conv0p1s1: 5^3 kernel, 3 -> 32, models/mink_unet.py:47-50): same contract as
+ * osn_spconv_fwd on the plain (unordered) table, exact fp32 FMA chain in ascending offset order, for cin <= 4
+ * and cout == 32 (no contraction worth a matrix unit; the op streams the 125 x n_out table once).            */
 int osn_stem_conv_fwd(const float* in, const float* W, const int32_t* nbr, float* out, int64_t n_out, int K,
                       int cin, int cout, osn_stream_t stream);
-size_t osn_stem_conv_wgrad_ws_bytes(int K, int cin);
-int osn_stem_conv_wgrad(const float* in, const float* gout, const int32_t* nbr, float* gW, int64_t n_out, int K,
-                        int cin, int cout, void* ws, size_t ws_bytes, osn_stream_t stream);
 
 /* ---- batch norm (+ReLU, +residual) -------------------------------------- *
  * Replaces [ME] MinkowskiBatchNorm (= torch.nn.BatchNorm1d on .F), MinkowskiReLU

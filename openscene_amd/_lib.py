@@ -50,8 +50,6 @@ PROTOTYPES = {
     "osn_spconv_wgrad_tl_ws_bytes": (_sz, [_i32, _i32, _i32]),
     "osn_spconv_wgrad_tl": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "osn_stem_conv_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
-    "osn_stem_conv_wgrad_ws_bytes": (_sz, [_i32, _i32]),
-    "osn_stem_conv_wgrad": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "osn_bn_ws_bytes": (_sz, [_i64, _i32]),
     "osn_bn_stats": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _sz, _vp]),
     "osn_bn_apply": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _i64, _i32, _vp]),

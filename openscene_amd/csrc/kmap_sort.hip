@@ -65,10 +65,9 @@ __global__ void kmap_group_mask_kernel(const int32_t* __restrict__ nbr_sorted, i
     if ((threadIdx.x & 31) == 0 && j < n_out) gmask[j >> 5] = m;
 }
 
-// rocPRIM picks a merge sort (1 block sort + ~8 merge launches) below 1 M items; the tables sorted here have 1e4-1e6
-// rows and 8..27 significant key bits, where the onesweep radix path needs fewer launches (a histogram + one launch
-// per 8-bit digit) -- the sort is launch-bound at these sizes (profiles/r02_s4: 98 merge launches per scene).
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
+// rocPRIM picks a merge sort (1 block sort + ~8 merge launches) below 1 M items -- 98 merge launches per scene
+// (profiles/r02_s4), 174 us for the level-0 3^3 table of S100k.
+using SortConfig = rocprim::default_config;      // measured: forcing the onesweep path (merge limit 4096) made the maps 0.25 ms slower per scene
 
 struct SortWs {
     uint32_t *mask, *mask_sorted;

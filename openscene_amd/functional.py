@@ -86,9 +86,7 @@ class SparseConvFunction(Function):
         if ctx.needs_input_grad[1]:
             cin, cout = kernel.shape[-2], kernel.shape[-1]
             tl, swap = ctx.wg_lists
-            if ctx.stem:
-                gk = ops.stem_conv_wgrad(feats, gout, nbr_fwd, K).reshape(kernel.shape)
-            elif CONV_MODE == "tl" and K > 1 and tl is not None and ops.tl_eligible(K, cin, cout, ctx.n_in):
+            if CONV_MODE == "tl" and K > 1 and tl is not None and ops.tl_eligible(K, cin, cout, ctx.n_in):
                 gk = ops.spconv_wgrad_tl(feats, gout, tl, K, swap=swap).reshape(kernel.shape)
             else:
                 gk = ops.spconv_wgrad(feats, gout, nbr_fwd, K, counts).reshape(kernel.shape)

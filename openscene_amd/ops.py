@@ -468,26 +468,6 @@ def stem_conv_fwd(feats, weight, nbr, n_out):
     return out
 
 
-def stem_conv_wgrad(feats, gout, nbr, K):
-    dev = feats.device
-    lib = _prep(dev)
-    feats = _f32c(feats, "features")
-    gout = _f32c(gout, "grad_output")
-    n_out, cout = gout.shape
-    cin = feats.shape[1]
-    gw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
-    wsb = _cached("osn_stem_conv_wgrad_ws_bytes", K, cin)
-    ws = _ws(wsb, dev)
-    tok = _profiler.start("stem_wgrad", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
-        if _profiler is not None else None
-    with _Dev(dev):
-        check(lib.osn_stem_conv_wgrad(_p(feats), _p(gout), _p(nbr.contiguous()), _p(gw), n_out, K, cin, cout, _p(ws),
-                                      ws.numel(), _stream(dev)), "osn_stem_conv_wgrad")
-    if tok is not None:
-        _profiler.stop(tok)
-    return gw
-
-
 def x6_eligible(K, cin, cout, n_out):
     """The split-bf16 kernel handles every conv of the U-Net except the 3-channel stem."""
     if cin % 4 or cin < 8:

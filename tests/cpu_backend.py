@@ -230,10 +230,6 @@ def stem_conv_fwd(feats, weight, nbr, n_out):
     return spconv_fwd(feats, weight, nbr, n_out)
 
 
-def stem_conv_wgrad(feats, gout, nbr, K):
-    return spconv_wgrad(feats, gout, nbr, K)
-
-
 def x6_eligible(K, cin, cout, n_out):
     return cin % 4 == 0 and cin >= 8
 
@@ -336,7 +332,7 @@ def weight_prep_x6_pair(weight, flip=False):
     return weight_prep_x6(weight), weight_prep_x6(weight, flip=flip, for_dgrad=True)
 
 
-_NAMES = ["stem_eligible", "stem_conv_fwd", "stem_conv_wgrad", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
+_NAMES = ["stem_eligible", "stem_conv_fwd", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
           "spconv_wgrad", "bn_stats", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
           "fnv_hash", "feature_remap", "batch_coords"]
 

@@ -89,7 +89,7 @@ def test_training_step_runs_through_the_real_wrappers(mock_ops):
     # gradient each; three BN calls per BatchNorm; at most one weight-prep launch per conv
     n_fwd = c.get("osn_spconv_fwd", 0) + c.get("osn_spconv_fwd_x6", 0) + c.get("osn_spconv_fwd_tl", 0) + c.get("osn_stem_conv_fwd", 0)
     assert n_fwd == 2 * n_conv - 1, c
-    assert c.get("osn_spconv_wgrad", 0) + c.get("osn_spconv_wgrad_tl", 0) + c.get("osn_stem_conv_wgrad", 0) == n_conv, c
+    assert c.get("osn_spconv_wgrad", 0) + c.get("osn_spconv_wgrad_tl", 0) == n_conv, c
     assert c.get("osn_pair_lists_build", 0) <= 10, c            # pair arrays: once per map, not per conv
     assert c["osn_bn_stats"] == n_bn and c["osn_bn_apply"] == n_bn and c["osn_bn_backward"] == n_bn, c
     assert c.get("osn_weight_prep_x6_pair", 0) + c.get("osn_weight_prep_x6", 0) + c.get("osn_weight_prep_tl", 0) <= n_conv + 8, c

@@ -124,5 +124,31 @@ if os.environ.get("MODE") == "wgrad":
     main = wgrad_main
 
 
+def stem_main():
+    """MODE=stem: generic kernels vs the dedicated stem kernels (5^3, 3 -> 32, level 0)."""
+    reps = int(os.environ.get("REPS", "5"))
+    dev = torch.device("cuda", 0)
+    vox = syn.shuffled(syn.grid_voxels(syn.room_points(0), 0.02), 0)
+    cm = CoordinateManager(torch.from_numpy(syn.batch_coords([vox])).to(dev))
+    n = cm.size(1)
+    nbr = cm.kmap(1, 1, 5)[0]
+    cnt = cm.kmap_counts(1, 1, 5)
+    x = torch.ones(n, 3, device=dev)
+    w = torch.randn(125, 3, 32, device=dev) * 0.05
+    g = torch.randn(n, 32, device=dev)
+    a, b = ops.spconv_fwd(x, w, nbr, n), ops.stem_conv_fwd(x, w, nbr, n)
+    print(json.dumps({"fwd_old_us": timed(lambda: ops.spconv_fwd(x, w, nbr, n), reps),
+                      "fwd_stem_us": timed(lambda: ops.stem_conv_fwd(x, w, nbr, n), reps),
+                      "wgrad_old_us": timed(lambda: ops.spconv_wgrad(x, g, nbr, 125, cnt), reps),
+                      "fwd_diff": (a - b).abs().max().item() / a.abs().max().item(),
+                      "kmap125_us": timed(lambda: ops.kmap_build(cm._tables[1], cm._coords[1], 5, 1, with_counts=True), reps),
+                      "kmap27_us": timed(lambda: ops.kmap_build(cm._tables[1], cm._coords[1], 3, 1, with_counts=True), reps),
+                      "sort27_us": timed(lambda: ops.kmap_sort(cm.kmap(1, 1, 3)[0], cm.kmap_counts(1, 1, 3)), reps)}))
+
+
+if os.environ.get("MODE") == "stem":
+    main = stem_main
+
+
 if __name__ == "__main__":
     main()
