@@ -192,6 +192,62 @@ def step_algorithmic_bytes(model, sizes, pair_counts):
     return total_b, total_f
 
 
+def variant_step_ms(device, arch, feature, coords, conv_mode=None, steps=5, warmup=2, train=True):
+    """ms per step of a fresh model on `coords` (same step definition as the headline: maps + forward + cosine loss +
+    backward + fused Adam; forward only if not train).  conv_mode overrides openscene_amd.functional.CONV_MODE."""
+    from openscene_amd import functional as F_
+    from openscene_amd.disnet import DisNet
+    from openscene_amd.sparse import SparseTensor
+
+    class Cfg:
+        arch_3d = arch
+        feature_2d_extractor = feature
+
+    old = F_.CONV_MODE
+    if conv_mode is not None:
+        F_.CONV_MODE = conv_mode
+    try:
+        torch.manual_seed(1463)
+        model = DisNet(Cfg()).to(device)
+        out_dim = model.net3d.final.out_channels
+        n = coords.shape[0]
+        feats = torch.ones(n, 3, device=device)
+        n_sup = min(20000, n)
+        g = torch.Generator().manual_seed(7)
+        sel = torch.randperm(n, generator=g)[:n_sup].sort()[0].to(device)
+        target = torch.nn.functional.normalize(torch.randn(n_sup, out_dim, generator=g), dim=1).half().float().to(device)
+        cos = torch.nn.CosineSimilarity()
+        if train:
+            try:
+                optim = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+            except (TypeError, RuntimeError):
+                optim = torch.optim.Adam(model.parameters(), lr=1e-4)
+        else:
+            model.eval()
+
+        def one():
+            if not train:
+                with torch.no_grad():
+                    return model(SparseTensor(feats, coords))
+            out = model(SparseTensor(feats, coords))
+            loss = (1 - cos(out.index_select(0, sel), target)).mean()
+            optim.zero_grad(set_to_none=True)
+            loss.backward()
+            optim.step()
+            return loss
+
+        for _ in range(warmup):
+            one()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) * 1e3 / steps
+    finally:
+        F_.CONV_MODE = old
+
+
 def _cpu_step(seed, n_pts, arch, out_dim):
     from oracle import coords as oc
     from oracle import sparse_ops as so
@@ -214,26 +270,42 @@ def _cpu_step(seed, n_pts, arch, out_dim):
 
 
 def cpu_baseline(seed, arch, out_dim):
-    """Time the CPU oracle (kind "port": per-offset gather -> BLAS mm -> index_add, the loop ME's CPU
-    backend runs) on a BOUNDED sample of the same workload: first a 1/8-size scene to estimate the
-    rate, then the full S100k scene if that fits ~60 s.  Threads = the cores this process may use."""
+    """Time the CPU oracle (kind "port": per-offset gather -> BLAS mm -> index_add, the loop ME's CPU backend runs) as
+    SURVEY.md 8(d) prescribes: on a bounded sample -- a 1/8-size scene of the same generator -- 2 warm-ups, then the
+    MEDIAN of 5 steps with all usable cores and ONE step single-threaded; the full S100k scene once if it fits ~40 s;
+    and the numpy restatement of the reference voxeliser (single-threaded by construction) on 200 k points."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 32))
+    threads = max(1, min(cores, 64))
     torch.set_num_threads(threads)
-    n_small, dt_small = _cpu_step(seed, 15000, arch, out_dim)
+    for _ in range(2):
+        _cpu_step(seed, 15000, arch, out_dim)
+    runs = sorted(_cpu_step(seed, 15000, arch, out_dim) for _ in range(5))
+    n_small, dt_small = runs[2]
+    torch.set_num_threads(1)
+    n1, dt1 = _cpu_step(seed, 15000, arch, out_dim)
+    torch.set_num_threads(threads)
+    res = {"value": n_small / dt_small, "unit": "voxels/s", "cores": threads, "kind": "port",
+           "sample": "median of 5 steps (after 2 warm-ups; maps + fwd + loss + bwd, fp32, no optimizer) of %s on a 1/8-size "
+                     "scene of the S100k generator: %d voxels in %.2f s with %d threads" % (arch, n_small, dt_small, threads),
+           "one_thread": {"value": n1 / dt1, "voxels": n1, "seconds": dt1}}
     est_full = dt_small * (100999.0 / n_small)
-    if est_full < 60.0:
+    if est_full < 40.0:
         n, dt = _cpu_step(seed, 120000, arch, out_dim)
-        what = "the same S100k scene"
-    else:
-        n, dt = n_small, dt_small
-        what = "a 1/8-size scene of the same generator (full scene estimated at %.0f s)" % est_full
-    return {"value": n / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
-            "sample": "1 step (maps + fwd + loss + bwd, fp32, no optimizer) of %s on %s: %d voxels in %.1f s, "
-                      "%d threads" % (arch, what, n, dt, threads)}
+        res["full_scene"] = {"value": n / dt, "voxels": n, "seconds": dt, "threads": threads}
+    from oracle import voxelize as ov
+    from openscene_amd import synthetic as syn
+    pts = syn.room_points(7, n_pts=200000)
+    np.random.seed(0)
+    T = ov.draw_transform(0.02)
+    t0 = time.perf_counter()
+    ov.voxelize_with_matrix(pts, T)
+    dtv = time.perf_counter() - t0
+    res["voxelizer"] = {"points_per_s": 200000 / dtv, "seconds": dtv, "n_points": 200000, "cores": 1,
+                        "what": "numpy restatement of dataset/voxelizer.py:97-140 + sparse_quantize (oracle/voxelize.py)"}
+    return res
 
 
 def main():
@@ -442,6 +514,24 @@ def main():
         q2_bytes = 4.0 * n2 * out_dim + 2.0 * c2 * out_dim + 2.0 * n2 * c2 + 16.0 * n2
         qres["matterport160"] = {"ms": q2_ms, "n_points": n2, "labels": c2, "scores_written": True,
                                  "hbm_frac": q2_bytes / (q2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # SURVEY.md 8(d) Q, largest case: (1 M points, 768, 160), labels only and with the fp16 score matrix
+        del x2, g2
+        n3 = 1000000
+        x3 = torch.randn(n3 // 2, out_dim, generator=gq).to(device)
+        g3 = torch.randint(0, n3 // 2, (n3,), generator=gq).to(device)
+        for key, want in (("q1m_labels", False), ("q1m_scores", True)):
+            query_distill(x3, t2, g3, return_scores=want)
+            torch.cuda.synchronize(device)
+            e0.record()
+            for _ in range(5):
+                query_distill(x3, t2, g3, return_scores=want)
+            e1.record()
+            torch.cuda.synchronize(device)
+            q3_ms = e0.elapsed_time(e1) / 5
+            q3_bytes = 4.0 * n3 * out_dim + 2.0 * c2 * out_dim + 16.0 * n3 + (2.0 * n3 * c2 if want else 0.0)
+            qres[key] = {"ms": q3_ms, "n_points": n3, "labels": c2, "scores_written": want,
+                         "hbm_frac": q3_bytes / (q3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del x3, g3
         # voxeliser (M3): 200 k points, 2 cm, reference transform draw; includes the one host sync for n_vox
         from openscene_amd import synthetic as syn
         from openscene_amd.voxelizer import Voxelizer
@@ -475,6 +565,49 @@ def main():
                                 "what": "GPU-resident FusedFeatureLoader.__getitem__ (train): voxelise + remap + gathers, "
                                         "two host syncs (voxel count, selected count)"}
         model.train()
+        # ---- the other workloads SURVEY.md 8(d) / BASELINE.json name (same step definition, fresh model each)
+        from openscene_amd import functional as F_
+        lidar = syn.shuffled(syn.grid_voxels(syn.lidar_points(0), 0.05), 0)
+        lidar_coords = torch.from_numpy(syn.batch_coords([lidar])).to(device)
+        replica = syn.shuffled(syn.grid_voxels(syn.room_points(1, n_pts=250000, dims=(6.0, 4.5, 2.6), n_boxes=12), 0.02), 1)
+        replica_coords = torch.from_numpy(syn.batch_coords([replica])).to(device)
+        del pred
+        torch.cuda.empty_cache()
+        ms32 = variant_step_ms(device, args.arch, args.feature, coords0, conv_mode="fp32")
+        ms512 = variant_step_ms(device, args.arch, "lseg", coords0)
+        ms34 = variant_step_ms(device, "MinkUNet34C", args.feature, lidar_coords, steps=3, warmup=2)
+        ms34i = variant_step_ms(device, "MinkUNet34C", args.feature, lidar_coords, steps=3, warmup=1, train=False)
+        msrep = variant_step_ms(device, args.arch, args.feature, replica_coords, steps=5, warmup=2, train=False)
+        extra["step_exact_fp32"] = {"ms": ms32, "voxels_per_s": n_vox / (ms32 * 1e-3),
+                                    "what": "the headline step with OSN_CONV_MODE=fp32 (fp32-input MFMA, exact fp32 products)"}
+        extra["step_d512"] = {"ms": ms512, "voxels_per_s": n_vox / (ms512 * 1e-3),
+                              "what": "the headline step with the 512-d (LSeg) head"}
+        extra["l235k_34c_step"] = {"ms": ms34, "voxels": int(lidar_coords.shape[0]),
+                                   "voxels_per_s": lidar_coords.shape[0] / (ms34 * 1e-3),
+                                   "what": "configs[4]: nuScenes-shaped sweep stack at 5 cm, MinkUNet34C, %d-d head, training step" % out_dim}
+        extra["l235k_34c_inference"] = {"ms": ms34i, "voxels_per_s": lidar_coords.shape[0] / (ms34i * 1e-3),
+                                        "what": "configs[4] inference: maps + eval-mode forward"}
+        extra["replica_fwd"] = {"ms": msrep, "voxels": int(replica_coords.shape[0]),
+                                "voxels_per_s": replica_coords.shape[0] / (msrep * 1e-3),
+                                "what": "configs[0] shape on the GPU: R-replica room (6 x 4.5 x 2.6 m, 250 k points, 2 cm), "
+                                        "maps + eval-mode forward of %s" % args.arch}
+        extra["conv_mode"] = F_.CONV_MODE
+
+    comm = None
+    if world > 1:
+        # exchange step of the path: the DDP gradient all-reduce (RCCL over xGMI).  Its stand-alone time on a flat
+        # buffer of the model's size bounds what DDP has to hide behind backward.
+        flat = torch.zeros(sum(p.numel() for p in model.parameters()), device=device)
+        for _ in range(2):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize(device)
+        tc = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize(device)
+        ar_ms = (time.perf_counter() - tc) * 1e3 / 5
+        comm = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "allreduce_MB": flat.numel() * 4 / 1e6,
+                "allreduce_ms_standalone": ar_ms, "share_of_step_if_exposed": ar_ms / (dt_max * 1e3 / args.steps)}
 
     if rank != 0:
         if world > 1:
@@ -529,7 +662,7 @@ def main():
         import subprocess
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--arch", args.arch,
-                                "--feature", args.feature], capture_output=True, text=True, timeout=240,
+                                "--feature", args.feature], capture_output=True, text=True, timeout=300,
                                env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
             cpu = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:      # noqa: BLE001  (a missing baseline must not lose the GPU measurement)
@@ -537,7 +670,7 @@ def main():
                    "sample": "cpu baseline failed: %s" % (str(e)[:200],)}
 
     from openscene_amd import functional as _F
-    conv_dtype = "f32 (bf16x6 split-precision MFMA, fp32 accumulate)" if _F.CONV_MODE == "bf16x6" else "f32"
+    conv_dtype = "f32 (bf16x6 split-precision MFMA, fp32 accumulate)" if _F.CONV_MODE in ("bf16x6", "tl") else "f32"
     line = {
         "metric": "active voxels/sec MinkUNet18A fwd+bwd @2cm ScanNet; per-point query ms",
         "value": vox_total * args.steps / dt_max, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
@@ -549,7 +682,8 @@ def main():
                    "arch": args.arch, "feature_dim": out_dim, "voxels_rank0": n_vox,
                    "level_sizes": sizes, "parallelism": "dp%d" % world,
                    "step_algorithmic_GB": step_bytes / 1e9, "step_GFLOP": step_flops / 1e9},
-        "query": qres, "voxelizer": vox_res, "phases": extra, "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "loss": float(loss.detach()),
+        "query": qres, "voxelizer": vox_res, "phases": extra, "roofline": roofline, "cpu_baseline": cpu, "comm": comm,
+        "kernels": kernels, "loss": float(loss.detach()),
     }
     print(json.dumps(line))
     if world > 1:
