@@ -31,16 +31,16 @@ def _install_cpu_backend():
         setattr(ops, n, getattr(cpu_backend, n))
 
 
-def _scene(seed):
+def _scene(seed, n_draw=220):
     rng = np.random.default_rng(seed)
-    g = np.unique(rng.integers(0, 10, (220, 3)), axis=0)
+    g = np.unique(rng.integers(0, 10, (n_draw, 3)), axis=0)
     g = g[rng.permutation(g.shape[0])]
     return torch.from_numpy(np.concatenate([np.zeros((g.shape[0], 1)), g], 1).astype(np.int32))
 
 
-def _loss(model, seed):
+def _loss(model, seed, n_draw=220):
     from openscene_amd.sparse import SparseTensor
-    c = _scene(seed)
+    c = _scene(seed, n_draw)
     out = model(SparseTensor(torch.ones(c.shape[0], 3, dtype=torch.float64), c))
     tgt = torch.randn(out.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
     return (1 - torch.nn.functional.cosine_similarity(out, tgt)).mean()
@@ -90,6 +90,75 @@ def test_ddp_two_ranks_gloo(tmp_path):
         for n in acc:
             scale = acc[n].abs().max().item() + 1e-12
             assert (acc[n] - r0["grads"][n]).abs().max().item() <= 1e-9 * scale + 1e-12, n
+    finally:
+        import importlib
+        import openscene_amd.ops as ops
+        importlib.reload(ops)
+
+
+# ---- four ranks, scenes of UNEQUAL size handed out by DistributedSampler (run/distill.py:183-184), two steps with an
+# optimizer in between: after every step all ranks hold the same parameters, and the first step's gradients are the
+# mean over the four ranks' scenes.
+_SIZES = [60, 140, 220, 400, 90, 300, 180, 260]            # scene i draws _SIZES[i] lattice points
+
+
+def _worker4(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    _install_cpu_backend()
+    from openscene_amd.mink_unet import mink_unet
+    from torch.utils.data.distributed import DistributedSampler
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(7 + rank)
+    model = mink_unet(3, 8, 3, "MinkUNet14A").double()
+    ddp = torch.nn.parallel.DistributedDataParallel(model)
+    optim = torch.optim.SGD(ddp.parameters(), lr=1e-2)
+    sampler = DistributedSampler(list(range(len(_SIZES))), num_replicas=world, rank=rank, shuffle=False)
+    mine = list(iter(sampler))                              # two scenes per rank
+    first_grads = None
+    for step, idx in enumerate(mine):
+        optim.zero_grad(set_to_none=True)
+        _loss(ddp, seed=20 + idx, n_draw=_SIZES[idx]).backward()
+        if step == 0:
+            first_grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+        optim.step()
+    params = {n: p.detach().clone() for n, p in model.named_parameters()}
+    bufs = {n: b.detach().clone() for n, b in model.named_buffers()}
+    torch.save({"grads": first_grads, "params": params, "bufs": bufs, "mine": mine}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_four_ranks_unequal_scenes_distributed_sampler(tmp_path):
+    world = 4
+    mp.spawn(_worker4, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, "r%d.pt" % r)) for r in range(world)]
+    assert sorted(i for r in res for i in r["mine"]) == list(range(len(_SIZES)))      # every scene exactly once
+    for r in res[1:]:
+        for n in res[0]["params"]:
+            assert torch.equal(res[0]["params"][n], r["params"][n]), "rank parameters diverged at %s" % n
+            assert torch.equal(res[0]["grads"][n], r["grads"][n]), "gradient %s not all-reduced" % n
+    # BN statistics are LOCAL (no SyncBN in the reference): running buffers differ between ranks with different scenes
+    assert any(not torch.equal(res[0]["bufs"][n], res[1]["bufs"][n]) for n in res[0]["bufs"] if "running_mean" in n)
+    _install_cpu_backend()
+    try:
+        from openscene_amd.mink_unet import mink_unet
+        torch.manual_seed(7)
+        model = mink_unet(3, 8, 3, "MinkUNet14A").double()
+        acc = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+        for r in res:
+            idx = r["mine"][0]
+            model.zero_grad()
+            for m in model.modules():                        # fresh BN buffers per rank, as each rank started
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.reset_running_stats()
+            _loss(model, 20 + idx, _SIZES[idx]).backward()
+            for n, p in model.named_parameters():
+                acc[n] += p.grad / world
+        for n in acc:
+            scale = acc[n].abs().max().item() + 1e-12
+            assert (acc[n] - res[0]["grads"][n]).abs().max().item() <= 1e-9 * scale + 1e-12, n
     finally:
         import importlib
         import openscene_amd.ops as ops
