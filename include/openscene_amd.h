@@ -274,6 +274,11 @@ int osn_voxelize_fnv(const double* xyz, int64_t n, const double* T12_host,
                      void* ws, size_t ws_bytes, osn_stream_t stream);
 /* fnv_hash_vec alone (dataset/voxelization_utils.py:9-22): keys[i] of integral rows. */
 int osn_fnv_hash(const double* grid, int64_t n, int ncol, uint64_t* keys, osn_stream_t stream);
+/* ravel_hash_vec (dataset/voxelization_utils.py:25-41, the alternative key of sparse_quantize; the path itself
+ * uses the FNV key): key = Fortran-style ravel of (coords - column minimum) over the column extents.
+ * grid: float64 [n, ncol <= 4] integral values; ws: 128 bytes.                                              */
+int osn_ravel_hash(const double* grid, int64_t n, int ncol, uint64_t* keys, void* ws, size_t ws_bytes,
+                   osn_stream_t stream);
 
 /* ---- loader-side batch assembly --------------------- *
  * Replaces the index1 / chunk_ind / cumsum chain of FusedFeatureLoader.__getitem__

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "osn_voxelize_ws_bytes": (_sz, [_i64]),
     "osn_voxelize_fnv": (_i32, [_vp, _i64, _c.POINTER(_c.c_double), _vp, _vp, _vp, _c.POINTER(_i64), _vp, _sz, _vp]),
     "osn_fnv_hash": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "osn_ravel_hash": (_i32, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "osn_feature_remap_ws_bytes": (_sz, [_i64, _i64]),
     "osn_feature_remap": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "osn_batch_coords": (_i32, [_vp, _i64, _i32, _vp, _vp]),

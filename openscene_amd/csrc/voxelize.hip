@@ -198,6 +198,69 @@ extern "C" int osn_voxelize_fnv(const double* xyz, int64_t n, const double* T12_
     return OSN_OK;
 }
 
+namespace osn {
+// ravel_hash_vec (dataset/voxelization_utils.py:25-41): key = ((c0 - min0) * (max1 - min1 + 1) + (c1 - min1)) * ... + (c_last - min_last)
+__global__ void ravel_init_kernel(long long* mm, int ncol) {
+    if (int(threadIdx.x) < ncol) {
+        mm[threadIdx.x] = 0x7FFFFFFFFFFFFFFFll;          // column minimum
+        mm[8 + threadIdx.x] = -0x7FFFFFFFFFFFFFFFll - 1;   // column maximum
+    }
+}
+
+__global__ __launch_bounds__(256) void ravel_minmax_kernel(const double* __restrict__ grid, int64_t n, int ncol,
+                                                           long long* __restrict__ mm) {
+    long long lo[4], hi[4];
+    for (int j = 0; j < 4; ++j) { lo[j] = 0x7FFFFFFFFFFFFFFFll; hi[j] = -0x7FFFFFFFFFFFFFFFll - 1; }
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+        for (int j = 0; j < ncol; ++j) {
+            const long long v = (long long)grid[i * ncol + j];
+            lo[j] = v < lo[j] ? v : lo[j];
+            hi[j] = v > hi[j] ? v : hi[j];
+        }
+    for (int j = 0; j < ncol; ++j) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            const long long a = __shfl_down(lo[j], d, 64), b = __shfl_down(hi[j], d, 64);
+            lo[j] = a < lo[j] ? a : lo[j];
+            hi[j] = b > hi[j] ? b : hi[j];
+        }
+        if ((threadIdx.x & 63) == 0) {          // min / max are order-independent: atomics stay deterministic
+            atomicMin(&mm[j], lo[j]);
+            atomicMax(&mm[8 + j], hi[j]);
+        }
+    }
+}
+
+__global__ void ravel_keys_kernel(const double* __restrict__ grid, int64_t n, int ncol, const long long* __restrict__ mm,
+                                  unsigned long long* __restrict__ keys) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long key = 0;
+    for (int j = 0; j < ncol - 1; ++j) {
+        key += (unsigned long long)((long long)grid[i * ncol + j] - mm[j]);
+        key *= (unsigned long long)(mm[8 + j + 1] - mm[j + 1] + 1);
+    }
+    key += (unsigned long long)((long long)grid[i * ncol + ncol - 1] - mm[ncol - 1]);
+    keys[i] = key;
+}
+}  // namespace osn
+
+extern "C" int osn_ravel_hash(const double* grid, int64_t n, int ncol, uint64_t* keys, void* ws, size_t ws_bytes,
+                              osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n >= 0 && ncol >= 1 && ncol <= 4, OSN_E_ARG, "osn_ravel_hash: bad sizes (ncol <= 4)");
+    if (n == 0) return OSN_OK;
+    OSN_REQUIRE(grid && keys && ws && ws_bytes >= 128, OSN_E_ARG, "osn_ravel_hash: null pointer or workspace < 128 bytes");
+    long long* mm = static_cast<long long*>(ws);
+    hipLaunchKernelGGL(osn::ravel_init_kernel, dim3(1), dim3(64), 0, st, mm, ncol);
+    int g = int(osn::cdiv(n, 256));
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(osn::ravel_minmax_kernel, dim3(g), dim3(256), 0, st, grid, n, ncol, mm);
+    hipLaunchKernelGGL(osn::ravel_keys_kernel, dim3(unsigned(osn::cdiv(n, 256))), dim3(256), 0, st, grid, n, ncol, mm,
+                       reinterpret_cast<unsigned long long*>(keys));
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}
+
 extern "C" int osn_fnv_hash(const double* grid, int64_t n, int ncol, uint64_t* keys, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n >= 0 && ncol >= 1, OSN_E_ARG, "osn_fnv_hash: bad sizes");

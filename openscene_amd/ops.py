@@ -695,6 +695,19 @@ def fnv_hash(grid):
     return keys
 
 
+def ravel_hash(grid):
+    """ravel_hash_vec of an integral float64 [n, ncol <= 4] matrix -> int64 keys (uint64 bit pattern)."""
+    dev = grid.device
+    lib = _prep(dev)
+    grid = grid.to(torch.float64).contiguous()
+    n, ncol = grid.shape
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    ws = _ws(128, dev)
+    with _Dev(dev):
+        check(lib.osn_ravel_hash(_p(grid), n, ncol, _p(keys), _p(ws), ws.numel(), _stream(dev)), "osn_ravel_hash")
+    return keys
+
+
 # ------------------------------------------------------------------ loader
 def feature_remap(mask_chunk, vox_ind):
     """mask_chunk bool/uint8 [N_pts], vox_ind int64 [N_vox] (device) ->

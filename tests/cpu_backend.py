@@ -316,6 +316,10 @@ def fnv_hash(grid):
     return torch.from_numpy(ov.fnv_keys(_np(grid)).view(np.int64))
 
 
+def ravel_hash(grid):
+    return torch.from_numpy(ov.ravel_keys(_np(grid)).view(np.int64))
+
+
 def feature_remap(mask_chunk, vox_ind):
     from oracle import loader as ol
     mv, src, ind = ol.remap(_np(mask_chunk).astype(bool), _np(vox_ind))
@@ -334,7 +338,7 @@ def weight_prep_x6_pair(weight, flip=False):
 
 _NAMES = ["stem_eligible", "stem_conv_fwd", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
           "spconv_wgrad", "bn_stats", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
-          "fnv_hash", "feature_remap", "batch_coords"]
+          "fnv_hash", "ravel_hash", "feature_remap", "batch_coords"]
 
 
 def install(monkeypatch):

@@ -183,6 +183,17 @@ def test_fnv_known_answers():
     assert np.array_equal(keys, g["fnv"])
 
 
+def test_ravel_known_answers():
+    """osn_ravel_hash vs outputs of the reference's own ravel_hash_vec (tests/golden/hash_kat.npz)."""
+    from openscene_amd import ops
+    g = np.load(os.path.join(GOLDEN, "hash_kat.npz"))
+    keys = ops.ravel_hash(torch.from_numpy(g["coords"]).to(dev())).cpu().numpy().view(np.uint64)
+    assert np.array_equal(keys, g["ravel"])
+    small = np.array([[0, 0, 0], [1, 2, 3], [241, 181, 121]], dtype=np.float64)
+    k3 = ops.ravel_hash(torch.from_numpy(small).to(dev())).cpu().numpy().view(np.uint64)
+    assert [int(v) for v in k3] == [0, 22451, 5373367]          # SURVEY.md 8(c): minted from the reference function
+
+
 def test_voxelizer_full_size_properties():
     """ScanNet-size cloud (200 k points): bit-exact vs the numpy oracle + np.unique structure."""
     from openscene_amd import ops
