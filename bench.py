@@ -320,6 +320,8 @@ def main():
     ap.add_argument("--prefetch-maps", action="store_true", help="build the maps of the NEXT batch on a side stream "
                     "while a step runs (openscene_amd.sparse.MapPrefetcher) instead of inside the step as "
                     "MinkowskiEngine does; measured 4 %% SLOWER on S100k (DESIGN.md section 4), off by default")
+    ap.add_argument("--prefetch-maps-threaded", action="store_true", help="as --prefetch-maps, but the maps are built by a "
+                    "worker thread (the main thread never waits on the pyramid's size read-backs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--train-only", action="store_true", help="skip the query / inference / voxeliser / loader phases "
@@ -383,8 +385,8 @@ def main():
         coords[:, 1:4] += shift                                    # run/distill.py:315
         return coords
 
-    prefetch = args.prefetch_maps
-    pf = MapPrefetcher(device) if prefetch else None
+    prefetch = args.prefetch_maps or args.prefetch_maps_threaded
+    pf = MapPrefetcher(device, threaded=args.prefetch_maps_threaded) if prefetch else None
     pending = [pf.submit(next_coords())] if prefetch else None
 
     def step():

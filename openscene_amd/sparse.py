@@ -151,7 +151,10 @@ class CoordinateManager:
         for t in self.tensors():
             t.record_stream(stream)
 
-    SORT_MIN_ROWS = 8192      # below this the launch is latency-bound and the sort does not pay
+    SORT_MIN_ROWS = int(__import__("os").environ.get("OSN_SORT_MIN_ROWS", "8192"))   # below this the sort does not pay
+    # 2^3 (strided / transposed) maps are never tile-ordered: measured per-step kernel time 14.81 ms with, 14.42 ms without
+    # (tools/ab_kernel_time.sh): their eight sorts cost more than the convs of those maps gain
+    SORT_MIN_ROWS_K8 = int(__import__("os").environ.get("OSN_SORT_MIN_ROWS_K8", str(10 ** 9)))
 
     def kmap_tiles(self, in_stride, out_stride, ksize, dilation=1):
         """Tile-ordered variants of kmap(): ((order, table) for the forward conv or None,
@@ -167,6 +170,8 @@ class CoordinateManager:
 
         def tiles(tbl):
             if tbl is None or tbl.shape[0] > 32 or tbl.shape[1] < self.SORT_MIN_ROWS:
+                return None
+            if tbl.shape[0] <= 8 and tbl.shape[1] < self.SORT_MIN_ROWS_K8:
                 return None
             return ops.kmap_sort(tbl, counts)
 
@@ -226,19 +231,21 @@ class MapPrefetcher:
     read-backs for longer than the maps take alone, and the step turns host-bound.  It is kept for
     loaders that run two batches ahead (submit from a worker thread); `bench.py --prefetch-maps`."""
 
-    def __init__(self, device, **prebuild_args):
+    def __init__(self, device, threaded=False, **prebuild_args):
+        """threaded: build on a worker thread, so that the caller never blocks on the pyramid's size read-backs (the
+        C calls release the GIL while they wait): submit() returns at once, take() joins the build."""
         self.device = torch.device(device)
         _lo, hi = torch.cuda.Stream.priority_range()
         self.stream = torch.cuda.Stream(self.device, priority=hi)
         self.prebuild_args = prebuild_args
+        self.threaded = bool(threaded)
+        self._pool = None
+        if self.threaded:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="osn-maps")
 
-    def submit(self, coordinates):
-        """`coordinates` int32 [N,4] must be complete on the CURRENT stream when this is called."""
-        if coordinates.dtype != torch.int32:
-            coordinates = coordinates.int()
-        main = torch.cuda.current_stream(self.device)
-        ready = torch.cuda.Event()
-        ready.record(main)
+    def _build(self, coordinates, ready):
+        torch.cuda.set_device(self.device)
         self.stream.wait_event(ready)
         coordinates.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
@@ -248,8 +255,19 @@ class MapPrefetcher:
             done.record(self.stream)
         return cm, done
 
+    def submit(self, coordinates):
+        """`coordinates` int32 [N,4] must be complete on the CURRENT stream when this is called."""
+        if coordinates.dtype != torch.int32:
+            coordinates = coordinates.int()
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        if self._pool is not None:
+            return self._pool.submit(self._build, coordinates, ready)
+        return self._build(coordinates, ready)
+
     def take(self, handle):
-        cm, done = handle
+        cm, done = handle.result() if hasattr(handle, "result") else handle
         main = torch.cuda.current_stream(self.device)
         main.wait_event(done)
         cm.record_stream(main)
