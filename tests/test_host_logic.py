@@ -208,6 +208,7 @@ def test_tile_ordered_maps_do_not_change_results(cpu_ops, monkeypatch):
     res = []
     for min_rows in (10 ** 9, 0):
         monkeypatch.setattr(CoordinateManager, "SORT_MIN_ROWS", min_rows)
+        monkeypatch.setattr(CoordinateManager, "SORT_MIN_ROWS_K8", min_rows)      # (2^3 maps are not ordered by default)
         model.zero_grad()
         st = SparseTensor(feats, coords)
         out = model(st)
