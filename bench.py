@@ -478,9 +478,28 @@ def main():
 
         fwd_ms = timed(infer, 10)
         maps_ms = timed(maps_only, 10)
+        # the same inference with the 1x1 head folded into the text matrix (no [N, 768] tensor)
+        from openscene_amd.query import query_distill_fused
+        gqf = torch.Generator().manual_seed(5)
+        inds_f = torch.randint(0, n_vox, (150000,), generator=gqf).to(device)
+        text_f = torch.nn.functional.normalize(torch.randn(20, out_dim, generator=gqf), dim=1).half().to(device)
+
+        def infer_unfused():
+            with torch.no_grad():
+                return query_distill(model(SparseTensor(feats, coords0)), text_f, inds_f)
+
+        def infer_fused():
+            with torch.no_grad():
+                f96, w_final = model.forward_features(SparseTensor(feats, coords0))
+                return query_distill_fused(f96, w_final, text_f, inds_f)
+
+        unf_ms, fus_ms = timed(infer_unfused, 10), timed(infer_fused, 10)
         extra = {"inference_fwd": {"ms": fwd_ms, "voxels_per_s": n_vox / (fwd_ms * 1e-3),
                                    "what": "configs[1]: maps + eval-mode forward, %d-d output" % out_dim},
-                 "maps_only": {"ms": maps_ms, "what": "coordinate pyramid + every kernel map + tile ordering of one scene"}}
+                 "maps_only": {"ms": maps_ms, "what": "coordinate pyramid + every kernel map + tile ordering of one scene"},
+                 "inference_plus_query": {"ms": unf_ms, "what": "maps + eval forward + 150 k-point / 20-label query (run/evaluate.py:283-292)"},
+                 "inference_plus_query_fused_head": {"ms": fus_ms, "what": "the same with the final 1x1 conv folded into the text "
+                                                     "matrix (SURVEY.md 8(f) row 2): no [N, %d] feature matrix" % out_dim}}
         gq = torch.Generator().manual_seed(5)
         n_pts = 150000
         inds_reverse = torch.randint(0, n_vox, (n_pts,), generator=gq).to(device)

@@ -29,3 +29,7 @@ class DisNet(nn.Module):
 
     def forward(self, sparse_3d):
         return self.net3d(sparse_3d)
+
+    def forward_features(self, sparse_3d):
+        """Penultimate features + the head weight, for the fused-head query (openscene_amd.query.query_distill_fused)."""
+        return self.net3d.forward_features(sparse_3d), self.net3d.final.kernel

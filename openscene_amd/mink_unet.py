@@ -86,7 +86,13 @@ class MinkUNetBase(nn.Module):
 
     def forward(self, x):
         with F_.deferred_bn_counters():
-            return self._forward(x)
+            return self.final(self._forward(x)).F
+
+    def forward_features(self, x):
+        """The input of the final 1x1 convolution (float32 [N_0, PLANES[7]], input row order): what
+        ``openscene_amd.query.query_distill_fused`` folds the head into."""
+        with F_.deferred_bn_counters():
+            return self._forward(x).F
 
     def _forward(self, x):
         x.coordinate_manager.prebuild()       # all level syncs first, then the host runs ahead of the GPU
@@ -101,7 +107,7 @@ class MinkUNetBase(nn.Module):
             out = self._conv_bn_relu(out, getattr(self, _UP[i]), getattr(self, "bntr%d" % (4 + i)))
             out = ME.cat(out, skips.pop())
             out = getattr(self, "block%d" % (5 + i))(out)
-        return self.final(out).F
+        return out
 
 
 def _variant(name, block, layers, planes):

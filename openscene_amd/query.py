@@ -34,3 +34,38 @@ def query_ensemble(predictions, feat_3d, text_features, inds_reverse=None, retur
     scores, labels, sel = ops.query_ensemble(predictions, feat_3d, text_features, inds_reverse, inds_reverse,
                                              want_scores=return_scores)
     return (labels, sel, scores) if return_scores else (labels, sel)
+
+
+def head_times_text(final_kernel, text_features):
+    """M = W_final @ text^T  (float32 [C_in, n_labels]): the 1x1 head of the network (models/mink_unet.py:108-113)
+    folded into the CLIP text matrix.  96 x 768 x n_labels multiply-adds -- done once per label set."""
+    return final_kernel.detach().float() @ text_features.float().t()
+
+
+def query_distill_fused(features, final_kernel, text_features, inds_reverse=None, return_scores=False):
+    """the distill-mode query with the head folded in,
+        labels = argmax_c  features[inds_reverse] @ (W_final @ text^T)
+    instead of  (features @ W_final)[inds_reverse].half() @ text^T  (models/mink_unet.py:174 + run/evaluate.py:288-292):
+    the [N, 768] feature matrix (310 MB per 100 k voxels) is neither written nor re-read.  `features` = the float32
+    [N_vox, 96] input of the final conv (``MinkUNetBase.forward_features``).  The contraction runs on the split-bf16
+    convolution kernel (K = 1), i.e. at fp32 accuracy: the scores differ from the reference's by the reference's OWN
+    fp16 rounding of the 768-d vector (<= 2e-3 absolute on O(1) scores, the same bound as the unfused path), and labels
+    agree wherever the reference's top-2 margin exceeds twice that.  Returns int64 labels [N_pts] (and float32 scores
+    [N_vox, n_labels] per VOXEL if return_scores)."""
+    import torch
+    M = head_times_text(final_kernel, text_features)                  # [96, C]
+    c = M.shape[1]
+    cp = (c + 3) // 4 * 4
+    if cp != c:
+        M = torch.cat([M, M.new_full((M.shape[0], cp - c), 0.0)], 1)
+    n = features.shape[0]
+    if ops.tl_eligible(1, M.shape[0], cp, n):
+        wf, _ = ops.weight_prep_tl(M.contiguous(), want_dgrad=False)
+        scores = ops.spconv_fwd_tl(features, wf, None, n, 1, cp)
+    else:
+        scores = ops.spconv_fwd(features, M.contiguous(), None, n)
+    scores = scores[:, :c]
+    labels = scores.argmax(1)
+    if inds_reverse is not None:
+        labels = labels[inds_reverse]
+    return (labels, scores) if return_scores else labels

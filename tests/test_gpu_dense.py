@@ -119,6 +119,42 @@ def test_query_scores_and_argmax(n_vox, n_pts, d, c):
     assert s2 is None and a2.shape[0] == n_vox
 
 
+def test_fused_head_query_matches_the_unfused_path():
+    """labels from features96 @ (W_final @ text^T) equal the labels of the reference expression
+    (model output [inds_reverse].half() @ text^T, run/evaluate.py:288-292) wherever the reference's top-2 margin exceeds
+    the fp16 rounding it applies to the 768-d vector; scores within that rounding (stated: 1e-3 * max(1, max|score|))."""
+    from openscene_amd.disnet import DisNet
+    from openscene_amd.query import query_distill_fused
+    from openscene_amd.sparse import SparseTensor
+    from openscene_amd import synthetic as syn
+
+    class Cfg:
+        arch_3d = "MinkUNet14A"
+        feature_2d_extractor = "openseg"
+    torch.manual_seed(3)
+    net = DisNet(Cfg()).to(dev()).eval()
+    coords = syn.batch_coords([syn.shuffled(syn.grid_voxels(syn.room_points(5, n_pts=9000), 0.05), 5)])
+    c = torch.from_numpy(coords).to(dev())
+    feats = torch.rand(coords.shape[0], 3, device=dev())
+    g = torch.Generator().manual_seed(1)
+    inds_reverse = torch.randint(0, coords.shape[0], (12000,), generator=g)
+    for n_labels in (20, 21, 160):
+        text = torch.nn.functional.normalize(torch.randn(n_labels, 768, generator=g), dim=1).half()
+        with torch.no_grad():
+            pred = net(SparseTensor(feats, c))
+            f96, w_final = net.forward_features(SparseTensor(feats, c))
+            labels, scores = query_distill_fused(f96, w_final, text.to(dev()), inds_reverse.to(dev()), return_scores=True)
+        assert f96.shape == (coords.shape[0], 96) and scores.shape == (coords.shape[0], n_labels)
+        ref_scores, ref_labels = oq.query(pred.cpu(), text, inds_reverse)
+        ref_scores = ref_scores.float()
+        tol = 1e-3 * max(1.0, ref_scores.abs().max().item())
+        assert (scores.cpu()[inds_reverse] - ref_scores).abs().max().item() <= tol
+        top2 = ref_scores.topk(2, dim=1)[0]
+        clear = (top2[:, 0] - top2[:, 1]) > 2 * tol
+        assert clear.float().mean().item() > 0.5
+        assert torch.equal(labels.cpu()[clear], ref_labels[clear])
+
+
 def test_query_ensemble():
     from openscene_amd import ops
     xd, t, gather = _query_inputs(3000, 5000, 768, 20, 1)

@@ -228,3 +228,21 @@ def test_gpu_resident_loader_matches_the_reference_loader(monkeypatch, golden_di
     cpu_backend.install(monkeypatch)
     d = loader_cases.load(golden_dir)
     loader_cases.check(d, loader_cases.run(d, torch.device("cpu"), split, eval_all, input_color), split, eval_all)
+
+
+def test_forward_features_is_the_input_of_the_final_conv(cpu_ops):
+    """MinkUNetBase.forward == final(forward_features): the fused-head query folds exactly
+    the last 1x1 convolution (models/mink_unet.py:108-113,174) and nothing else."""
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.query import head_times_text
+    from openscene_amd.sparse import SparseTensor
+    torch.manual_seed(9)
+    model = mink_unet(3, 24, 3, "MinkUNet14A").double().eval()
+    coords = cloud(4)
+    feats = torch.rand(coords.shape[0], 3, dtype=torch.float64)
+    out = model(SparseTensor(feats, coords))
+    f = model.forward_features(SparseTensor(feats, coords))
+    assert f.shape == (coords.shape[0], 96)
+    assert torch.allclose(out, f @ model.final.kernel, atol=1e-12)
+    text = torch.randn(5, 24, dtype=torch.float64)
+    assert torch.allclose(out @ text.t(), f @ head_times_text(model.final.kernel, text).double(), atol=1e-5)
