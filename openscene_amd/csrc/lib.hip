@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace osn
 
-extern "C" int osn_version(void) { return 1; }
+extern "C" int osn_version(void) { return 2; }
 
 extern "C" const char* osn_last_error(void) { return osn::g_err; }
 

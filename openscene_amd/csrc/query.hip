@@ -22,7 +22,7 @@ constexpr int Q_LD = Q_DK + 8;  // padded LDS row (144 B: 16-B aligned, conflict
 
 // sources: point p reads row g0[p] of X0 (or p if g0 null); if sel && sel[p], row g1[p] of X1.
 template <int CT>
-__global__ __launch_bounds__(256) void query_kernel(const float* __restrict__ X0, const int64_t* __restrict__ g0,
+__global__ __launch_bounds__(256, 2) void query_kernel(const float* __restrict__ X0, const int64_t* __restrict__ g0,
                                                     const float* __restrict__ X1, const int64_t* __restrict__ g1,
                                                     const uint8_t* __restrict__ sel, const float* __restrict__ rowdiv,
                                                     const _Float16* __restrict__ T, _Float16* __restrict__ scores,
