@@ -83,6 +83,10 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
+        # torch ships its own libamdhip64; it must be the HIP runtime this process binds to, so make sure it is loaded
+        # BEFORE dlopen resolves the library's dependency (loading ours first pulls /opt/rocm's copy: two runtimes in one
+        # process, and every HIP call from here then sees no device)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise OpenSceneAmdError(
                 "libopenscene_amd.so is not built (%s).  Build it with `python -m openscene_amd.build` "
