@@ -102,6 +102,13 @@ class LaunchProfiler:
         for name, m, e0, e1 in self.records:
             ms = e0.elapsed_time(e1)
             pairs = pair_counts.get((m["K"], m["n_out"]))
+            if pairs is None and m["K"] > 1:
+                # the per-step lattice shift changes the coarse levels' sizes by a few rows (floor-by-stride of shifted
+                # coordinates): take the surveyed map of the same K whose table size is nearest (within 3 %), scaled
+                near = [(abs(n - m["n_out"]), n) for (k, n) in pair_counts if k == m["K"]]
+                if near and min(near)[0] <= 0.03 * m["n_out"]:
+                    n0 = min(near)[1]
+                    pairs = int(round(pair_counts[(m["K"], n0)] * m["n_out"] / float(n0)))
             if pairs is None:
                 pairs = m["n_out"] if m["K"] == 1 else 0
             byts = 4.0 * (m["n_in"] * m["cin"] + m["n_out"] * m["cout"] + m["K"] * m["cin"] * m["cout"])
@@ -278,19 +285,33 @@ def cpu_baseline(seed, arch, out_dim):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
+    # thread count: the cgroup may grant fewer CPUs than the affinity mask shows and oversubscribed BLAS threads are far
+    # slower than one thread, so scan a short ladder (one step each) and keep the fastest
+    _cpu_step(seed, 15000, arch, out_dim)
+    ladder, best = {}, None
+    for t in (1, 4, 8, 16, 32, 64):
+        if t > cores:
+            break
+        torch.set_num_threads(t)
+        _cpu_step(seed, 4000, arch, out_dim)
+        n_t, dt_t = _cpu_step(seed, 15000, arch, out_dim)
+        ladder[t] = n_t / dt_t
+        if best is None or ladder[t] > ladder[best]:
+            best = t
+        elif ladder[t] < 0.5 * ladder[best]:
+            break
+    threads = best
     torch.set_num_threads(threads)
-    for _ in range(2):
-        _cpu_step(seed, 15000, arch, out_dim)
+    _cpu_step(seed, 15000, arch, out_dim)
     runs = sorted(_cpu_step(seed, 15000, arch, out_dim) for _ in range(5))
     n_small, dt_small = runs[2]
-    torch.set_num_threads(1)
-    n1, dt1 = _cpu_step(seed, 15000, arch, out_dim)
-    torch.set_num_threads(threads)
     res = {"value": n_small / dt_small, "unit": "voxels/s", "cores": threads, "kind": "port",
-           "sample": "median of 5 steps (after 2 warm-ups; maps + fwd + loss + bwd, fp32, no optimizer) of %s on a 1/8-size "
-                     "scene of the S100k generator: %d voxels in %.2f s with %d threads" % (arch, n_small, dt_small, threads),
-           "one_thread": {"value": n1 / dt1, "voxels": n1, "seconds": dt1}}
+           "sample": "median of 5 steps (after warm-ups; maps + fwd + loss + bwd, fp32, no optimizer) of %s on a 1/8-size "
+                     "scene of the S100k generator: %d voxels in %.2f s with %d threads (fastest of the thread ladder)"
+                     % (arch, n_small, dt_small, threads),
+           "cores_visible": cores,
+           "thread_ladder_voxels_per_s": {str(k): v for k, v in ladder.items()},
+           "one_thread": {"value": ladder[1], "voxels": n_small}}
     est_full = dt_small * (100999.0 / n_small)
     if est_full < 40.0:
         n, dt = _cpu_step(seed, 120000, arch, out_dim)

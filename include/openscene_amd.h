@@ -160,6 +160,28 @@ int osn_spconv_fwd_tl(const float* in, int64_t n_in, const void* Wp, const void*
                       float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm,
                       void* ws, size_t ws_bytes, osn_stream_t stream);
 
+/* ---- every weight image of a model in one launch ----------------------------------------------- *
+ * [ME] keeps one `kernel` parameter per MinkowskiConvolution / MinkowskiConvolutionTranspose
+ * (models/mink_unet.py:47-113, models/resnet_base.py:38-60); an optimizer step changes all of them at once.
+ * Instead of one osn_weight_prep_x6 / osn_weight_prep_tl launch per convolution and step, the host keeps a
+ * table of jobs in DEVICE memory (built once per model: pointers and shapes do not change) and one launch
+ * fills every image.  jobs[i].first_block = sum of osn_weight_prep_job_blocks(...) of the jobs before i,
+ * total_blocks = the sum over all jobs.  Image contents are identical to the per-weight entry points
+ * (layout OSN_PREP_X6: osn_weight_prep_x6(W, .., flip, for_dgrad); OSN_PREP_TL: the Wp_fwd (for_dgrad = 0)
+ * or Wp_dgrad (for_dgrad = 1) of osn_weight_prep_tl).                                                      */
+enum { OSN_PREP_X6 = 0, OSN_PREP_TL = 1 };
+typedef struct osn_prep_job {
+    const float* W;       /* [K][cin][cout] fp32 weight                                   */
+    void* out;            /* image: osn_weight_prep_x6_bytes / osn_weight_prep_tl_bytes    */
+    int64_t first_block;  /* exclusive prefix of the jobs' block counts                    */
+    int32_t K, cin, cout; /* weight shape                                                  */
+    int32_t flip;         /* mirror the offsets (input gradient of stride-1 odd kernels)   */
+    int32_t for_dgrad;    /* 1: image of the transposed weight                             */
+    int32_t layout;       /* OSN_PREP_X6 | OSN_PREP_TL                                     */
+} osn_prep_job;           /* 48 bytes */
+int64_t osn_weight_prep_job_blocks(int K, int cin, int cout, int for_dgrad, int layout);
+int osn_weight_prep_batch(const osn_prep_job* jobs_dev, int n_jobs, int64_t total_blocks, osn_stream_t stream);
+
 /* Which kernel instance / launch shape osn_spconv_fwd() uses for a problem (host helper, for
  * profiling): plan6 = {WM, WN, TN, BK, S (offset splits), workgroups};
  * the kernel symbol is spconv_fwd_kernel<WM, WN, TN, BK>.                          */

@@ -21,7 +21,8 @@ constexpr int Q_DK = 64;    // feature chunk
 constexpr int Q_LD = Q_DK + 8;  // padded LDS row (144 B: 16-B aligned, conflict-free ds_read_b128)
 
 // sources: point p reads row g0[p] of X0 (or p if g0 null); if sel && sel[p], row g1[p] of X1.
-template <int CT>
+// DEEP: two chunks of point rows in flight (64 more registers; fits CT <= 2), else one.
+template <int CT, bool DEEP>
 __global__ __launch_bounds__(256, 2) void query_kernel(const float* __restrict__ X0, const int64_t* __restrict__ g0,
                                                     const float* __restrict__ X1, const int64_t* __restrict__ g1,
                                                     const uint8_t* __restrict__ sel, const float* __restrict__ rowdiv,
@@ -30,30 +31,34 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const float* __restrict__
                                                     int64_t n, int d, int c) {
     __shared__ __attribute__((aligned(16))) _Float16 Xs[Q_BM][Q_LD];
     __shared__ __attribute__((aligned(16))) _Float16 Ts[CT * 32][Q_LD];
-    __shared__ const float* rowptr[Q_BM];
+    // byte offset of every point's source row RELATIVE TO X0 (also for rows of X1): the gathers then stay X0-based
+    // global loads.  (A pointer fetched from LDS has lost its address space: the loads become FLAT, which also count on
+    // the LDS counter, and every LDS wait of the MFMA loop would drain the prefetched rows.)
+    __shared__ int64_t rowoff[Q_BM];
     __shared__ float rowden[Q_BM];
+    __shared__ float bestv_s[Q_BM];      // running row maximum / its column over the column groups (first maximum wins)
+    __shared__ int besti_s[Q_BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row0 = int64_t(blockIdx.x) * Q_BM;
 
     if (tid < Q_BM) {
         const int64_t p = row0 + tid;
-        const float* ptr = nullptr;
+        int64_t off = -1;                                   // -1: no such point
         float den = 1.f;
         if (p < n) {
-            if (sel && sel[p]) ptr = X1 + (g1 ? g1[p] : p) * int64_t(d);
-            else ptr = X0 + (g0 ? g0[p] : p) * int64_t(d);
+            if (sel && sel[p])
+                off = int64_t(reinterpret_cast<uintptr_t>(X1) - reinterpret_cast<uintptr_t>(X0)) + (g1 ? g1[p] : p) * int64_t(d) * 4;
+            else
+                off = (g0 ? g0[p] : p) * int64_t(d) * 4;
             if (rowdiv) den = rowdiv[p];
         }
-        rowptr[tid] = ptr;
+        rowoff[tid] = off;
         rowden[tid] = den;
+        bestv_s[tid] = -INFINITY;
+        besti_s[tid] = 0x7fffffff;
     }
     __syncthreads();
-
-    float bestv[16];
-    int besti[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { bestv[r] = -INFINITY; besti[r] = 0x7fffffff; }
 
     for (int cg0 = 0; cg0 < c; cg0 += 32 * CT) {
         f32x16 acc[CT];
@@ -62,18 +67,24 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-        // software pipeline over the feature chunks: the rows / text of chunk i+1 are loaded into
-        // registers (unconditional loads from clamped addresses) while the MFMAs of chunk i run
-        float4 px[Q_BM / 16];
+        // software pipeline over the feature chunks, TWO chunks of point rows in flight: while the MFMAs of chunk i run
+        // from LDS, the rows of chunk i+1 are already on their way (issued one iteration ago) and the rows of chunk
+        // i+2 are issued now -- the kernel is bound by bytes in flight x latency (random 256-byte segments), and the
+        // register file is the largest buffer a CU has (2 x 32 KB per workgroup).  The text chunk i+1 (L2-resident) is
+        // issued BEFORE the rows of chunk i+2, so that waiting for it does not drain the younger row loads
+        // (the memory counter retires in order).  All loads are unconditional from clamped addresses.
+        float4 pxa[Q_BM / 16], pxb[Q_BM / 16];
         uint4 pt[CT];
         const int xq = tid & 15, xr = tid >> 4;
-        auto fetch = [&](int d0) {
+        auto fetch_x = [&](int d0, float4 (&px)[Q_BM / 16]) {
 #pragma unroll
             for (int ps = 0; ps < Q_BM / 16; ++ps) {
-                const float* src = rowptr[ps * 16 + xr];
-                const bool ok = src != nullptr && d0 + xq * 4 < d;
-                px[ps] = *reinterpret_cast<const float4*>(ok ? src + d0 + xq * 4 : X0);
+                const int64_t off = rowoff[ps * 16 + xr];
+                const bool ok = row0 + ps * 16 + xr < n && d0 + xq * 4 < d;
+                px[ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X0) + (ok ? off + (d0 + xq * 4) * 4 : 0));
             }
+        };
+        auto fetch_t = [&](int d0) {
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
                 const int f = tid + 256 * j;
@@ -83,11 +94,11 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const float* __restrict__
                 pt[j] = *reinterpret_cast<const uint4*>(ok ? T + int64_t(col) * d + d0 + ch * 8 : T);
             }
         };
-        auto stash = [&](int d0) {
+        auto stash = [&](int d0, float4 (&px)[Q_BM / 16]) {
 #pragma unroll
             for (int ps = 0; ps < Q_BM / 16; ++ps) {
                 const int row = ps * 16 + xr;
-                const bool ok = rowptr[row] != nullptr && d0 + xq * 4 < d;
+                const bool ok = row0 + row < n && d0 + xq * 4 < d;
                 float4 v = px[ps];
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (rowdiv) {
@@ -108,12 +119,7 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const float* __restrict__
                 *reinterpret_cast<uint4*>(&Ts[trow][ch * 8]) = v;
             }
         };
-        fetch(0);
-        stash(0);
-        __syncthreads();
-        for (int d0 = 0; d0 < d; d0 += Q_DK) {
-            const bool more = d0 + Q_DK < d;
-            if (more) fetch(d0 + Q_DK);
+        auto mfmas = [&]() {
             const int arow = wave * 32 + (lane & 31);
             const int kh = 8 * (lane >> 5);
 #pragma unroll
@@ -125,11 +131,46 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const float* __restrict__
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
                 }
             }
-            __syncthreads();
-            if (more) stash(d0 + Q_DK);
-            __syncthreads();
+        };
+        fetch_x(0, pxa);
+        fetch_t(0);
+        if (DEEP && Q_DK < d) fetch_x(Q_DK, pxb);
+        stash(0, pxa);
+        __syncthreads();
+        if (DEEP) {
+            for (int d0 = 0; d0 < d; d0 += 2 * Q_DK) {
+                // ---- even chunk d0 in LDS; pxb = chunk d0 + 64 (in flight); issue text d0 + 64, rows d0 + 128 -> pxa
+                if (d0 + Q_DK < d) fetch_t(d0 + Q_DK);
+                if (d0 + 2 * Q_DK < d) fetch_x(d0 + 2 * Q_DK, pxa);
+                mfmas();
+                __syncthreads();
+                if (d0 + Q_DK >= d) break;
+                stash(d0 + Q_DK, pxb);
+                __syncthreads();
+                // ---- odd chunk d0 + 64 in LDS; pxa = chunk d0 + 128 (in flight); issue text d0 + 128, rows d0 + 192 -> pxb
+                if (d0 + 2 * Q_DK < d) fetch_t(d0 + 2 * Q_DK);
+                if (d0 + 3 * Q_DK < d) fetch_x(d0 + 3 * Q_DK, pxb);
+                mfmas();
+                __syncthreads();
+                if (d0 + 2 * Q_DK < d) stash(d0 + 2 * Q_DK, pxa);
+                __syncthreads();
+            }
+        } else {
+            for (int d0 = 0; d0 < d; d0 += Q_DK) {
+                const bool more = d0 + Q_DK < d;
+                if (more) { fetch_t(d0 + Q_DK); fetch_x(d0 + Q_DK, pxa); }
+                mfmas();
+                __syncthreads();
+                if (more) stash(d0 + Q_DK, pxa);
+                __syncthreads();
+            }
         }
-        // ---- group epilogue: round to fp16, optional store, running argmax
+        // ---- group epilogue: round to fp16, optional store, row argmax of the group merged into the running one
+        // (kept in LDS between groups: 32 registers less in the main loop; a thread always owns the same rows)
+        float bestv[16];
+        int besti[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { bestv[r] = -INFINITY; besti[r] = 0x7fffffff; }
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
             const int col = cg0 + t * 32 + (lane & 31);
@@ -144,25 +185,30 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const float* __restrict__
                 }
             }
         }
-    }
-    // ---- reduce over the 32 lanes that hold one row's columns
+        // reduce over the 32 lanes that hold one row's columns
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float v = bestv[r];
-        int i = besti[r];
+        for (int r = 0; r < 16; ++r) {
+            float v = bestv[r];
+            int i = besti[r];
 #pragma unroll
-        for (int m = 1; m < 32; m <<= 1) {
-            const float ov = __shfl_xor(v, m, 64);
-            const int oi = __shfl_xor(i, m, 64);
-            if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-        }
-        if ((lane & 31) == 0) {
-            const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < n) {
-                if (argmax) argmax[row] = (i == 0x7fffffff) ? 0 : i;
-                if (rowmax) rowmax[row] = v;
+            for (int m = 1; m < 32; m <<= 1) {
+                const float ov = __shfl_xor(v, m, 64);
+                const int oi = __shfl_xor(i, m, 64);
+                if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+            }
+            if ((lane & 31) == 0) {
+                const int lrow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float pv = bestv_s[lrow];
+                const int pi = besti_s[lrow];
+                if (v > pv || (v == pv && i < pi)) { bestv_s[lrow] = v; besti_s[lrow] = i; }
             }
         }
+    }
+    __syncthreads();
+    if (tid < Q_BM && row0 + tid < n) {
+        const int i = besti_s[tid];
+        if (argmax) argmax[row0 + tid] = (i == 0x7fffffff) ? 0 : i;
+        if (rowmax) rowmax[row0 + tid] = bestv_s[tid];
     }
 }
 
@@ -195,13 +241,13 @@ static int launch_query(hipStream_t st, const float* X0, const int64_t* g0, cons
     const dim3 grid(cdiv(n, Q_BM)), block(256);
     const int ct = int(cdiv(c, 32));
     if (ct <= 1)
-        hipLaunchKernelGGL((query_kernel<1>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
+        hipLaunchKernelGGL((query_kernel<1, true>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
     else if (ct <= 2)
-        hipLaunchKernelGGL((query_kernel<2>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
+        hipLaunchKernelGGL((query_kernel<2, true>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
     else if (ct <= 3)
-        hipLaunchKernelGGL((query_kernel<3>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
+        hipLaunchKernelGGL((query_kernel<3, false>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
     else
-        hipLaunchKernelGGL((query_kernel<5>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
+        hipLaunchKernelGGL((query_kernel<5, false>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
 }

@@ -19,6 +19,7 @@
 //     loop across workgroups (deterministic partial buffers + ordered reduce) so
 //     the launch still covers the 256 CUs.
 #include "common.h"
+#include "weight_prep.h"
 #include <stdlib.h>
 
 namespace osn {
@@ -760,30 +761,6 @@ __global__ void fixup_units_kernel(const float* __restrict__ extra, const int32_
         for (int p = 1; p < np; ++p) s += extra[int64_t(p - 1) * total + e];
         out[o] = s;
     }
-}
-
-// Wp[plane][k][n][c] (bf16, c padded to cp with zeros) = piece `plane` of the weight that multiplies input
-// channel c into output channel n at offset k:  forward  W[k][c][n];  input gradient  W[flip ? K-1-k : k][n][c].
-__device__ __forceinline__ void weight_prep_x6_one(const float* __restrict__ W, int K, int cin, int cout, int flip,
-                                                    int for_dgrad, int64_t e, __bf16* __restrict__ Wp) {
-    const int nn = for_dgrad ? cin : cout, nc = for_dgrad ? cout : cin;
-    const int cp = (nc + 31) / 32 * 32;
-    const int64_t per_plane = int64_t(K) * nn * cp;
-    const int c = int(e % cp);
-    const int n = int((e / cp) % nn);
-    const int k = int(e / (int64_t(cp) * nn));
-    float v = 0.f;
-    if (c < nc) {
-        const int ks = flip ? K - 1 - k : k;
-        v = for_dgrad ? W[(int64_t(ks) * cin + n) * cout + c] : W[(int64_t(ks) * cin + c) * cout + n];
-    }
-    const __bf16 h1 = (__bf16)v;
-    const float r1 = v - (float)h1;
-    const __bf16 h2 = (__bf16)r1;
-    const float r2 = r1 - (float)h2;
-    Wp[e] = h1;
-    Wp[per_plane + e] = h2;
-    Wp[2 * per_plane + e] = (__bf16)r2;
 }
 
 // One launch fills the forward planes (Wf, nullable) and/or the input-gradient planes (Wb, nullable).

@@ -30,6 +30,7 @@
 // Arithmetic: "bf16x6" -- x = x1 + x2 + x3 (bf16 pieces), a*b ~= a3b1 + a2b2 + a1b3 + a2b1 + a1b2 + a1b1
 // accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (dropped terms <= 2^-24 relative): fp32-class accuracy.
 #include "common.h"
+#include "weight_prep.h"
 
 namespace osn {
 
@@ -88,39 +89,6 @@ __global__ __launch_bounds__(256) void tile_lists_kernel(const int32_t* __restri
 }
 
 // ------------------------------------------------------------------------------------- weight prep
-// MFMA-ready image of a weight: Wp[plane][k][s][cb][lane][8] bf16, one 1 KB block per (k, 32-deep k-step s,
-// 16-column block cb, plane); lane l of a wave holds the B fragment of v_mfma_f32_16x16x32_bf16:
-//   element e of lane l = piece `plane` of  B[c = 32 s + 8 (l >> 4) + e][n = 16 cb + (l & 15)]
-// with B[c][n] = W[k][c][n] (forward) or W[flip ? K-1-k : k][n][c] (input gradient: contraction over the
-// conv's OUTPUT channels).  Channels / columns beyond the real ones are zero.
-__device__ __forceinline__ void weight_prep_tl_one(const float* __restrict__ W, int K, int cin, int cout, int flip,
-                                                    int for_dgrad, int64_t e, __bf16* __restrict__ Wp) {
-    const int nc = for_dgrad ? cout : cin;     // contraction length
-    const int nn = for_dgrad ? cin : cout;     // columns of B
-    const int ns = (nc + 31) >> 5, ncb = (nn + 15) >> 4;
-    const int64_t per_plane = int64_t(K) * ns * ncb * 512;
-    const int el = int(e & 7);
-    const int lane = int((e >> 3) & 63);
-    int64_t blk = e >> 9;
-    const int cb = int(blk % ncb); blk /= ncb;
-    const int s = int(blk % ns);
-    const int k = int(blk / ns);
-    const int c = 32 * s + 8 * (lane >> 4) + el;
-    const int n = 16 * cb + (lane & 15);
-    float v = 0.f;
-    if (c < nc && n < nn) {
-        const int ks = flip ? K - 1 - k : k;
-        v = for_dgrad ? W[(int64_t(ks) * cin + n) * cout + c] : W[(int64_t(ks) * cin + c) * cout + n];
-    }
-    const __bf16 h1 = (__bf16)v;
-    const float r1 = v - (float)h1;
-    const __bf16 h2 = (__bf16)r1;
-    const float r2 = r1 - (float)h2;
-    Wp[e] = h1;
-    Wp[per_plane + e] = h2;
-    Wp[2 * per_plane + e] = (__bf16)r2;
-}
-
 __global__ void weight_prep_tl_kernel(const float* __restrict__ W, int K, int cin, int cout, int flip_b, int64_t per_plane_f,
                                       int64_t per_plane_b, __bf16* __restrict__ Wf, __bf16* __restrict__ Wb) {
     const int64_t total = per_plane_f + per_plane_b;

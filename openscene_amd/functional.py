@@ -19,6 +19,10 @@ from . import ops
 #   "fp32"   the same kernel on v_mfma_f32_32x32x2_f32 (exact fp32 products, 157 TF peak)
 CONV_MODE = os.environ.get("OSN_CONV_MODE", "tl")
 TL_FWD_MIN_ROWS = int(os.environ.get("OSN_TL_FWD_MIN_ROWS", "65536"))
+# Backward of a convolution on a map of at most this many rows: the weight gradient (plan + kernel + reduce) runs on an
+# auxiliary stream beside the input gradient (+ its reduce) -- both chains are latency-bound there and neither fills the
+# chip; the node forks after `gout` is ready and joins before it returns, so nothing outside sees the second stream.
+WGRAD_OVERLAP_MAX_ROWS = int(os.environ.get("OSN_WGRAD_OVERLAP_MAX_ROWS", "40000"))
 
 
 class SparseConvFunction(Function):
@@ -49,17 +53,17 @@ class SparseConvFunction(Function):
             fwd_ok = lists_fwd is not None and n_out >= TL_FWD_MIN_ROWS
             bwd_ok = (ctx.needs_input_grad[0] and ops.tl_eligible(K, cout, cin, n_out) and lists_bwd is not None
                       and ctx.n_in >= TL_FWD_MIN_ROWS)
-            if fwd_ok or bwd_ok:
-                wf, wb = ops.weight_prep_tl(kernel, flip, want_fwd=fwd_ok, want_dgrad=bwd_ok)
-                if bwd_ok:
-                    ctx.wp_dgrad, ctx.tl_bwd = wb, lists_bwd
-                if fwd_ok:
-                    return ops.spconv_fwd_tl(feats, wf, lists_fwd, n_out, K, cout)
+            # weight images: parameters are served from ops' per-device cache (one launch per optimizer step for the
+            # whole model); the input-gradient image is requested here too so that it is part of that launch
+            wf = ops.weight_image(kernel, False, False, ops.PREP_TL) if fwd_ok else None
+            if bwd_ok:
+                ctx.wp_dgrad, ctx.tl_bwd = ops.weight_image(kernel, flip, True, ops.PREP_TL), lists_bwd
+            if fwd_ok:
+                return ops.spconv_fwd_tl(feats, wf, lists_fwd, n_out, K, cout)
         if mode == "bf16x6" and ops.x6_eligible(K, cin, cout, n_out):
+            wp = ops.weight_image(kernel, False, False, ops.PREP_X6)
             if ctx.needs_input_grad[0] and ctx.tl_bwd is None and ops.x6_eligible(K, cout, cin, ctx.n_in):
-                wp, ctx.wp_dgrad = ops.weight_prep_x6_pair(kernel, flip)     # both layouts, one launch
-            else:
-                wp = ops.weight_prep_x6(kernel)
+                ctx.wp_dgrad = ops.weight_image(kernel, flip, True, ops.PREP_X6)
             return ops.spconv_fwd_x6(feats, wp, tbl, n_out, out_rows=rows, gmask=gm)
         return ops.spconv_fwd(feats, kernel, tbl, n_out, out_rows=rows, gmask=gm)
 
@@ -70,6 +74,25 @@ class SparseConvFunction(Function):
         gout = gout.contiguous()
         gin = gk = None
         K = 1 if kernel.dim() == 2 else kernel.shape[0]
+
+        def weight_grad():
+            cin, cout = kernel.shape[-2], kernel.shape[-1]
+            tl, swap = ctx.wg_lists
+            if CONV_MODE == "tl" and K > 1 and tl is not None and ops.tl_eligible(K, cin, cout, ctx.n_in):
+                return ops.spconv_wgrad_tl(feats, gout, tl, K, swap=swap).reshape(kernel.shape)
+            return ops.spconv_wgrad(feats, gout, nbr_fwd, K, counts).reshape(kernel.shape)
+
+        side = None
+        if ctx.needs_input_grad[1]:
+            if (ctx.needs_input_grad[0] and gout.is_cuda
+                    and max(ctx.n_in, gout.shape[0]) <= WGRAD_OVERLAP_MAX_ROWS):
+                main = torch.cuda.current_stream(gout.device)
+                side = ops.side_stream(gout.device)
+                side.wait_stream(main)                    # fork: gout (and everything before it) is ready
+                with ops.on_stream(side):
+                    gk = weight_grad()
+            else:
+                gk = weight_grad()
         if ctx.needs_input_grad[0]:
             cin, cout = kernel.shape[-2], kernel.shape[-1]
             tbl, rows, gm = (tiles_bwd[1], tiles_bwd[0], tiles_bwd[2]) if tiles_bwd is not None else (nbr_bwd, None, None)
@@ -78,18 +101,13 @@ class SparseConvFunction(Function):
                 gin = ops.spconv_fwd_tl(gout, ctx.wp_dgrad, ctx.tl_bwd, ctx.n_in, K, cin)
                 ctx.wp_dgrad = ctx.tl_bwd = None
             elif mode == "bf16x6" and ops.x6_eligible(K, cout, cin, ctx.n_in):
-                wp = ctx.wp_dgrad if ctx.wp_dgrad is not None else ops.weight_prep_x6(kernel, flip=flip, for_dgrad=True)
+                wp = ctx.wp_dgrad if ctx.wp_dgrad is not None else ops.weight_image(kernel, flip, True, ops.PREP_X6)
                 ctx.wp_dgrad = None
                 gin = ops.spconv_fwd_x6(gout, wp, tbl, ctx.n_in, out_rows=rows, gmask=gm)
             else:
                 gin = ops.spconv_fwd(gout, ops.weight_transpose(kernel, flip), tbl, ctx.n_in, out_rows=rows, gmask=gm)
-        if ctx.needs_input_grad[1]:
-            cin, cout = kernel.shape[-2], kernel.shape[-1]
-            tl, swap = ctx.wg_lists
-            if CONV_MODE == "tl" and K > 1 and tl is not None and ops.tl_eligible(K, cin, cout, ctx.n_in):
-                gk = ops.spconv_wgrad_tl(feats, gout, tl, K, swap=swap).reshape(kernel.shape)
-            else:
-                gk = ops.spconv_wgrad(feats, gout, nbr_fwd, K, counts).reshape(kernel.shape)
+        if side is not None:
+            main.wait_stream(side)                        # join: later work on this stream sees the weight gradient
         return gin, gk, None, None, None, None, None, None, None, None, None, None
 
 

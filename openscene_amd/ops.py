@@ -3,6 +3,7 @@ pass raw device pointers and the current HIP stream.  No autograd here (see
 functional.py) and no CPU fallback."""
 import ctypes
 import os
+import threading
 import weakref
 
 import torch
@@ -30,6 +31,13 @@ _raw_stream_of = torch._C._cuda_getCurrentRawStream      # device index -> curre
 _current_device = torch._C._cuda_getDevice
 
 
+def _prof_start(kind, dev, **meta):
+    # the profiler brackets torch's current stream: launches redirected by on_stream() are not bracketed
+    if _profiler is None or getattr(_tls, "stream", None) is not None:
+        return None
+    return _profiler.start(kind, dev, **meta)
+
+
 def _p(t):
     return t.data_ptr() if t is not None else None       # ctypes converts the int to void* (argtypes are set)
 
@@ -39,8 +47,41 @@ def _idx(dev):
     return i if i is not None else _current_device()
 
 
+_tls = threading.local()
+
+
 def _stream(dev):
-    return _raw_stream_of(_idx(dev))
+    s = getattr(_tls, "stream", None)
+    return s if s is not None else _raw_stream_of(_idx(dev))
+
+
+class on_stream:
+    """Context: the C-ABI calls of this thread launch on `stream` (a torch.cuda.Stream) instead of torch's current
+    stream -- without touching torch's stream state, so tensors are still allocated from the current stream's pool.
+    The caller orders the two streams (functional.py forks / joins around the weight gradient)."""
+    __slots__ = ("raw", "prev")
+
+    def __init__(self, stream):
+        self.raw = stream.cuda_stream
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "stream", None)
+        _tls.stream = self.raw
+
+    def __exit__(self, *a):
+        _tls.stream = self.prev
+
+
+_side_streams = {}
+
+
+def side_stream(dev):
+    """One auxiliary HIP stream per device (created on first use)."""
+    i = _idx(dev)
+    s = _side_streams.get(i)
+    if s is None:
+        s = _side_streams[i] = torch.cuda.Stream(device=i)
+    return s
 
 
 # Scratch for the C-ABI calls: ONE growing buffer per (device, stream).  Every call's scratch is only
@@ -52,7 +93,7 @@ _ws_pool = {}
 def _ws(nbytes, dev):
     nbytes = max(int(nbytes), 16)
     i = _idx(dev)
-    key = (i, _raw_stream_of(i))
+    key = (i, _stream(dev))
     buf = _ws_pool.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
@@ -228,8 +269,7 @@ def spconv_fwd(feats, weight, nbr, n_out, out_rows=None, gmask=None):
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
     wsb = _cached("osn_spconv_fwd_ws_bytes", n_out, K, cin, cout)
     ws = _ws(wsb, dev) if wsb else None
-    tok = _profiler.start("spconv_fwd", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
-        if _profiler is not None else None
+    tok = _prof_start("spconv_fwd", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout)
     with _Dev(dev):
         check(lib.osn_spconv_fwd(_p(feats), _p(w), _p(nbr), _p(out_rows), _p(gmask), _p(out), n_out, K, cin, cout,
                                  _p(ws), int(wsb), _stream(dev)), "osn_spconv_fwd")
@@ -285,8 +325,7 @@ def spconv_fwd_x6(feats, wp, nbr, n_out, out_rows=None, gmask=None):
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
     wsb = _cached("osn_spconv_fwd_ws_bytes", n_out, K, cin, cout)
     ws = _ws(wsb, dev) if wsb else None
-    tok = _profiler.start("spconv_fwd_x6", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
-        if _profiler is not None else None
+    tok = _prof_start("spconv_fwd_x6", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout)
     with _Dev(dev):
         check(lib.osn_spconv_fwd_x6(_p(feats), _p(wp), _p(nbr), _p(out_rows), _p(gmask), _p(out), n_out, K, cin, cout,
                                     _p(ws), int(wsb), _stream(dev)), "osn_spconv_fwd_x6")
@@ -357,6 +396,108 @@ def weight_prep_tl(weight, flip=False, want_fwd=True, want_dgrad=True):
     return wf, wb
 
 
+# ------------------------------------------------- weight images of model parameters: one launch per optimizer step
+# A convolution weight that is an nn.Parameter keeps its images (forward / input gradient, plane or fragment layout)
+# between calls, keyed on the parameter's version counter: an optimizer step bumps every version, the first
+# convolution of the next forward then refreshes ALL images of the device in one osn_weight_prep_batch launch (the job
+# table lives in device memory and is reused while the set of stale images is the same); in eval mode nothing is
+# launched.  Anything that changes a parameter without bumping its version (writes through `.data` / raw pointers)
+# must call clear_weight_cache().  OSN_WEIGHT_CACHE=0 switches the cache off (one prep launch per convolution).
+WEIGHT_CACHE = os.environ.get("OSN_WEIGHT_CACHE", "1") != "0"
+PREP_X6, PREP_TL = 0, 1
+
+
+class _Image:
+    __slots__ = ("ref", "ptr", "version", "image", "K", "cin", "cout", "flip", "for_dgrad", "layout", "blocks")
+
+
+class _WeightImages:
+    def __init__(self):
+        self.entries = {}          # (id(param), flip, for_dgrad, layout) -> _Image
+        self.table = None          # (tuple of entry keys, job table on the device, total blocks)
+        self.keep = []             # recent job tables (their launches may still be queued)
+        self.lock = threading.Lock()
+
+
+_weight_images = {}
+
+
+def clear_weight_cache():
+    _weight_images.clear()
+
+
+def _alloc_image(K, cin, cout, for_dgrad, layout, dev):
+    if layout == PREP_TL:
+        return torch.empty(_cached("osn_weight_prep_tl_bytes", K, cin, cout, int(for_dgrad)), dtype=torch.uint8, device=dev)
+    nn, nc = (cin, cout) if for_dgrad else (cout, cin)
+    return torch.empty((3, K, nn, (nc + 31) // 32 * 32), dtype=torch.bfloat16, device=dev)
+
+
+def _refresh_images(imgs, lib, dev):
+    import numpy as np
+    stale, keys = [], []
+    for key, e in list(imgs.entries.items()):
+        p = e.ref()
+        if p is None:
+            del imgs.entries[key]
+            continue
+        if e.version != p._version or e.ptr != p.data_ptr():
+            stale.append((e, p))
+            keys.append(key)
+    if not stale:
+        return
+    keys = tuple(keys)
+    tbl = imgs.table
+    if tbl is None or tbl[0] != keys or any(e.ptr != p.data_ptr() for e, p in stale):
+        jobs = np.zeros(len(stale), dtype=[("W", "<u8"), ("out", "<u8"), ("first", "<i8"), ("K", "<i4"), ("cin", "<i4"),
+                                           ("cout", "<i4"), ("flip", "<i4"), ("dg", "<i4"), ("layout", "<i4")])
+        first = 0
+        for i, (e, p) in enumerate(stale):
+            e.ptr = p.data_ptr()
+            jobs[i] = (e.ptr, e.image.data_ptr(), first, e.K, e.cin, e.cout, e.flip, e.for_dgrad, e.layout)
+            first += e.blocks
+        tbl = (keys, torch.from_numpy(jobs.view(np.uint8)).to(dev), first)
+        imgs.table = tbl
+        imgs.keep = (imgs.keep + [tbl[1]])[-8:]
+    with _Dev(dev):
+        check(lib.osn_weight_prep_batch(_p(tbl[1]), len(stale), tbl[2], _stream(dev)), "osn_weight_prep_batch")
+    for e, p in stale:
+        e.version = p._version
+
+
+def weight_image(weight, flip=False, for_dgrad=False, layout=PREP_X6):
+    """Image of `weight` for spconv_fwd_x6 (layout PREP_X6) or spconv_fwd_tl (PREP_TL); for_dgrad: the image the input
+    gradient multiplies with (transposed, offsets mirrored if flip).  Parameters are served from the per-device cache
+    (see above), other tensors are prepared on the spot."""
+    flip, for_dgrad = bool(flip), bool(for_dgrad)
+    cacheable = (WEIGHT_CACHE and isinstance(weight, torch.nn.Parameter) and weight.dtype == torch.float32
+                 and weight.is_contiguous())
+    if not cacheable:
+        if layout == PREP_TL:
+            wf, wb = weight_prep_tl(weight, flip, want_fwd=not for_dgrad, want_dgrad=for_dgrad)
+            return wb if for_dgrad else wf
+        return weight_prep_x6(weight, flip=flip, for_dgrad=for_dgrad)
+    dev = weight.device
+    lib = _prep(dev)
+    imgs = _weight_images.get(dev)
+    if imgs is None:
+        imgs = _weight_images[dev] = _WeightImages()
+    key = (id(weight), flip, for_dgrad, layout)
+    with imgs.lock:
+        e = imgs.entries.get(key)
+        if e is None or e.ref() is not weight:
+            K, cin, cout = _w3(weight).shape
+            e = _Image()
+            e.ref, e.ptr, e.version = weakref.ref(weight), 0, -1
+            e.K, e.cin, e.cout, e.flip, e.for_dgrad, e.layout = K, cin, cout, int(flip), int(for_dgrad), layout
+            e.blocks = _cached("osn_weight_prep_job_blocks", K, cin, cout, int(for_dgrad), layout)
+            e.image = _alloc_image(K, cin, cout, for_dgrad, layout, dev)
+            imgs.entries[key] = e
+        if e.version != weight._version or e.ptr != weight.data_ptr():
+            _refresh_images(imgs, lib, dev)
+        return e.image
+
+
 def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
     """out[o] = sum_k feats[list rows] @ B[k] with B given as a weight_prep_tl image; tl None <=> K == 1 identity.
     bn_partial: optional float64 [n_tiles, 2, cout] receiving per-tile column sums / sums of squares."""
@@ -377,8 +518,7 @@ def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
         raise ValueError("prepared weight has %d bytes, a [%d, %d, %d] conv needs %d" % (wp.numel(), K, cin, cout, need))
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
     ws = _ws(_cached("osn_spconv_fwd_tl_ws_bytes", n_out, K if tl is not None else 1, cout, bm), dev)
-    tok = _profiler.start("spconv_fwd_tl", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
-        if _profiler is not None else None
+    tok = _prof_start("spconv_fwd_tl", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout)
     with _Dev(dev):
         check(lib.osn_spconv_fwd_tl(_p(feats), feats.shape[0], _p(wp), _p(buf), _p(rows), _p(out), _p(bn_partial), n_out,
                                     K, cin, cout, bm, _p(ws), ws.numel(), _stream(dev)), "osn_spconv_fwd_tl")
@@ -434,8 +574,7 @@ def spconv_wgrad_tl(feats, gout, tl, K, swap=False):
     gw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
     wsb = _cached("osn_spconv_wgrad_tl_ws_bytes", K, cin, cout)
     ws = _ws(wsb, dev)
-    tok = _profiler.start("spconv_wgrad_tl", dev, n_in=n_in, n_out=n_out, K=K, cin=cin, cout=cout) \
-        if _profiler is not None else None
+    tok = _prof_start("spconv_wgrad_tl", dev, n_in=n_in, n_out=n_out, K=K, cin=cin, cout=cout)
     with _Dev(dev):
         check(lib.osn_spconv_wgrad_tl(_p(feats), _p(gout), _p(pl), int(bool(swap)), _p(gw), n_in, n_out, K, cin, cout,
                                       _p(ws), ws.numel(), _stream(dev)), "osn_spconv_wgrad_tl")
@@ -458,8 +597,7 @@ def stem_conv_fwd(feats, weight, nbr, n_out):
     if nbr.dtype != torch.int32 or nbr.shape != (K, n_out):
         raise ValueError("nbr must be int32 [%d, %d], got %s %s" % (K, n_out, nbr.dtype, tuple(nbr.shape)))
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
-    tok = _profiler.start("stem_fwd", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
-        if _profiler is not None else None
+    tok = _prof_start("stem_fwd", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout)
     with _Dev(dev):
         check(lib.osn_stem_conv_fwd(_p(feats), _p(w), _p(nbr.contiguous()), _p(out), n_out, K, cin, cout, _stream(dev)),
               "osn_stem_conv_fwd")
@@ -528,8 +666,7 @@ def spconv_wgrad(feats, gout, nbr, K, counts=None):
     gw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
     wsb = _cached("osn_spconv_wgrad_ws_bytes", n_out, K, cin, cout)
     ws = _ws(wsb, dev) if wsb else None
-    tok = _profiler.start("spconv_wgrad", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout) \
-        if _profiler is not None else None
+    tok = _prof_start("spconv_wgrad", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout)
     items = _wgrad_plan_items(lib, counts, n_out, K, cin, cout, dev) if (counts is not None and n_out > 0) else None
     with _Dev(dev):
         check(lib.osn_spconv_wgrad(_p(feats), _p(gout), _p(nbr), _p(counts), _p(items), _p(gw), n_out, K, cin, cout,

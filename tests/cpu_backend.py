@@ -336,7 +336,15 @@ def weight_prep_x6_pair(weight, flip=False):
     return weight_prep_x6(weight), weight_prep_x6(weight, flip=flip, for_dgrad=True)
 
 
-_NAMES = ["stem_eligible", "stem_conv_fwd", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
+def weight_image(weight, flip=False, for_dgrad=False, layout=0):
+    """Spec of ops.weight_image (no cache on the CPU: the image is a function of the current weight)."""
+    if layout == 1:
+        wf, wb = weight_prep_tl(weight, flip, want_fwd=not for_dgrad, want_dgrad=for_dgrad)
+        return wb if for_dgrad else wf
+    return weight_prep_x6(weight, flip=flip, for_dgrad=for_dgrad)
+
+
+_NAMES = ["weight_image", "stem_eligible", "stem_conv_fwd", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
           "spconv_wgrad", "bn_stats", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
           "fnv_hash", "ravel_hash", "feature_remap", "batch_coords"]
 

@@ -342,3 +342,40 @@ def test_weight_prep_x6_is_an_exact_three_way_split():
         assert torch.all(rec[:, :, nc:] == 0)
         err = (rec[:, :, :nc] - ref).abs().max().item()
         assert err <= 2 ** -23 * ref.abs().max().item()
+
+
+def test_weight_image_cache_batches_and_follows_the_parameter_version():
+    """ops.weight_image: (i) the batched launch writes bit-identical images to the per-weight entry points, for both
+    layouts, forward / input gradient, flipped or not, K = 1 [cin, cout] weights included; (ii) an in-place update of
+    the parameter (what an optimizer step is) refreshes every image of the device in one go; (iii) an unchanged
+    parameter is served without a launch; (iv) the per-step wgrad / dgrad overlap stream does not change results."""
+    from openscene_amd import ops
+    ops.clear_weight_cache()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(27, 96, 96), (8, 32, 64), (1, 96, 768), (27, 20, 36), (125, 4, 32)]
+    params = []
+    for K, cin, cout in shapes:
+        w = torch.randn((K, cin, cout) if K > 1 else (cin, cout), generator=g) * 0.1
+        params.append(torch.nn.Parameter(w.to(dev())))
+
+    def direct(p, flip, dg, layout):
+        if layout == ops.PREP_TL:
+            wf, wb = ops.weight_prep_tl(p.detach(), flip, want_fwd=not dg, want_dgrad=dg)
+            return wb if dg else wf
+        return ops.weight_prep_x6(p.detach(), flip=flip, for_dgrad=dg)
+
+    combos = [(False, False), (False, True), (True, True)]
+    for rnd in range(3):
+        for p in params:
+            for layout in (ops.PREP_X6, ops.PREP_TL):
+                for flip, dg in combos:
+                    img = ops.weight_image(p, flip, dg, layout)
+                    ref = direct(p, flip, dg, layout)
+                    assert img.shape == ref.shape and img.dtype == ref.dtype
+                    assert torch.equal(img.view(torch.uint8).flatten(), ref.view(torch.uint8).flatten()), (rnd, tuple(p.shape), layout, flip, dg)
+        first = ops.weight_image(params[0], False, False, ops.PREP_X6)
+        assert ops.weight_image(params[0], False, False, ops.PREP_X6) is first        # served from the cache
+        with torch.no_grad():                                                         # "optimizer step"
+            for p in params:
+                p.add_(0.01 * torch.randn(p.shape, generator=g).to(dev()))
+    ops.clear_weight_cache()

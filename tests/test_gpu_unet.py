@@ -227,3 +227,37 @@ def test_prefetched_maps_give_the_same_step():
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert torch.equal(a, b)
+
+
+def test_wgrad_on_the_auxiliary_stream_and_cached_weight_images_change_nothing(monkeypatch):
+    """The backward of a convolution on a small map forks the weight gradient onto an auxiliary stream and joins before
+    it returns; weight images of parameters come from a per-device cache refreshed once per optimizer step.  Both are
+    pure scheduling: two optimizer steps with them on must be bitwise identical to two steps with them off."""
+    from openscene_amd import functional as F_, ops
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import SparseTensor
+    d = torch.device("cuda", 0)
+    v = syn.shuffled(syn.grid_voxels(syn.room_points(6, n_pts=30000), 0.03), 6)
+    coords = torch.from_numpy(syn.batch_coords([v])).to(d)
+    feats = torch.rand(coords.shape[0], 3, device=d)
+
+    def two_steps(overlap_rows, cache):
+        monkeypatch.setattr(F_, "WGRAD_OVERLAP_MAX_ROWS", overlap_rows)
+        monkeypatch.setattr(ops, "WEIGHT_CACHE", cache)
+        ops.clear_weight_cache()
+        torch.manual_seed(5)
+        model = mink_unet(3, 32, 3, "MinkUNet18A").to(d).train()
+        optim = torch.optim.SGD(model.parameters(), lr=0.05)
+        for _ in range(2):
+            optim.zero_grad(set_to_none=True)
+            out = model(SparseTensor(feats, coords))
+            out.square().mean().backward()
+            optim.step()
+        torch.cuda.synchronize(d)
+        return [out.detach().clone()] + [p.detach().clone() for p in model.parameters()]
+
+    ref = two_steps(0, False)
+    for got in (two_steps(1 << 30, True), two_steps(40000, True), two_steps(1 << 30, False)):
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+    ops.clear_weight_cache()
