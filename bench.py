@@ -81,8 +81,11 @@ class LaunchProfiler:
         if not self.enabled:
             return None
         name = self.name_of(kind, meta)
-        if self.only is not None and name != self.only:
-            return None
+        if self.only is not None:
+            o_name, o_K, o_cin, o_cout, o_n = self.only
+            if (name != o_name or meta["K"] != o_K or meta["cin"] != o_cin or meta["cout"] != o_cout
+                    or abs(meta["n_out"] - o_n) > 0.03 * o_n):
+                return None
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(dev))
@@ -95,8 +98,8 @@ class LaunchProfiler:
         e1.record(torch.cuda.current_stream(dev))
         self.records.append((name, meta, e0, e1))
 
-    def summarise(self, pair_counts):
-        """Group by kernel instance; algorithmic bytes per SURVEY.md 8(d):
+    def summarise(self, pair_counts, by_shape=False):
+        """Group by kernel instance (by_shape: and launch shape); algorithmic bytes per SURVEY.md 8(d):
         conv: 4*(N_in*Cin + N_out*Cout + K*Cin*Cout) + 8*pairs (K == 1: no map term)."""
         groups = {}
         for name, m, e0, e1 in self.records:
@@ -115,7 +118,8 @@ class LaunchProfiler:
             if m["K"] > 1:
                 byts += 8.0 * pairs
             flops = 2.0 * pairs * m["cin"] * m["cout"]
-            g = groups.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
+            key = (name, m["K"], m["cin"], m["cout"], int(round(m["n_out"], -3))) if by_shape else name
+            g = groups.setdefault(key, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0, "meta": m})
             g["launches"] += 1
             g["ms"] += ms
             g["bytes"] += byts
@@ -450,9 +454,13 @@ def main():
         step()
         torch.cuda.synchronize(device)
         survey = prof.summarise(pair_counts)
+        shapes = prof.summarise(pair_counts, by_shape=True)
         prof.records = []
-        if survey:
-            prof.only = max(survey.items(), key=lambda kv: kv[1]["ms"])[0]
+        if shapes:
+            # the dominant launch shape: one kernel instance on one (K, cin, cout, map) -- a well-defined launch whose
+            # algorithmic bytes / flops, duration and PMC traffic refer to the same thing
+            (d_name, d_K, d_cin, d_cout, _), d_g = max(shapes.items(), key=lambda kv: kv[1]["ms"])
+            prof.only = (d_name, d_K, d_cin, d_cout, d_g["meta"]["n_out"])
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -669,6 +677,7 @@ def main():
         groups = prof.summarise(pair_counts)
         dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
         name, gk = dom
+        dm = gk["meta"]
         achieved = gk["bytes"] / (gk["ms"] * 1e-3) / 1e9
         pmc = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -682,7 +691,10 @@ def main():
         # which roof binds this kernel: the one whose time-at-peak is larger (arithmetic intensity vs ridge)
         t_hbm = gk["bytes"] / (HBM_PEAK_GBS * 1e9)
         t_mfma = gk["flops"] / (mfma_peak * 1e12)
-        common = {"kernel": name, "traffic": pmc,
+        common = {"kernel": name,
+                  "shape": {"K": dm["K"], "cin": dm["cin"], "cout": dm["cout"], "n_in": dm["n_in"], "n_out": dm["n_out"]},
+                  "traffic": (pmc or {}).get("hbm_bytes"), "traffic_unit": "bytes per launch (PMC, profiles/pmc_traffic.json)",
+                  "traffic_detail": pmc,
                   "avg_launch_us": 1e3 * gk["ms"] / gk["launches"], "launches_per_step": gk["launches"] / args.steps,
                   "bytes_per_launch": gk["bytes"] / gk["launches"], "flops_per_launch": gk["flops"] / gk["launches"],
                   "flop_per_byte": gk["flops"] / gk["bytes"], "ridge_flop_per_byte": mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9),

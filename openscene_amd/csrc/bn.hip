@@ -119,10 +119,23 @@ __device__ inline void finalize_sums(const double* __restrict__ partial, int n_r
     red[0][part][cl] = a;
     red[1][part][cl] = b;
     __syncthreads();
+    // two levels, fixed order: slices 8 g .. 8 g + 7 by thread (g, cl), then the eight group sums by thread (0, cl)
+    // (a single thread adding 64 slices is a chain of 128 dependent LDS reads + fp64 adds: 3 of the kernel's 5 us)
+    double t1 = 0, t2 = 0;
+    if (part < 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { t1 += red[0][part * 8 + q][cl]; t2 += red[1][part * 8 + q][cl]; }
+    }
+    __syncthreads();
+    if (part < 8) {
+        red[0][part][cl] = t1;
+        red[1][part][cl] = t2;
+    }
+    __syncthreads();
     s1 = 0; s2 = 0;
     if (part == 0) {
 #pragma unroll
-        for (int q = 0; q < FIN_PARTS; ++q) { s1 += red[0][q][cl]; s2 += red[1][q][cl]; }
+        for (int q = 0; q < 8; ++q) { s1 += red[0][q][cl]; s2 += red[1][q][cl]; }
     }
 }
 

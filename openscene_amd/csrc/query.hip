@@ -9,6 +9,7 @@
 // contraction: v_mfma_f32_32x32x16_f16, A = 32 point rows x 16 k, B = text rows
 // (text is [C, D] row-major = the K-contiguous B operand, no transpose needed).
 #include "common.h"
+#include <stdlib.h>
 
 namespace osn {
 
@@ -21,9 +22,9 @@ constexpr int Q_DK = 64;    // feature chunk
 constexpr int Q_LD = Q_DK + 8;  // padded LDS row (144 B: 16-B aligned, conflict-free ds_read_b128)
 
 // sources: point p reads row g0[p] of X0 (or p if g0 null); if sel && sel[p], row g1[p] of X1.
-// DEEP: two chunks of point rows in flight (64 more registers; fits CT <= 2), else one.
-template <int CT, bool DEEP>
-__global__ __launch_bounds__(256, 2) void query_kernel(const float* __restrict__ X0, const int64_t* __restrict__ g0,
+// NBUF chunks of point rows (and of the text) in flight per thread, WGS workgroups per CU (register budget 512 / WGS).
+template <int CT, int NBUF, int WGS>
+__global__ __launch_bounds__(256, WGS) void query_kernel(const float* __restrict__ X0, const int64_t* __restrict__ g0,
                                                     const float* __restrict__ X1, const int64_t* __restrict__ g1,
                                                     const uint8_t* __restrict__ sel, const float* __restrict__ rowdiv,
                                                     const _Float16* __restrict__ T, _Float16* __restrict__ scores,
@@ -67,39 +68,37 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-        // software pipeline over the feature chunks, TWO chunks of point rows in flight: while the MFMAs of chunk i run
-        // from LDS, the rows of chunk i+1 are already on their way (issued one iteration ago) and the rows of chunk
-        // i+2 are issued now -- the kernel is bound by bytes in flight x latency (random 256-byte segments), and the
-        // register file is the largest buffer a CU has (2 x 32 KB per workgroup).  The text chunk i+1 (L2-resident) is
-        // issued BEFORE the rows of chunk i+2, so that waiting for it does not drain the younger row loads
-        // (the memory counter retires in order).  All loads are unconditional from clamped addresses.
-        float4 pxa[Q_BM / 16], pxb[Q_BM / 16];
-        uint4 pt[CT];
+        // software pipeline over the feature chunks with NBUF chunks in flight: while the MFMAs of chunk i run from LDS,
+        // chunks i+1 .. i+NBUF-1 are on their way and chunk i+NBUF is issued into the register buffer chunk i just left.
+        // The kernel is bound by bytes in flight x latency (random 256-byte segments) and the register file is the
+        // largest buffer a CU has.  The text chunk (L2-resident) travels with its rows at the same distance and is
+        // issued first: the memory counter retires in order, so waiting for chunk i+1 leaves the NBUF-1 younger
+        // fetches in flight.  All loads are unconditional from clamped addresses.
+        float4 px[NBUF][Q_BM / 16];
+        uint4 pt[NBUF][CT];
         const int xq = tid & 15, xr = tid >> 4;
-        auto fetch_x = [&](int d0, float4 (&px)[Q_BM / 16]) {
-#pragma unroll
-            for (int ps = 0; ps < Q_BM / 16; ++ps) {
-                const int64_t off = rowoff[ps * 16 + xr];
-                const bool ok = row0 + ps * 16 + xr < n && d0 + xq * 4 < d;
-                px[ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X0) + (ok ? off + (d0 + xq * 4) * 4 : 0));
-            }
-        };
-        auto fetch_t = [&](int d0) {
+        auto fetch = [&](int d0, float4 (&pxb)[Q_BM / 16], uint4 (&ptb)[CT]) {
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
                 const int f = tid + 256 * j;
                 const int trow = f >> 3, ch = f & 7;
                 const int col = cg0 + trow;
                 const bool ok = col < c && d0 + ch * 8 < d;
-                pt[j] = *reinterpret_cast<const uint4*>(ok ? T + int64_t(col) * d + d0 + ch * 8 : T);
+                ptb[j] = *reinterpret_cast<const uint4*>(ok ? T + int64_t(col) * d + d0 + ch * 8 : T);
+            }
+#pragma unroll
+            for (int ps = 0; ps < Q_BM / 16; ++ps) {
+                const int64_t off = rowoff[ps * 16 + xr];
+                const bool ok = row0 + ps * 16 + xr < n && d0 + xq * 4 < d;
+                pxb[ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X0) + (ok ? off + (d0 + xq * 4) * 4 : 0));
             }
         };
-        auto stash = [&](int d0, float4 (&px)[Q_BM / 16]) {
+        auto stash = [&](int d0, float4 (&pxb)[Q_BM / 16], uint4 (&ptb)[CT]) {
 #pragma unroll
             for (int ps = 0; ps < Q_BM / 16; ++ps) {
                 const int row = ps * 16 + xr;
                 const bool ok = row0 + row < n && d0 + xq * 4 < d;
-                float4 v = px[ps];
+                float4 v = pxb[ps];
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (rowdiv) {
                     const float den = rowden[row];
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const float* __restrict__
                 const int f = tid + 256 * j;
                 const int trow = f >> 3, ch = f & 7;
                 const bool ok = cg0 + trow < c && d0 + ch * 8 < d;
-                uint4 v = pt[j];
+                uint4 v = ptb[j];
                 if (!ok) v = make_uint4(0, 0, 0, 0);
                 *reinterpret_cast<uint4*>(&Ts[trow][ch * 8]) = v;
             }
@@ -132,37 +131,22 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const float* __restrict__
                 }
             }
         };
-        fetch_x(0, pxa);
-        fetch_t(0);
-        if (DEEP && Q_DK < d) fetch_x(Q_DK, pxb);
-        stash(0, pxa);
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b)
+            if (b * Q_DK < d) fetch(b * Q_DK, px[b], pt[b]);
+        stash(0, px[0], pt[0]);
         __syncthreads();
-        if (DEEP) {
-            for (int d0 = 0; d0 < d; d0 += 2 * Q_DK) {
-                // ---- even chunk d0 in LDS; pxb = chunk d0 + 64 (in flight); issue text d0 + 64, rows d0 + 128 -> pxa
-                if (d0 + Q_DK < d) fetch_t(d0 + Q_DK);
-                if (d0 + 2 * Q_DK < d) fetch_x(d0 + 2 * Q_DK, pxa);
-                mfmas();
-                __syncthreads();
-                if (d0 + Q_DK >= d) break;
-                stash(d0 + Q_DK, pxb);
-                __syncthreads();
-                // ---- odd chunk d0 + 64 in LDS; pxa = chunk d0 + 128 (in flight); issue text d0 + 128, rows d0 + 192 -> pxb
-                if (d0 + 2 * Q_DK < d) fetch_t(d0 + 2 * Q_DK);
-                if (d0 + 3 * Q_DK < d) fetch_x(d0 + 3 * Q_DK, pxb);
-                mfmas();
-                __syncthreads();
-                if (d0 + 2 * Q_DK < d) stash(d0 + 2 * Q_DK, pxa);
-                __syncthreads();
-            }
-        } else {
-            for (int d0 = 0; d0 < d; d0 += Q_DK) {
-                const bool more = d0 + Q_DK < d;
-                if (more) { fetch_t(d0 + Q_DK); fetch_x(d0 + Q_DK, pxa); }
-                mfmas();
-                __syncthreads();
-                if (more) stash(d0 + Q_DK, pxa);
-                __syncthreads();
+        for (int base = 0; base < d; base += NBUF * Q_DK) {
+#pragma unroll
+            for (int b = 0; b < NBUF; ++b) {
+                const int d0 = base + b * Q_DK;                    // chunk d0 is in LDS, register buffer b is free
+                if (d0 < d) {
+                    if (d0 + NBUF * Q_DK < d) fetch(d0 + NBUF * Q_DK, px[b], pt[b]);
+                    mfmas();
+                    __syncthreads();
+                    if (d0 + Q_DK < d) stash(d0 + Q_DK, px[(b + 1) % NBUF], pt[(b + 1) % NBUF]);
+                    __syncthreads();
+                }
             }
         }
         // ---- group epilogue: round to fp16, optional store, row argmax of the group merged into the running one
@@ -240,14 +224,19 @@ static int launch_query(hipStream_t st, const float* X0, const int64_t* g0, cons
                         float* rowmax, int64_t n, int d, int c) {
     const dim3 grid(cdiv(n, Q_BM)), block(256);
     const int ct = int(cdiv(c, 32));
-    if (ct <= 1)
-        hipLaunchKernelGGL((query_kernel<1, true>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
-    else if (ct <= 2)
-        hipLaunchKernelGGL((query_kernel<2, true>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
-    else if (ct <= 3)
-        hipLaunchKernelGGL((query_kernel<3, false>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
-    else
-        hipLaunchKernelGGL((query_kernel<5, false>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c);
+#define OSN_Q(CT, NB, WG) hipLaunchKernelGGL((query_kernel<CT, NB, WG>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c)
+    const char* ev = getenv("OSN_QUERY_VARIANT");        // tools only: A/B of the pipeline depth / occupancy
+    const int v = ev ? atoi(ev) : 0;
+    if (ct <= 1) {
+        if (v == 1) OSN_Q(1, 1, 3); else if (v == 2) OSN_Q(1, 2, 2); else if (v == 3) OSN_Q(1, 3, 2); else OSN_Q(1, 1, 2);
+    } else if (ct <= 2) {
+        if (v == 1) OSN_Q(2, 1, 3); else if (v == 2) OSN_Q(2, 2, 2); else if (v == 3) OSN_Q(2, 3, 1); else OSN_Q(2, 1, 2);
+    } else if (ct <= 3) {
+        if (v == 1) OSN_Q(3, 2, 1); else if (v == 2) OSN_Q(3, 3, 1); else if (v == 3) OSN_Q(3, 4, 1); else OSN_Q(3, 1, 2);
+    } else {
+        if (v == 1) OSN_Q(5, 2, 1); else if (v == 2) OSN_Q(5, 3, 1); else if (v == 3) OSN_Q(5, 4, 1); else OSN_Q(5, 1, 2);
+    }
+#undef OSN_Q
     OSN_LAUNCH_CHECK();
     return OSN_OK;
 }

@@ -20,9 +20,11 @@ from . import ops
 CONV_MODE = os.environ.get("OSN_CONV_MODE", "tl")
 TL_FWD_MIN_ROWS = int(os.environ.get("OSN_TL_FWD_MIN_ROWS", "65536"))
 # Backward of a convolution on a map of at most this many rows: the weight gradient (plan + kernel + reduce) runs on an
-# auxiliary stream beside the input gradient (+ its reduce) -- both chains are latency-bound there and neither fills the
-# chip; the node forks after `gout` is ready and joins before it returns, so nothing outside sees the second stream.
-WGRAD_OVERLAP_MAX_ROWS = int(os.environ.get("OSN_WGRAD_OVERLAP_MAX_ROWS", "40000"))
+# auxiliary stream beside the input gradient (+ its reduce); the node forks after `gout` is ready and joins before it
+# returns, so nothing outside sees the second stream.  OFF by default (0): measured on S100k (tools/ab_wall.sh, 2 rounds)
+# 14.78 / 14.18 ms with 40000 against 14.31 / 14.29 ms without -- the deep levels are bound by the host's launch rate,
+# not by the GPU, so there is nothing to overlap; 70000 and 200000 are slower (15.0 ms).  Results are bitwise identical.
+WGRAD_OVERLAP_MAX_ROWS = int(os.environ.get("OSN_WGRAD_OVERLAP_MAX_ROWS", "0"))
 
 
 class SparseConvFunction(Function):

@@ -20,18 +20,21 @@ def main():
         x = torch.randn(n_vox, d, generator=g).to(dev)
         idx = torch.randint(0, n_vox, (n_pts,), generator=g).to(dev)
         t = torch.nn.functional.normalize(torch.randn(c, d, generator=g), dim=1).half().to(dev)
-        for _ in range(2):
-            query_distill(x, t, idx, return_scores=scores)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            query_distill(x, t, idx, return_scores=scores)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
-        byts = 4.0 * n_pts * d + 2.0 * c * d + 16.0 * n_pts + (2.0 * n_pts * c if scores else 0.0)
-        print("n=%d d=%d c=%d scores=%s: %.3f ms  %.1f %% of 8 TB/s" % (n_pts, d, c, scores, ms, 100 * byts / (ms * 1e-3) / 8e12))
+        for variant in os.environ.get("VARIANTS", "0").split(","):
+            os.environ["OSN_QUERY_VARIANT"] = variant
+            for _ in range(2):
+                query_distill(x, t, idx, return_scores=scores)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                query_distill(x, t, idx, return_scores=scores)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            byts = 4.0 * n_pts * d + 2.0 * c * d + 16.0 * n_pts + (2.0 * n_pts * c if scores else 0.0)
+            print("n=%d d=%d c=%d scores=%s variant=%s: %.3f ms  %.1f %% of 8 TB/s" % (
+                n_pts, d, c, scores, variant, ms, 100 * byts / (ms * 1e-3) / 8e12), flush=True)
         del x, idx
 
 
