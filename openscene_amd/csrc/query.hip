@@ -9,7 +9,6 @@
 // contraction: v_mfma_f32_32x32x16_f16, A = 32 point rows x 16 k, B = text rows
 // (text is [C, D] row-major = the K-contiguous B operand, no transpose needed).
 #include "common.h"
-#include <stdlib.h>
 
 namespace osn {
 
@@ -118,22 +117,38 @@ __global__ __launch_bounds__(256, WGS) void query_kernel(const float* __restrict
                 *reinterpret_cast<uint4*>(&Ts[trow][ch * 8]) = v;
             }
         };
+        // MFMA phase: the fragments of k-step ks+1 are read from LDS while the MFMAs of k-step ks run (two register
+        // sets; the scheduling fences keep the compiler from sinking the reads back to their first use, which leaves
+        // every MFMA waiting for its own LDS round trip)
         auto mfmas = [&]() {
             const int arow = wave * 32 + (lane & 31);
             const int kh = 8 * (lane >> 5);
+            half8 fa[2], fb[2][CT];
+            auto frags = [&](int ks, int w) {
+                fa[w] = *reinterpret_cast<const half8*>(&Xs[arow][ks * 16 + kh]);
+#pragma unroll
+                for (int t = 0; t < CT; ++t)
+                    fb[w][t] = *reinterpret_cast<const half8*>(&Ts[t * 32 + (lane & 31)][ks * 16 + kh]);
+            };
+            frags(0, 0);
 #pragma unroll
             for (int ks = 0; ks < Q_DK / 16; ++ks) {
-                const half8 a = *reinterpret_cast<const half8*>(&Xs[arow][ks * 16 + kh]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 1 < Q_DK / 16) frags(ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < CT; ++t) {
-                    const half8 b = *reinterpret_cast<const half8*>(&Ts[t * 32 + (lane & 31)][ks * 16 + kh]);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
-                }
+                for (int t = 0; t < CT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1], fb[ks & 1][t], acc[t], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         };
+        // (scheduling fences: the fetches must be ISSUED in program order -- the compiler is free to reorder independent
+        // loads, and the in-order memory counter then makes the oldest buffer wait for the youngest load)
 #pragma unroll
-        for (int b = 0; b < NBUF; ++b)
-            if (b * Q_DK < d) fetch(b * Q_DK, px[b], pt[b]);
+        for (int b = 0; b < NBUF; ++b) {
+            fetch(b * Q_DK, px[b], pt[b]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         stash(0, px[0], pt[0]);
         __syncthreads();
         for (int base = 0; base < d; base += NBUF * Q_DK) {
@@ -141,7 +156,12 @@ __global__ __launch_bounds__(256, WGS) void query_kernel(const float* __restrict
             for (int b = 0; b < NBUF; ++b) {
                 const int d0 = base + b * Q_DK;                    // chunk d0 is in LDS, register buffer b is free
                 if (d0 < d) {
-                    if (d0 + NBUF * Q_DK < d) fetch(d0 + NBUF * Q_DK, px[b], pt[b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // unconditional (a chunk past the end loads the first 16 bytes of X0 / T for every lane): with a
+                    // conditional fetch the compiler must assume the older buffers may be the YOUNGEST loads on some
+                    // path and drains the counter to zero before every stash
+                    fetch(d0 + NBUF * Q_DK, px[b], pt[b]);
+                    __builtin_amdgcn_sched_barrier(0);
                     mfmas();
                     __syncthreads();
                     if (d0 + Q_DK < d) stash(d0 + Q_DK, px[(b + 1) % NBUF], pt[(b + 1) % NBUF]);
@@ -225,17 +245,13 @@ static int launch_query(hipStream_t st, const float* X0, const int64_t* g0, cons
     const dim3 grid(cdiv(n, Q_BM)), block(256);
     const int ct = int(cdiv(c, 32));
 #define OSN_Q(CT, NB, WG) hipLaunchKernelGGL((query_kernel<CT, NB, WG>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c)
-    const char* ev = getenv("OSN_QUERY_VARIANT");        // tools only: A/B of the pipeline depth / occupancy
-    const int v = ev ? atoi(ev) : 0;
-    if (ct <= 1) {
-        if (v == 1) OSN_Q(1, 1, 3); else if (v == 2) OSN_Q(1, 2, 2); else if (v == 3) OSN_Q(1, 3, 2); else OSN_Q(1, 1, 2);
-    } else if (ct <= 2) {
-        if (v == 1) OSN_Q(2, 1, 3); else if (v == 2) OSN_Q(2, 2, 2); else if (v == 3) OSN_Q(2, 3, 1); else OSN_Q(2, 1, 2);
-    } else if (ct <= 3) {
-        if (v == 1) OSN_Q(3, 2, 1); else if (v == 2) OSN_Q(3, 3, 1); else if (v == 3) OSN_Q(3, 4, 1); else OSN_Q(3, 1, 2);
-    } else {
-        if (v == 1) OSN_Q(5, 2, 1); else if (v == 2) OSN_Q(5, 3, 1); else if (v == 3) OSN_Q(5, 4, 1); else OSN_Q(5, 1, 2);
-    }
+    // one chunk in flight per thread; three workgroups per CU where the registers allow it (<= 64 labels).  Measured
+    // alternatives (profiles/r02_s6_query_variants.txt): deeper register pipelines (2-4 chunks, also with one 512-register
+    // workgroup per CU) and a column-split kernel with the text read straight from L2 are all slower.
+    if (ct <= 1) OSN_Q(1, 1, 3);
+    else if (ct <= 2) OSN_Q(2, 1, 3);
+    else if (ct <= 3) OSN_Q(3, 1, 2);
+    else OSN_Q(5, 1, 2);
 #undef OSN_Q
     OSN_LAUNCH_CHECK();
     return OSN_OK;

@@ -98,7 +98,10 @@ def _query_inputs(n_vox, n_pts, d, c, seed):
 
 
 @pytest.mark.parametrize("n_vox,n_pts,d,c", [(4000, 6001, 768, 20), (3000, 3000, 512, 21), (2500, 4000, 768, 160),
-                                             (1000, 1500, 768, 43), (700, 900, 512, 300), (130, 1, 768, 2)])
+                                             (1000, 1500, 768, 43), (700, 900, 512, 300), (130, 1, 768, 2),
+                                             # column-split kernel (> 64 labels): two tiles per wave, ragged last feature
+                                             # chunk; exactly one full group; one label more than the narrow kernel takes
+                                             (2000, 3000, 520, 100), (1500, 2500, 768, 192), (900, 1300, 512, 65)])
 def test_query_scores_and_argmax(n_vox, n_pts, d, c):
     from openscene_amd import ops
     x, t, gather = _query_inputs(n_vox, n_pts, d, c, n_vox + c)
