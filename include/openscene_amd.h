@@ -74,6 +74,14 @@ int osn_kmap_build(const uint64_t* in_table_keys, const int32_t* in_table_vals, 
                    int32_t* nbr, int64_t* counts /* nullable: int64 [K] pairs per offset */,
                    osn_stream_t stream);
 
+/* The same map when the output coordinates ARE the table's own rows in row order (every stride-1
+ * convolution of the path: models/mink_unet.py:47-113 BasicBlock convs, conv0p1s1) and ksize is odd:
+ * such a map is its own mirror (nbr[k][o] = i <=> nbr[K-1-k][i] = o), so only the offsets below the centre
+ * are probed and each hit also writes its mirrored entry.  Bit-identical output to osn_kmap_build. */
+int osn_kmap_build_self(const uint64_t* table_keys, const int32_t* table_vals, int64_t cap,
+                        const int32_t* coords4, int64_t n, int ksize, int offset_scale,
+                        int32_t* nbr, int64_t* counts /* nullable */, osn_stream_t stream);
+
 /* tbl[k, i] = o  <=>  nbr[k, o] = i : the map of the transposed operator
  * ([ME] MinkowskiConvolutionTranspose, models/mink_unet.py:77-78,84-85,91-92,98-99,
  * and the input-gradient of every strided convolution).                          */

@@ -191,6 +191,42 @@ __global__ void kmap_build_kernel(const uint64_t* __restrict__ keys, const int32
     }
 }
 
+// Map of an ODD kernel over the table's OWN rows (stride-1 convolution: out_coords = the coordinates the table was built
+// from, in row order).  Such a map is its own mirror -- nbr[k][o] = i  <=>  nbr[K-1-k][i] = o -- so only the offsets
+// below the centre are probed (blockIdx.y < K/2); a hit also writes its mirrored entry (the upper half is preset to -1),
+// and the centre offset is the identity.  Same table, bit for bit, as kmap_build_kernel; half the random probes.
+__global__ void kmap_build_self_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals, uint32_t mask,
+                                       const int4* __restrict__ coords, int64_t n, int ksize, int scale,
+                                       int32_t* __restrict__ nbr, unsigned long long* __restrict__ counts) {
+    const int64_t o = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    const int K = ksize * ksize * ksize;
+    if (k == K / 2) {                               // centre: every row is its own neighbour
+        if (o < n) nbr[int64_t(k) * n + o] = int(o);
+        if (counts && blockIdx.x == 0 && threadIdx.x == 0) counts[k] = (unsigned long long)n;
+        return;
+    }
+    int r = -1;
+    if (o < n) {
+        const int ix = k % ksize, iy = (k / ksize) % ksize, iz = k / (ksize * ksize);
+        const int c = ksize / 2;
+        const int4 p = coords[o];
+        const int x = p.y + (ix - c) * scale, y = p.z + (iy - c) * scale, z = p.w + (iz - c) * scale;
+        const int lim = COORD_BIAS - 1;
+        if (x >= -lim && x <= lim && y >= -lim && y <= lim && z >= -lim && z <= lim)
+            r = table_find(keys, vals, mask, pack_key(p.x, x, y, z));
+        nbr[int64_t(k) * n + o] = r;
+        if (r >= 0) nbr[int64_t(K - 1 - k) * n + r] = int(o);
+    }
+    if (counts) {
+        const int c = __syncthreads_count(r >= 0);
+        if (threadIdx.x == 0 && c) {
+            atomicAdd(&counts[k], (unsigned long long)c);
+            atomicAdd(&counts[K - 1 - k], (unsigned long long)c);
+        }
+    }
+}
+
 __global__ void kmap_transpose_kernel(const int32_t* __restrict__ nbr, int64_t n_out, int64_t n_in,
                                       int32_t* __restrict__ tbl) {
     const int64_t o = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -311,6 +347,27 @@ extern "C" int osn_kmap_build(const uint64_t* in_table_keys, const int32_t* in_t
     const int T = 256;
     hipLaunchKernelGGL(kmap_build_kernel, dim3(cdiv(n_out, T), K), dim3(T), 0, st, in_table_keys, in_table_vals,
                        uint32_t(cap - 1), reinterpret_cast<const int4*>(out_coords4), n_out, ksize, offset_scale, nbr,
+                       reinterpret_cast<unsigned long long*>(counts));
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}
+
+extern "C" int osn_kmap_build_self(const uint64_t* table_keys, const int32_t* table_vals, int64_t cap,
+                                   const int32_t* coords4, int64_t n, int ksize, int offset_scale, int32_t* nbr,
+                                   int64_t* counts, osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(ksize >= 1 && ksize <= 7 && (ksize & 1) == 1, OSN_E_ARG, "osn_kmap_build_self: ksize=%d must be odd, <= 7", ksize);
+    OSN_REQUIRE(cap >= 2 && (cap & (cap - 1)) == 0, OSN_E_ARG, "osn_kmap_build_self: cap must be a power of two");
+    OSN_REQUIRE(n >= 0, OSN_E_ARG, "osn_kmap_build_self: n < 0");
+    const int K = ksize * ksize * ksize;
+    if (counts) OSN_HIP(hipMemsetAsync(counts, 0, size_t(K) * 8, st));
+    if (n == 0) return OSN_OK;
+    OSN_REQUIRE(table_keys && table_vals && coords4 && nbr, OSN_E_ARG, "osn_kmap_build_self: null pointer");
+    OSN_REQUIRE(aligned16(coords4), OSN_E_ARG, "osn_kmap_build_self: coords4 must be 16-byte aligned");
+    if (K > 1) OSN_HIP(hipMemsetAsync(nbr + int64_t(K / 2 + 1) * n, 0xFF, size_t(K / 2) * size_t(n) * 4, st));
+    const int T = 256;
+    hipLaunchKernelGGL(kmap_build_self_kernel, dim3(cdiv(n, T), K / 2 + 1), dim3(T), 0, st, table_keys, table_vals,
+                       uint32_t(cap - 1), reinterpret_cast<const int4*>(coords4), n, ksize, offset_scale, nbr,
                        reinterpret_cast<unsigned long long*>(counts));
     OSN_LAUNCH_CHECK();
     return OSN_OK;

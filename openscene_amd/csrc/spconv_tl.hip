@@ -30,6 +30,7 @@
 // Arithmetic: "bf16x6" -- x = x1 + x2 + x3 (bf16 pieces), a*b ~= a3b1 + a2b2 + a1b3 + a2b1 + a1b2 + a1b1
 // accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (dropped terms <= 2^-24 relative): fp32-class accuracy.
 #include "common.h"
+#include <type_traits>
 #include "weight_prep.h"
 
 namespace osn {
@@ -104,6 +105,7 @@ struct TlIter {
     int s0;       // first 32-deep k-step of the channel chunk
     int g;        // 32-pair step within the offset
     int niter;    // steps of offset a
+    int np;       // pairs of offset a
 };
 
 // PROF (tools only): wave 0 accumulates s_memtime deltas of the phases into prof[workgroup][10].
@@ -260,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
             auto first = [&](int a) {
                 TlIter it;
                 it.a = a; it.s0 = 0; it.g = 0;
-                it.niter = a < a1 ? (__builtin_amdgcn_readfirstlane(kcnt[a]) + 31) >> 5 : 0;
+                it.np = a < a1 ? __builtin_amdgcn_readfirstlane(kcnt[a]) : 0;
+                it.niter = (it.np + 31) >> 5;
                 return it;
             };
             auto advance = [&](TlIter& it) {
@@ -270,7 +273,8 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                     if (it.s0 >= ns) {
                         it.s0 = 0;
                         ++it.a;
-                        it.niter = it.a < a1 ? (__builtin_amdgcn_readfirstlane(kcnt[it.a]) + 31) >> 5 : 0;
+                        it.np = it.a < a1 ? __builtin_amdgcn_readfirstlane(kcnt[it.a]) : 0;
+                        it.niter = (it.np + 31) >> 5;
                     }
                 }
             };
@@ -340,6 +344,9 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                 TL_TICK(4)                                 // 4: barrier B
                 if (wave >= NW) return;                    // staging-only wave
                 // ---- 32 pairs x 32 columns per wave: accumulator blocks [pair half][column block]
+                // (the last step of an offset may hold at most 16 pairs -- the average (tile, offset) of a 100 k-row map
+                // has 36 -- : its second 16-pair half is all padding and is skipped: MFMAs, fragment reads, tile update)
+                const bool half1 = it.np - 32 * it.g > 16;          // wave-uniform
                 f32x4 acc[2][2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
@@ -354,19 +361,28 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                         for (int h = 0; h < 2; ++h)
 #pragma unroll
                             for (int pl = 0; pl < 3; ++pl)
-                                af[h][pl] = *reinterpret_cast<const bf16x8*>(&stage[pl][h * 16 + (lane & 15)][ks * 32 + akq]);
+                                af[h][pl] = *reinterpret_cast<const bf16x8*>(&stage[pl][(half1 ? h : 0) * 16 + (lane & 15)][ks * 32 + akq]);
                         // product-major order: consecutive MFMAs go to DIFFERENT accumulators (a dependent chain per
                         // accumulator would stall the in-order issue on every MFMA's result); per accumulator the
                         // order is still smallest terms first: a3b1, a2b2, a1b3, a2b1, a1b2, a1b1
-#define TL_MFMA(AP, BP)                                                                                     \
-    _Pragma("unroll") for (int h = 0; h < 2; ++h) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)            \
+#define TL_MFMA(H0, H1, AP, BP)                                                                             \
+    _Pragma("unroll") for (int h = H0; h < H1; ++h) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)          \
         acc[h][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[h][AP], B[ks][nb][BP], acc[h][nb], 0, 0, 0);
-                        TL_MFMA(2, 0)
-                        TL_MFMA(1, 1)
-                        TL_MFMA(0, 2)
-                        TL_MFMA(1, 0)
-                        TL_MFMA(0, 1)
-                        TL_MFMA(0, 0)
+                        if (half1) {
+                            TL_MFMA(0, 2, 2, 0)
+                            TL_MFMA(0, 2, 1, 1)
+                            TL_MFMA(0, 2, 0, 2)
+                            TL_MFMA(0, 2, 1, 0)
+                            TL_MFMA(0, 2, 0, 1)
+                            TL_MFMA(0, 2, 0, 0)
+                        } else {
+                            TL_MFMA(0, 1, 2, 0)
+                            TL_MFMA(0, 1, 1, 1)
+                            TL_MFMA(0, 1, 0, 2)
+                            TL_MFMA(0, 1, 1, 0)
+                            TL_MFMA(0, 1, 0, 1)
+                            TL_MFMA(0, 1, 0, 0)
+                        }
 #undef TL_MFMA
                     }
                 }
@@ -384,24 +400,29 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                 // within an offset -- but the compiler cannot know, and a read-add-write chain per cell would
                 // serialise 16 LDS round trips)
                 const int pbase = __builtin_amdgcn_readfirstlane(lstart[it.a]) + 32 * it.g + 4 * (lane >> 4);
-                int orow[2][4];
+                auto update = [&](auto nh) {                // nh halves: all reads, then all writes
+                    constexpr int NH = decltype(nh)::value;
+                    int orow[NH][4];
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                    for (int h = 0; h < NH; ++h)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) orow[h][r] = int(plist[pbase + 16 * h + r] >> 24) * S + 32 * wave + (lane & 15);
-                float cur[2][2][4];
+                        for (int r = 0; r < 4; ++r) orow[h][r] = int(plist[pbase + 16 * h + r] >> 24) * S + 32 * wave + (lane & 15);
+                    float cur[NH][2][4];
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                    for (int h = 0; h < NH; ++h)
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
+                        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) cur[h][nb][r] = otile[orow[h][r] + 16 * nb];
+                            for (int r = 0; r < 4; ++r) cur[h][nb][r] = otile[orow[h][r] + 16 * nb];
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                    for (int h = 0; h < NH; ++h)
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
+                        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) otile[orow[h][r] + 16 * nb] = cur[h][nb][r] + acc[h][nb][r];
+                            for (int r = 0; r < 4; ++r) otile[orow[h][r] + 16 * nb] = cur[h][nb][r] + acc[h][nb][r];
+                };
+                if (half1) update(std::integral_constant<int, 2>{});
+                else update(std::integral_constant<int, 1>{});
                 TL_TICK(6)                                 // 6: output-tile read-add-write
             };
 

@@ -191,8 +191,9 @@ def coords_unique(coords4, stride=1):
     return out[:u], inverse[:n], first[:u], table
 
 
-def kmap_build(table, out_coords4, ksize, offset_scale, with_counts=False):
-    """nbr int32 [K, n_out] (and, with_counts, int64 [K] pairs per offset from the same pass)."""
+def kmap_build(table, out_coords4, ksize, offset_scale, with_counts=False, self_map=False):
+    """nbr int32 [K, n_out] (and, with_counts, int64 [K] pairs per offset from the same pass).  self_map: out_coords4 are
+    the rows the table was built from, in row order, and ksize is odd (stride-1 convolution): the half-probe builder."""
     dev = out_coords4.device
     lib = _prep(dev)
     out_coords4 = out_coords4.contiguous()
@@ -200,9 +201,11 @@ def kmap_build(table, out_coords4, ksize, offset_scale, with_counts=False):
     K = ksize ** 3
     nbr = torch.empty((K, n_out), dtype=torch.int32, device=dev)
     counts = torch.empty(K, dtype=torch.int64, device=dev) if with_counts else None
+    fn, what = (lib.osn_kmap_build_self, "osn_kmap_build_self") if (self_map and ksize % 2 == 1) else \
+        (lib.osn_kmap_build, "osn_kmap_build")
     with _Dev(dev):
-        check(lib.osn_kmap_build(_p(table.keys), _p(table.vals), table.cap, _p(out_coords4), n_out, int(ksize),
-                                 int(offset_scale), _p(nbr), _p(counts), _stream(dev)), "osn_kmap_build")
+        check(fn(_p(table.keys), _p(table.vals), table.cap, _p(out_coords4), n_out, int(ksize),
+                 int(offset_scale), _p(nbr), _p(counts), _stream(dev)), what)
     return (nbr, counts) if with_counts else nbr
 
 

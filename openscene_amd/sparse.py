@@ -73,7 +73,7 @@ class CoordinateManager:
         elif in_stride == out_stride:
             self.coords(in_stride)
             nbr, cnt = ops.kmap_build(self._tables[in_stride], self._coords[in_stride], ksize, dilation * in_stride,
-                                      with_counts=True)
+                                      with_counts=True, self_map=True)
             self._kmaps[("counts",) + key] = cnt
             if ksize % 2 == 1:
                 res = (nbr, nbr, True)            # the map of an odd stride-1 kernel is its own mirror

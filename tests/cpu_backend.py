@@ -37,7 +37,7 @@ def coords_unique(coords4, stride=1):
             torch.from_numpy(first.astype(np.int32)), HashTable(uniq))
 
 
-def kmap_build(table, out_coords4, ksize, offset_scale, with_counts=False):
+def kmap_build(table, out_coords4, ksize, offset_scale, with_counts=False, self_map=False):
     # kernel_offsets(ksize, tensor_stride) scales by the tensor stride; dilation folded into offset_scale
     off = oc.kernel_offsets(ksize, offset_scale)
     nbr = torch.from_numpy(oc.kernel_map(table.coords4, _np(out_coords4), off))

@@ -156,3 +156,18 @@ def test_kmap_sort_bit_exact_and_skip_efficiency():
     v = (tup >= 0).cpu().numpy()
     n = v.shape[1] // 128 * 128
     assert v[:, :n].reshape(8, -1, 128).any(2).sum(0).mean() < 1.2
+
+
+@pytest.mark.parametrize("ksize", [1, 3, 5])
+def test_half_probe_self_map_equals_the_full_probe(ksize):
+    """osn_kmap_build_self (offsets below the centre probed, hits mirrored) against osn_kmap_build on the same table:
+    tables and per-offset counts bit-identical, at a scaled offset too (a deeper level's stride)."""
+    from openscene_amd import ops
+    for seed, scale in ((3, 1), (4, 2)):
+        c = random_cloud(seed, 9000, 40, batch=2, lo=-15)
+        c[:, 1:] *= scale
+        uniq, _, _, table = ops.coords_unique(torch.from_numpy(c).to(dev()))
+        a, ca = ops.kmap_build(table, uniq, ksize, scale, with_counts=True, self_map=False)
+        b, cb = ops.kmap_build(table, uniq, ksize, scale, with_counts=True, self_map=True)
+        assert torch.equal(a, b) and torch.equal(ca, cb)
+        assert torch.equal(ops.kmap_build(table, uniq, ksize, scale, self_map=True), a)      # without counts
