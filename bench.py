@@ -642,6 +642,26 @@ def main():
                                 "what": "configs[0] shape on the GPU: R-replica room (6 x 4.5 x 2.6 m, 250 k points, 2 cm), "
                                         "maps + eval-mode forward of %s" % args.arch}
         extra["conv_mode"] = F_.CONV_MODE
+        # multi-view feature fusion: one 320 x 240 view of a 200 k-point scene, 768-d pixel features
+        from openscene_amd.fusion import FeatureFusion, PointCloudToImageMapper, adjust_intrinsic, make_intrinsic
+        intr = adjust_intrinsic(make_intrinsic(577.870605, 577.870605, 319.5, 239.5), [640, 480], (320, 240))
+        mapper = PointCloudToImageMapper((320, 240), 0.25, 10, intr, device=device)
+        room_pts = torch.from_numpy(syn.room_points(7, n_pts=200000)).to(device=device, dtype=torch.float64)
+        c2w = np.eye(4)
+        c2w[:3, :3] = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])     # looks along +x, z up
+        c2w[:3, 3] = [0.5, 1.5, 1.3]
+        depth_img = torch.full((240, 320), 3.0, dtype=torch.float64, device=device)
+        feat_img = torch.randn(out_dim, 240, 320, device=device)
+        fuser = FeatureFusion(room_pts.shape[0], out_dim, device=device)
+        mp = mapper.compute_mapping(c2w, room_pts, depth_img)
+        p_ms = timed(lambda: mapper.compute_mapping(c2w, room_pts, depth_img), 10)
+        a_ms = timed(lambda: fuser.add_view(feat_img, mp), 10)
+        n_vis = int(mp[:, 2].sum())
+        extra["fusion_view"] = {"project_ms": p_ms, "accumulate_ms": a_ms, "n_points": int(room_pts.shape[0]), "visible": n_vis,
+                                "accumulate_GBps": (n_vis * out_dim * 12.0) / (a_ms * 1e-3) / 1e9,
+                                "what": "fusion_util.py:93-139 + scannet_openseg.py:93-106 for one view: projection with "
+                                        "occlusion test of 200 k points (fp64), then sum += feat[:, y, x] for the visible ones"}
+        del fuser, feat_img
 
     comm = None
     if world > 1:

@@ -329,6 +329,23 @@ int osn_feature_remap(const uint8_t* mask_chunk, const int64_t* vox_ind, int64_t
 int osn_batch_coords(const int32_t* xyz3, int64_t n, int batch_index, int32_t* out_coords4,
                      osn_stream_t stream);
 
+/* ---- multi-view feature fusion (the producer of the fused features the distillation trains on) ---- *
+ * osn_fusion_project: scripts/feature_fusion/fusion_util.py:93-139 (PointCloudToImageMapper.compute_mapping).
+ *   coords3 double [n, 3] (device); world_to_camera16 = np.linalg.inv(camera_to_world), row-major 4 x 4 (HOST);
+ *   intrinsic4 = {fx, fy, cx, cy} (HOST); depth double [H, W] in metres (device) or NULL (then: in front of the camera);
+ *   image is W x H pixels; cut_bound pixels of border are excluded; mapping int64 [n, 3] = (row, column, visible),
+ *   zeros where not visible -- bit-identical to the numpy code (fp64, same operation order and rounding).
+ * osn_fusion_accumulate: scripts/feature_fusion/scannet_openseg.py:93-106, one view: for visible points
+ *   counter[p] += 1, sum_features[p, :] += feat2d[:, row, column]; feat2d float [D, H, W], sum float [n, D], counter float [n].
+ * osn_fusion_finish: scannet_openseg.py:108-109: feat_bank = sum_features / (counter == 0 ? 1e-5 : counter).        */
+int osn_fusion_project(const double* coords3, int64_t n, const double* world_to_camera16, const double* intrinsic4,
+                       const double* depth, int H, int W, int cut_bound, double vis_thres, int64_t* mapping,
+                       osn_stream_t stream);
+int osn_fusion_accumulate(const float* feat2d, int D, int H, int W, const int64_t* mapping, int64_t n,
+                          float* sum_features, float* counter, osn_stream_t stream);
+int osn_fusion_finish(const float* sum_features, const float* counter, int64_t n, int D, float* feat_bank,
+                      osn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

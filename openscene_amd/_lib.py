@@ -68,6 +68,10 @@ PROTOTYPES = {
     "osn_feature_remap_ws_bytes": (_sz, [_i64, _i64]),
     "osn_feature_remap": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "osn_batch_coords": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "osn_fusion_project": (_i32, [_vp, _i64, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _vp, _i32, _i32, _i32,
+                                  _c.c_double, _vp, _vp]),
+    "osn_fusion_accumulate": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "osn_fusion_finish": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
 }
 
 _lock = threading.Lock()

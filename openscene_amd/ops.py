@@ -886,3 +886,54 @@ def batch_coords(xyz3, batch_index, out):
     with _Dev(dev):
         check(lib.osn_batch_coords(_p(xyz3), n, int(batch_index), _p(out), _stream(dev)), "osn_batch_coords")
     return out
+
+
+# ------------------------------------------------------- multi-view feature fusion
+def fusion_project(coords3, world_to_camera, intrinsic4, depth, image_hw, cut_bound, vis_thres):
+    """int64 [n, 3] (pixel row, pixel column, visible) of fusion_util.py:93-139; coords3 float64 [n, 3] on the device,
+    world_to_camera a 4x4 float64 numpy array (host), intrinsic4 = (fx, fy, cx, cy), depth float64 [H, W] device or None."""
+    dev = coords3.device
+    lib = _prep(dev)
+    if coords3.dtype != torch.float64 or coords3.dim() != 2 or coords3.shape[1] != 3:
+        raise TypeError("coords must be float64 [n, 3] (the reference concatenates with a float64 column of ones)")
+    coords3 = coords3.contiguous()
+    n = coords3.shape[0]
+    H, W = int(image_hw[0]), int(image_hw[1])
+    if depth is not None:
+        if depth.dtype != torch.float64 or tuple(depth.shape) != (H, W):
+            raise TypeError("depth must be float64 [%d, %d]" % (H, W))
+        depth = depth.contiguous()
+    m16 = (ctypes.c_double * 16)(*[float(v) for v in world_to_camera.reshape(-1)])
+    i4 = (ctypes.c_double * 4)(*[float(v) for v in intrinsic4])
+    mapping = torch.empty((n, 3), dtype=torch.int64, device=dev)
+    with _Dev(dev):
+        check(lib.osn_fusion_project(_p(coords3), n, m16, i4, _p(depth), H, W, int(cut_bound), float(vis_thres),
+                                     _p(mapping), _stream(dev)), "osn_fusion_project")
+    return mapping
+
+
+def fusion_accumulate(feat2d, mapping, sum_features, counter):
+    """One view: counter[p] += 1 and sum_features[p] += feat2d[:, row, col] for the visible points (in place)."""
+    dev = feat2d.device
+    lib = _prep(dev)
+    feat2d = _f32c(feat2d, "feat_2d")
+    D, H, W = feat2d.shape
+    n = mapping.shape[0]
+    if mapping.dtype != torch.int64 or tuple(mapping.shape) != (n, 3) or not mapping.is_contiguous():
+        raise TypeError("mapping must be a contiguous int64 [n, 3] tensor")
+    if (sum_features.dtype != torch.float32 or tuple(sum_features.shape) != (n, D) or not sum_features.is_contiguous()
+            or counter.dtype != torch.float32 or counter.numel() != n or not counter.is_contiguous()):
+        raise TypeError("sum_features must be contiguous float32 [n, D] and counter contiguous float32 [n] / [n, 1]")
+    with _Dev(dev):
+        check(lib.osn_fusion_accumulate(_p(feat2d), D, H, W, _p(mapping), n, _p(sum_features), _p(counter), _stream(dev)),
+              "osn_fusion_accumulate")
+
+
+def fusion_finish(sum_features, counter):
+    dev = sum_features.device
+    lib = _prep(dev)
+    n, D = sum_features.shape
+    bank = torch.empty_like(sum_features)
+    with _Dev(dev):
+        check(lib.osn_fusion_finish(_p(sum_features), _p(counter), n, D, _p(bank), _stream(dev)), "osn_fusion_finish")
+    return bank

@@ -336,6 +336,25 @@ def weight_prep_x6_pair(weight, flip=False):
     return weight_prep_x6(weight), weight_prep_x6(weight, flip=flip, for_dgrad=True)
 
 
+def fusion_project(coords3, world_to_camera, intrinsic4, depth, image_hw, cut_bound, vis_thres):
+    from oracle import fusion as of
+    k = np.eye(4)
+    k[0][0], k[1][1], k[0][2], k[1][2] = intrinsic4
+    m = of.compute_mapping(None, _np(coords3), None if depth is None else _np(depth), k,
+                           (image_hw[1], image_hw[0]), vis_thres, cut_bound, world_to_camera=world_to_camera)
+    return torch.from_numpy(m)
+
+
+def fusion_accumulate(feat2d, mapping, sum_features, counter):
+    from oracle import fusion as of
+    of.accumulate(sum_features, counter.view(-1, 1), feat2d, mapping)
+
+
+def fusion_finish(sum_features, counter):
+    from oracle import fusion as of
+    return of.finish(sum_features, counter.view(-1, 1))
+
+
 def weight_image(weight, flip=False, for_dgrad=False, layout=0):
     """Spec of ops.weight_image (no cache on the CPU: the image is a function of the current weight)."""
     if layout == 1:
@@ -344,7 +363,7 @@ def weight_image(weight, flip=False, for_dgrad=False, layout=0):
     return weight_prep_x6(weight, flip=flip, for_dgrad=for_dgrad)
 
 
-_NAMES = ["weight_image", "stem_eligible", "stem_conv_fwd", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
+_NAMES = ["fusion_project", "fusion_accumulate", "fusion_finish", "weight_image", "stem_eligible", "stem_conv_fwd", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
           "spconv_wgrad", "bn_stats", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
           "fnv_hash", "ravel_hash", "feature_remap", "batch_coords"]
 

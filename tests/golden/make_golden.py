@@ -118,6 +118,73 @@ def loader_cases():
         shutil.rmtree(root, ignore_errors=True)
 
 
+def fusion_cases():
+    """PointCloudToImageMapper / make_intrinsic / adjust_intrinsic of scripts/feature_fusion/fusion_util.py, executed
+    from the reference file itself (the module imports TensorFlow at the top, so only these three definitions are
+    compiled out of its syntax tree -- nothing is copied).  Three views of a room-shaped cloud: ScanNet intrinsics
+    (scannet_openseg.py:119-125) resized 640x480 -> 320x240, cut_bound 10, visibility 0.25, a z-buffer depth image
+    with noise and holes (so that both outcomes of the occlusion test occur) and one view without depth."""
+    import ast
+    import math
+    src = open("/root/reference/scripts/feature_fusion/fusion_util.py").read()
+    want = ("PointCloudToImageMapper", "make_intrinsic", "adjust_intrinsic")
+    body = [n for n in ast.parse(src).body if getattr(n, "name", None) in want]
+    ns = {"np": np, "math": math}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "fusion_util.py (subset)", "exec"), ns)
+    rng = np.random.default_rng(21)
+    n = 24000
+    # surface-ish room cloud 6 x 4.5 x 2.6 m: points on the floor, the walls and a few boxes, float32 like the scene files
+    face = rng.integers(0, 6, n)
+    pts = rng.random((n, 3)) * np.array([6.0, 4.5, 2.6])
+    pts[face == 0, 2] = 0.0
+    pts[face == 1, 0] = 0.0
+    pts[face == 2, 0] = 6.0
+    pts[face == 3, 1] = 0.0
+    pts[face == 4, 1] = 4.5
+    box = face == 5
+    pts[box] = np.array([2.0, 1.5, 0.0]) + rng.random((int(box.sum()), 3)) * np.array([1.2, 0.8, 0.9])
+    coords = pts.astype(np.float32).astype(np.float64)
+    intr = ns["make_intrinsic"](577.870605, 577.870605, 319.5, 239.5)
+    intr = ns["adjust_intrinsic"](intr, [640, 480], (320, 240))
+    mapper = ns["PointCloudToImageMapper"](image_dim=(320, 240), visibility_threshold=0.25, cut_bound=10, intrinsics=intr)
+
+    def pose(eye, yaw, pitch):
+        cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+        fwd = np.array([cy * cp, sy * cp, sp])
+        right = np.cross(fwd, [0.0, 0.0, 1.0])
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        m = np.eye(4)
+        m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = right, down, fwd, eye      # camera axes x right, y down, z forward
+        return m
+
+    out = {"coords": coords, "intrinsic": intr, "image_dim": np.array([320, 240]), "cut_bound": 10, "vis_thres": 0.25}
+    views = [((3.0, 2.2, 1.4), 0.4, -0.2), ((1.0, 1.0, 1.6), 2.3, -0.35), ((5.0, 3.5, 1.2), -2.6, 0.05)]
+    for v, (eye, yaw, pitch) in enumerate(views):
+        c2w = pose(np.array(eye), yaw, pitch)
+        # z-buffer of the cloud itself, then noise and holes
+        w2c = np.linalg.inv(c2w)
+        pc = w2c @ np.concatenate([coords, np.ones((n, 1))], 1).T
+        u = np.round(pc[0] * intr[0][0] / pc[2] + intr[0][2]).astype(int)
+        w = np.round(pc[1] * intr[1][1] / pc[2] + intr[1][2]).astype(int)
+        ok = (pc[2] > 0.1) & (u >= 0) & (u < 320) & (w >= 0) & (w < 240)
+        depth = np.full((240, 320), np.inf)
+        np.minimum.at(depth, (w[ok], u[ok]), pc[2][ok])
+        depth[np.isinf(depth)] = 0.0
+        depth *= 1.0 + rng.normal(0, 0.08, depth.shape)                       # pushes some points across the threshold
+        depth[rng.random(depth.shape) < 0.05] = 0.0                           # invalid depth pixels
+        depth = np.round(depth * 1000.0) / 1000.0                             # uint16 millimetres / depth_scale
+        out["pose%d" % v] = c2w
+        out["depth%d" % v] = depth
+        out["mapping%d" % v] = mapper.compute_mapping(c2w, coords, depth)
+    out["mapping_nodepth"] = mapper.compute_mapping(out["pose0"], coords, None)
+    # the un-adjusted intrinsics too (make_intrinsic alone) and an adjust that returns its input
+    out["intrinsic_raw"] = ns["make_intrinsic"](577.870605, 577.870605, 319.5, 239.5)
+    np.savez_compressed(os.path.join(HERE, "fusion_mapping.npz"), **out)
+    print("fusion: visible per view", [int(out["mapping%d" % v][:, 2].sum()) for v in range(3)],
+          "no depth", int(out["mapping_nodepth"][:, 2].sum()))
+
+
 if __name__ == "__main__":
     hash_kat()
     rng = np.random.default_rng(3)
@@ -126,4 +193,5 @@ if __name__ == "__main__":
     voxelize_case("voxelize_a.npz", 11, 6000, 0.02, (1.2, 0.9, 0.6))
     voxelize_case("voxelize_b.npz", 12, 20000, 0.05, (8.0, 6.0, 2.5))
     loader_cases()
+    fusion_cases()
     print("golden vectors written to", HERE)
