@@ -919,8 +919,9 @@ def fusion_accumulate(feat2d, mapping, sum_features, counter):
     feat2d = _f32c(feat2d, "feat_2d")
     D, H, W = feat2d.shape
     n = mapping.shape[0]
-    if mapping.dtype != torch.int64 or tuple(mapping.shape) != (n, 3) or not mapping.is_contiguous():
-        raise TypeError("mapping must be a contiguous int64 [n, 3] tensor")
+    if mapping.dtype != torch.int64 or tuple(mapping.shape) != (n, 3):
+        raise TypeError("mapping must be an int64 [n, 3] tensor")
+    mapping = mapping.contiguous()
     if (sum_features.dtype != torch.float32 or tuple(sum_features.shape) != (n, D) or not sum_features.is_contiguous()
             or counter.dtype != torch.float32 or counter.numel() != n or not counter.is_contiguous()):
         raise TypeError("sum_features must be contiguous float32 [n, D] and counter contiguous float32 [n] / [n, 1]")
