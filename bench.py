@@ -336,6 +336,9 @@ def cpu_baseline(seed, arch, out_dim):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dist-single", action="store_true", help="run the N > 1 code path with ONE rank: RCCL process group, "
+                    "DistributedDataParallel around the model, barriers, the timing all-reduces and the comm block "
+                    "(readiness check on a 1-GPU box; the line then carries `comm`)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--arch", default="MinkUNet18A")
@@ -368,8 +371,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    dist_on = world > 1 or args.dist_single
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
 
     from openscene_amd import ops
@@ -385,7 +390,7 @@ def main():
     model = DisNet(Cfg()).to(device)
     out_dim = model.net3d.final.out_channels
     net = model
-    if world > 1:
+    if dist_on:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
     try:
         optim = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
@@ -437,7 +442,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -471,7 +476,7 @@ def main():
     ops.set_profiler(None)
 
     tt = torch.tensor([dt, float(n_vox)], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist_on:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone()
@@ -664,7 +669,7 @@ def main():
         del fuser, feat_img
 
     comm = None
-    if world > 1:
+    if dist_on:
         # exchange step of the path: the DDP gradient all-reduce (RCCL over xGMI).  Its stand-alone time on a flat
         # buffer of the model's size bounds what DDP has to hide behind backward.
         flat = torch.zeros(sum(p.numel() for p in model.parameters()), device=device)
@@ -680,7 +685,7 @@ def main():
                 "allreduce_ms_standalone": ar_ms, "share_of_step_if_exposed": ar_ms / (dt_max * 1e3 / args.steps)}
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -760,7 +765,7 @@ def main():
         "kernels": kernels, "loss": float(loss.detach()),
     }
     print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
