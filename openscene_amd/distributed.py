@@ -1,0 +1,77 @@
+"""The path's one exchange step: the data-parallel gradient all-reduce of
+``run/distill.py:149-150`` (``DistributedDataParallel`` around the model), sized for xGMI.
+
+torch's DDP works on these modules unchanged (plain ``nn.Parameter``s, tested) -- but its reducer handles every
+parameter separately: per step and parameter one copy into the bucket and one division by the world size, 290 extra
+launches and +2.3 ms on a 14.7 ms step for the 145 parameters of MinkUNet18A (measured with one rank on an MI355X,
+``tools/ab_ddp.sh``), before a byte moves.  The model's gradients are 62 MB: over xGMI that is ONE collective of a
+fraction of a millisecond, so there is nothing to hide behind backward and no reason to bucket.
+``FlatGradAllReduce`` therefore keeps one flat fp32 buffer, gathers the gradients into it with one multi-tensor copy
+after backward, averages it with one all-reduce (backend ``nccl`` = RCCL on ROCm; ``gloo`` in the CPU tests) and hands
+the optimizer views of that buffer.  Same arithmetic as DDP: parameters (and buffers) broadcast from rank 0 at
+construction, gradient = mean over ranks, BN running statistics broadcast from rank 0 before each forward
+(``broadcast_buffers=True`` is DDP's default and what the reference runs with)."""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradAllReduce(object):
+    def __init__(self, module, broadcast_buffers=True, process_group=None):
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("module has no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        if any(p.device != dev or p.dtype != dt for p in self.params):
+            raise ValueError("FlatGradAllReduce needs all parameters on one device with one dtype")
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.buffers = [b for b in module.buffers() if b.is_floating_point()] if broadcast_buffers else []
+        self.int_buffers = [b for b in module.buffers() if not b.is_floating_point()] if broadcast_buffers else []
+        # rank 0's parameters and buffers everywhere (DDP does the same when it wraps the module)
+        self._broadcast([p.data for p in self.params])
+        self._broadcast([b.data for b in module.buffers()])
+
+    def _broadcast(self, tensors):
+        by_type = {}
+        for t in tensors:
+            by_type.setdefault(t.dtype, []).append(t)
+        for ts in by_type.values():
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.broadcast(flat, 0, group=self.group)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+
+    def sync_buffers(self):
+        """Before a forward: rank 0's buffers (BN running statistics, counters) on every rank, as DDP's
+        broadcast_buffers=True does.  One collective per dtype."""
+        if self.world > 1 and (self.buffers or self.int_buffers):
+            self._broadcast([b.data for b in self.buffers])
+            self._broadcast([b.data for b in self.int_buffers])
+
+    def reduce_gradients(self):
+        """After backward: p.grad <- mean over ranks, as views of the flat buffer (no copy back)."""
+        grads = []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()                           # unused parameter: contributes zero, like DDP with find_unused_parameters
+                grads.append(None)
+            else:
+                grads.append(p.grad)
+        src = [g for g in grads if g is not None]
+        dst = [v for g, v in zip(grads, self.views) if g is not None]
+        same = all(g.data_ptr() == v.data_ptr() for g, v in zip(src, dst))
+        if not same:
+            torch._foreach_copy_(dst, src)          # one multi-tensor copy into the flat buffer
+        if self.world > 1:
+            self.flat.div_(self.world)
+            dist.all_reduce(self.flat, group=self.group)
+        for p, v in zip(self.params, self.views):
+            p.grad = v

@@ -163,3 +163,46 @@ def test_ddp_four_ranks_unequal_scenes_distributed_sampler(tmp_path):
         import importlib
         import openscene_amd.ops as ops
         importlib.reload(ops)
+
+
+# ---- the flat one-collective exchange (openscene_amd/distributed.py) gives what DDP gives: same broadcast parameters,
+# gradients = mean over the ranks (same scenes as above), buffers of rank 0 on every rank after sync_buffers.
+def _worker_flat(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    _install_cpu_backend()
+    from openscene_amd.distributed import FlatGradAllReduce
+    from openscene_amd.mink_unet import mink_unet
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    model = mink_unet(3, 8, 3, "MinkUNet14A").double()
+    ex = FlatGradAllReduce(model)
+    optim = torch.optim.SGD(model.parameters(), lr=1e-2)
+    first = None
+    for step in range(2):
+        ex.sync_buffers()
+        optim.zero_grad(set_to_none=True)
+        _loss(model, seed=10 + rank + 2 * step).backward()
+        ex.reduce_gradients()
+        if step == 0:
+            first = {n: p.grad.clone() for n, p in model.named_parameters()}
+        optim.step()
+    torch.save({"grads": first, "params": {n: p.detach().clone() for n, p in model.named_parameters()},
+                "bufs": {n: b.detach().clone() for n, b in model.named_buffers()}}, os.path.join(out_dir, "f%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_equals_ddp(tmp_path):
+    world = 2
+    mp.spawn(_worker_flat, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)          # DDP, first step only
+    f0 = torch.load(os.path.join(tmp_path, "f0.pt"))
+    f1 = torch.load(os.path.join(tmp_path, "f1.pt"))
+    d0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    for n in f0["params"]:
+        assert torch.equal(f0["params"][n], f1["params"][n]), "parameters diverged at %s" % n
+        assert torch.equal(f0["grads"][n], f1["grads"][n]), "gradient %s differs between ranks" % n
+        scale = d0["grads"][n].abs().max().item() + 1e-12
+        assert (f0["grads"][n] - d0["grads"][n]).abs().max().item() <= 1e-12 * scale + 1e-15, n     # == DDP's mean
