@@ -153,7 +153,7 @@ int osn_spconv_fwd_x6(const float* in, const void* Wp, const int32_t* nbr, const
  *                                   row j; tl = null <=> K == 1 identity map.  bn_partial (nullable):
  *                                   double [n_tiles][2][cout] per-tile column sums / sums of squares of
  *                                   `out` (the following batch norm's statistics without a pass over out).
- *                                   ws: osn_spconv_fwd_tl_ws_bytes(..) bytes: tile counters (zeroed by the call) and, on
+ *                                   ws: osn_spconv_fwd_tl_ws_bytes(..) bytes: tile counters (512 bytes, zeroed by the call) and, on
  *                                   small tables, the partial tiles of a launch that splits each tile's offsets over
  *                                   several workgroups (summed in a fixed order; bn_partial must be null there).
  *                                   Needs cin % 4 == 0, cout % 4 == 0 and n_in <= 2^24 (OSN_E_RANGE otherwise).  */
@@ -164,9 +164,15 @@ size_t osn_weight_prep_tl_bytes(int K, int cin, int cout, int for_dgrad);
 int osn_weight_prep_tl(const float* W, int K, int cin, int cout, int flip, void* Wp_fwd, void* Wp_dgrad,
                        osn_stream_t stream);
 size_t osn_spconv_fwd_tl_ws_bytes(int64_t n_out, int K, int cout, int bm);
+/* osn_spconv_fwd_tl_pc: the same call with caller-owned PERSISTENT tile counters (128 int32 in device memory, zero before
+ * the first call, one buffer per stream): the kernel's last workgroup puts them back to zero, so the call needs no memset
+ * launch.  A launch that fails leaves them undefined (zero them again).                                                  */
 int osn_spconv_fwd_tl(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
                       float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm,
                       void* ws, size_t ws_bytes, osn_stream_t stream);
+int osn_spconv_fwd_tl_pc(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
+                         float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm,
+                         void* ws, size_t ws_bytes, int32_t* counters, osn_stream_t stream);
 
 /* ---- every weight image of a model in one launch ----------------------------------------------- *
  * [ME] keeps one `kernel` parameter per MinkowskiConvolution / MinkowskiConvolutionTranspose

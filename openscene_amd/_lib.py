@@ -43,6 +43,7 @@ PROTOTYPES = {
     "osn_weight_prep_batch": (_i32, [_vp, _i32, _i64, _vp]),
     "osn_spconv_fwd_tl_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "osn_spconv_fwd_tl": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "osn_spconv_fwd_tl_pc": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp, _vp]),
     "osn_weight_transpose": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "osn_spconv_wgrad_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "osn_spconv_wgrad_items_bytes": (_sz, [_i64, _i32, _i32, _i32]),

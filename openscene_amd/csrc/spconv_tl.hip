@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                                                                double* __restrict__ bn_partial, int32_t* __restrict__ counter,
                                                                float* __restrict__ partial, int nz, int n_out, int K, int cin,
                                                                int cout, int bm, int n_tiles, int ns, int ncb,
-                                                               long long* __restrict__ prof) {
+                                                               int self_reset, long long* __restrict__ prof) {
     constexpr int NT = 256;
     constexpr int CW = 32 * NW;               // output columns of the workgroup
     constexpr int S = CW + 4;                 // fp32 row stride of the output tile
@@ -480,6 +480,15 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
     }
     if (PROF && tid == 0 && blockIdx.y == 0)
         for (int i = 0; i < 10; ++i) prof[int64_t(blockIdx.x) * 10 + i] = tacc[i];
+    // caller-owned persistent counters: the last workgroup of a column group to leave (every other one has made its final
+    // draw before it took its exit ticket) puts both counters back to zero for the next launch -- no memset per call
+    if (self_reset && tid == 0) {
+        const int done = atomicAdd(&counter[64 + blockIdx.y], 1);
+        if (done == int(gridDim.x) - 1) {
+            counter[blockIdx.y] = 0;
+            counter[64 + blockIdx.y] = 0;
+        }
+    }
 }
 #undef TL_TICK
 
@@ -557,9 +566,9 @@ static int tl_split(int64_t n_out, int K, int cout, int bm) {
 
 // tile counters (one per column group; MUST be zero on entry, left dirty) + the partial tiles of a split launch
 extern "C" size_t osn_spconv_fwd_tl_ws_bytes(int64_t n_out, int K, int cout, int bm) {
-    if (bm < 1) return 256;
+    if (bm < 1) return 512;
     const int nz = tl_split(n_out, K, cout, bm);
-    return 256 + (nz > 1 ? size_t(nz) * size_t(n_out) * size_t(cout) * 4 : 0);
+    return 512 + (nz > 1 ? size_t(nz) * size_t(n_out) * size_t(cout) * 4 : 0);
 }
 
 // out[out_rows ? out_rows[r] : r] = partial[0][r] + partial[1][r] + ...  (fixed order)
@@ -583,7 +592,7 @@ __global__ void tl_reduce_parts_kernel(const float4* __restrict__ partial, int S
 
 static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
                               float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm, void* ws,
-                              size_t ws_bytes, long long* prof, osn_stream_t stream) {
+                              size_t ws_bytes, int32_t* counters, long long* prof, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_spconv_fwd_tl: n_out out of range");
     OSN_REQUIRE(K >= 1 && K <= TL_KMAX && cin >= 4 && (cin & 3) == 0 && cout >= 4 && (cout & 3) == 0, OSN_E_ARG,
@@ -601,9 +610,13 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
     const size_t need = osn_spconv_fwd_tl_ws_bytes(n_out, tl ? K : 1, cout, bm);
     OSN_REQUIRE(ws && ws_bytes >= need && gy <= 64, OSN_E_WS, "osn_spconv_fwd_tl: workspace %zu < %zu (or more than 64 column groups)", ws_bytes, need);
     OSN_REQUIRE(!(bn_partial && nz > 1), OSN_E_ARG, "osn_spconv_fwd_tl: bn_partial is not available on split (small-table) launches");
-    OSN_HIP(hipMemsetAsync(ws, 0, 256, st));
-    int32_t* counter = static_cast<int32_t*>(ws);
-    float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + 256);
+    int32_t* counter = counters;
+    if (!counter) {                                  // no persistent counters: the head of the workspace, zeroed here
+        OSN_HIP(hipMemsetAsync(ws, 0, 512, st));
+        counter = static_cast<int32_t*>(ws);
+    }
+    const int self_reset = counters ? 1 : 0;
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + 512);
     const int32_t* cnt = nullptr;
     const int2* lst = nullptr;
     const int64_t n_tiles = cdiv(n_out, bm);
@@ -620,10 +633,10 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
     do {                                                                                                                   \
         if (prof)                                                                                                          \
             hipLaunchKernelGGL((spconv_tl_kernel<NW_, true>), grid, dim3(256), 0, st, in, wp, cnt, lst, out_rows, out,   \
-                               bn_partial, counter, partial, nz, int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, prof); \
+                               bn_partial, counter, partial, nz, int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof); \
         else                                                                                                               \
             hipLaunchKernelGGL((spconv_tl_kernel<NW_, false>), grid, dim3(256), 0, st, in, wp, cnt, lst, out_rows, out,  \
-                               bn_partial, counter, partial, nz, int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, prof); \
+                               bn_partial, counter, partial, nz, int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof); \
     } while (0)
     switch (nw) {
         case 4: OSN_TL(4); break;
@@ -647,7 +660,16 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
 extern "C" int osn_spconv_fwd_tl(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
                                  float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm, void* ws,
                                  size_t ws_bytes, osn_stream_t stream) {
-    return spconv_fwd_tl_impl(in, n_in, Wp, tl, out_rows, out, bn_partial, n_out, K, cin, cout, bm, ws, ws_bytes, nullptr, stream);
+    return spconv_fwd_tl_impl(in, n_in, Wp, tl, out_rows, out, bn_partial, n_out, K, cin, cout, bm, ws, ws_bytes, nullptr, nullptr,
+                              stream);
+}
+
+extern "C" int osn_spconv_fwd_tl_pc(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
+                                    float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm, void* ws,
+                                    size_t ws_bytes, int32_t* counters, osn_stream_t stream) {
+    OSN_REQUIRE(counters, OSN_E_ARG, "osn_spconv_fwd_tl_pc: null counters (128 int32, zero before the first call)");
+    return spconv_fwd_tl_impl(in, n_in, Wp, tl, out_rows, out, bn_partial, n_out, K, cin, cout, bm, ws, ws_bytes, counters, nullptr,
+                              stream);
 }
 
 // Tools only (not part of include/openscene_amd.h): the same launch with the phase timers of wave 0 of every
@@ -655,5 +677,5 @@ extern "C" int osn_spconv_fwd_tl(const float* in, int64_t n_in, const void* Wp, 
 extern "C" int osn_dbg_spconv_fwd_tl_prof(const float* in, int64_t n_in, const void* Wp, const void* tl,
                                           const int32_t* out_rows, float* out, int64_t n_out, int K, int cin, int cout,
                                           int bm, void* ws, size_t ws_bytes, long long* prof, osn_stream_t stream) {
-    return spconv_fwd_tl_impl(in, n_in, Wp, tl, out_rows, out, nullptr, n_out, K, cin, cout, bm, ws, ws_bytes, prof, stream);
+    return spconv_fwd_tl_impl(in, n_in, Wp, tl, out_rows, out, nullptr, n_out, K, cin, cout, bm, ws, ws_bytes, nullptr, prof, stream);
 }

@@ -501,6 +501,9 @@ def weight_image(weight, flip=False, for_dgrad=False, layout=PREP_X6):
         return e.image
 
 
+_tl_counters = {}
+
+
 def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
     """out[o] = sum_k feats[list rows] @ B[k] with B given as a weight_prep_tl image; tl None <=> K == 1 identity.
     bn_partial: optional float64 [n_tiles, 2, cout] receiving per-tile column sums / sums of squares."""
@@ -522,9 +525,14 @@ def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
     ws = _ws(_cached("osn_spconv_fwd_tl_ws_bytes", n_out, K if tl is not None else 1, cout, bm), dev)
     tok = _prof_start("spconv_fwd_tl", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout)
+    st = _stream(dev)
+    ck = (_idx(dev), st)
+    counters = _tl_counters.get(ck)
+    if counters is None:                # 128 tile counters per (device, stream), zero once: the kernel leaves them zero
+        counters = _tl_counters[ck] = torch.zeros(128, dtype=torch.int32, device=dev)
     with _Dev(dev):
-        check(lib.osn_spconv_fwd_tl(_p(feats), feats.shape[0], _p(wp), _p(buf), _p(rows), _p(out), _p(bn_partial), n_out,
-                                    K, cin, cout, bm, _p(ws), ws.numel(), _stream(dev)), "osn_spconv_fwd_tl")
+        check(lib.osn_spconv_fwd_tl_pc(_p(feats), feats.shape[0], _p(wp), _p(buf), _p(rows), _p(out), _p(bn_partial), n_out,
+                                       K, cin, cout, bm, _p(ws), ws.numel(), _p(counters), st), "osn_spconv_fwd_tl_pc")
     if tok is not None:
         _profiler.stop(tok)
     return out

@@ -33,7 +33,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert lib.osn_tile_rows(100999) == 88 and lib.osn_tile_rows(3052) == 32 and lib.osn_tile_rows(47618) == 48
     assert lib.osn_weight_prep_tl_bytes(27, 96, 96, 0) == 3 * 27 * 3 * 6 * 1024
     assert lib.osn_tile_lists_bytes(1000, 27, 32) > 27 * 1000 * 8 and lib.osn_pair_lists_bytes(1000, 27, 32) > 2 * 27 * 1000 * 4
-    assert lib.osn_spconv_fwd_tl_ws_bytes(100999, 27, 96, 88) == 256                 # big table: no offset split
+    assert lib.osn_spconv_fwd_tl_ws_bytes(100999, 27, 96, 88) == 512                 # big table: no offset split
     assert lib.osn_spconv_fwd_tl_ws_bytes(700, 27, 256, 32) > 256                    # small table: partial tiles
 
 

@@ -379,3 +379,30 @@ def test_weight_image_cache_batches_and_follows_the_parameter_version():
             for p in params:
                 p.add_(0.01 * torch.randn(p.shape, generator=g).to(dev()))
     ops.clear_weight_cache()
+
+
+def test_tile_list_conv_leaves_its_persistent_counters_zero():
+    """osn_spconv_fwd_tl_pc: caller-owned tile counters, zero before the first call and put back to zero by the last
+    workgroup of every launch (no memset per call): many launches of different shapes in a row stay correct and
+    bitwise repeatable, and the counters read zero afterwards."""
+    from openscene_amd import ops
+    cm = cloud("big")
+    nbr = torch.from_numpy(cm.kmap(1, 1, 3)).to(dev())
+    n = nbr.shape[1]
+    tl = ops.tile_lists(nbr)
+    g = torch.Generator().manual_seed(2)
+    outs = []
+    for rnd in range(3):
+        for cin, cout in ((32, 32), (96, 128), (64, 20)):
+            x = torch.randn(n, cin, generator=torch.Generator().manual_seed(cin)).to(dev())
+            w = (torch.randn(27, cin, cout, generator=torch.Generator().manual_seed(cout)) * 0.1).to(dev())
+            wf, _ = ops.weight_prep_tl(w, want_dgrad=False)
+            out = ops.spconv_fwd_tl(x, wf, tl, n, 27, cout)
+            if rnd == 0:
+                ref = ops.spconv_fwd_x6(x, ops.weight_prep_x6(w), nbr, n)
+                close(out, ref, "tile-list conv %d->%d" % (cin, cout), tol=2e-6)
+                outs.append(out)
+            else:
+                assert torch.equal(out, outs[[(32, 32), (96, 128), (64, 20)].index((cin, cout))])
+    torch.cuda.synchronize()
+    assert ops._tl_counters and all(int(c.abs().sum()) == 0 for c in ops._tl_counters.values())

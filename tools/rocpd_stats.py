@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Per-kernel statistics (calls, total / average duration) from a rocprofv3 rocpd database
 (`rocprofv3 --kernel-trace --stats -d DIR -o NAME -- cmd` writes NAME_results.db on this ROCm), as CSV.
-usage: rocpd_stats.py trace_results.db [steps]   (steps: divide the calls / totals to per-step figures)"""
+usage: rocpd_stats.py trace_results.db [steps]   (steps: divide the calls / totals to per-step figures)
+       rocpd_stats.py trace_results.db --dispatches PATTERN [N]   (durations in us of the last N dispatches of the kernels
+                                                                   whose name contains PATTERN, in launch order)"""
 import re
 import sqlite3
 import sys
@@ -13,8 +15,19 @@ def short(name):
     return name[:110]
 
 
+def dispatches(db, pattern, n):
+    rows = db.cursor().execute("select s.kernel_name, d.start, d.end - d.start from rocpd_kernel_dispatch d join "
+                               "rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start").fetchall()
+    sel = [(short(k), dur / 1e3) for k, _, dur in rows if pattern in k][-n:]
+    print("# last %d dispatches of kernels matching %r (us, launch order)" % (len(sel), pattern))
+    for k, us in sel:
+        print("%-60s %9.2f" % (k[:60], us))
+
+
 def main():
     db = sqlite3.connect(sys.argv[1])
+    if len(sys.argv) > 3 and sys.argv[2] == "--dispatches":
+        return dispatches(db, sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 64)
     steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
     cur = db.cursor()
     rows = cur.execute("select s.kernel_name, count(*), sum(d.end - d.start), min(d.end - d.start), max(d.end - d.start) "
