@@ -531,8 +531,12 @@ def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
     if counters is None:                # 128 tile counters per (device, stream), zero once: the kernel leaves them zero
         counters = _tl_counters[ck] = torch.zeros(128, dtype=torch.int32, device=dev)
     with _Dev(dev):
-        check(lib.osn_spconv_fwd_tl_pc(_p(feats), feats.shape[0], _p(wp), _p(buf), _p(rows), _p(out), _p(bn_partial), n_out,
-                                       K, cin, cout, bm, _p(ws), ws.numel(), _p(counters), st), "osn_spconv_fwd_tl_pc")
+        try:
+            check(lib.osn_spconv_fwd_tl_pc(_p(feats), feats.shape[0], _p(wp), _p(buf), _p(rows), _p(out), _p(bn_partial), n_out,
+                                           K, cin, cout, bm, _p(ws), ws.numel(), _p(counters), st), "osn_spconv_fwd_tl_pc")
+        except Exception:
+            _tl_counters.pop(ck, None)      # a failed launch leaves the counters undefined: start from a fresh zero buffer
+            raise
     if tok is not None:
         _profiler.stop(tok)
     return out
