@@ -401,7 +401,7 @@ def main():
         # one flat 62 MB all-reduce per step instead of DDP's per-parameter reducer (openscene_amd/distributed.py:
         # same arithmetic, 290 launches and ~2 ms per step less; nothing needs hiding behind backward over xGMI)
         from openscene_amd.distributed import FlatGradAllReduce
-        exchange = FlatGradAllReduce(model)
+        exchange = FlatGradAllReduce(model, single_rank_collectives=args.dist_single)
     try:
         optim = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
     except (TypeError, RuntimeError):

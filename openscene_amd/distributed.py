@@ -16,10 +16,14 @@ import torch.distributed as dist
 
 
 class FlatGradAllReduce(object):
-    def __init__(self, module, broadcast_buffers=True, process_group=None):
+    def __init__(self, module, broadcast_buffers=True, process_group=None, single_rank_collectives=False):
+        """single_rank_collectives: issue the broadcasts / the all-reduce also in a one-rank group (readiness checks of the
+        N > 1 path on one GPU; a real one-rank job skips them)."""
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        self.collectives = self.world > 1 or single_rank_collectives
         self.params = [p for p in module.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("module has no trainable parameters")
@@ -38,21 +42,25 @@ class FlatGradAllReduce(object):
         self._broadcast([b.data for b in module.buffers()])
 
     def _broadcast(self, tensors):
+        """rank 0's values into `tensors` on every rank: one flat buffer, one collective and one multi-tensor copy per dtype."""
         by_type = {}
         for t in tensors:
             by_type.setdefault(t.dtype, []).append(t)
         for ts in by_type.values():
             flat = torch.cat([t.reshape(-1) for t in ts])
             dist.broadcast(flat, 0, group=self.group)
-            off = 0
+            if self.rank == 0:
+                continue                            # the source already holds these values
+            views, off = [], 0
             for t in ts:
-                t.copy_(flat[off:off + t.numel()].view_as(t))
+                views.append(flat[off:off + t.numel()].view_as(t))
                 off += t.numel()
+            torch._foreach_copy_(ts, views)
 
     def sync_buffers(self):
         """Before a forward: rank 0's buffers (BN running statistics, counters) on every rank, as DDP's
         broadcast_buffers=True does.  One collective per dtype."""
-        if self.world > 1 and (self.buffers or self.int_buffers):
+        if self.collectives and (self.buffers or self.int_buffers):
             self._broadcast([b.data for b in self.buffers])
             self._broadcast([b.data for b in self.int_buffers])
 
@@ -70,8 +78,9 @@ class FlatGradAllReduce(object):
         same = all(g.data_ptr() == v.data_ptr() for g, v in zip(src, dst))
         if not same:
             torch._foreach_copy_(dst, src)          # one multi-tensor copy into the flat buffer
-        if self.world > 1:
-            self.flat.div_(self.world)
+        if self.collectives:
+            if self.world > 1:
+                self.flat.div_(self.world)
             dist.all_reduce(self.flat, group=self.group)
         for p, v in zip(self.params, self.views):
             p.grad = v
