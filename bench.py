@@ -402,6 +402,7 @@ def main():
         # same arithmetic, 290 launches and ~2 ms per step less; nothing needs hiding behind backward over xGMI)
         from openscene_amd.distributed import FlatGradAllReduce
         exchange = FlatGradAllReduce(model, single_rank_collectives=args.dist_single)
+        exchange.sync_buffers()     # rank 0's BN running statistics: needed before evaluation / checkpoints, not per step
     try:
         optim = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
     except (TypeError, RuntimeError):
@@ -441,8 +442,6 @@ def main():
             sinput = SparseTensor(feats, coordinate_manager=pf.take(pending[0]))
         else:
             sinput = SparseTensor(feats, next_coords())            # builds every map (ME does per forward)
-        if exchange is not None:
-            exchange.sync_buffers()                                # rank 0's BN running statistics, as DDP's default does
         out = net(sinput)
         loss = (1 - cos(out.index_select(0, sel), feat_3d)).mean()  # = out[mask], run/distill.py:322-326
         optim.zero_grad(set_to_none=True)
