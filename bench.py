@@ -370,6 +370,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if os.environ.get("OSN_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0              # functional test of the N > 1 control flow on a 1-GPU box (with OSN_DIST_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -377,7 +379,7 @@ def main():
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
+        dist.init_process_group(backend=os.environ.get("OSN_DIST_BACKEND", "nccl"), rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
 
     from openscene_amd import ops
     from openscene_amd.disnet import DisNet
