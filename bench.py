@@ -647,7 +647,7 @@ def main():
         ms512 = variant_step_ms(device, args.arch, "lseg", coords0)
         ms34 = variant_step_ms(device, "MinkUNet34C", args.feature, lidar_coords, steps=3, warmup=2)
         ms34i = variant_step_ms(device, "MinkUNet34C", args.feature, lidar_coords, steps=3, warmup=1, train=False)
-        msrep = variant_step_ms(device, args.arch, args.feature, replica_coords, steps=5, warmup=2, train=False)
+        msrep = variant_step_ms(device, args.arch, args.feature, replica_coords, steps=5, warmup=3, train=False)
         extra["step_exact_fp32"] = {"ms": ms32, "voxels_per_s": n_vox / (ms32 * 1e-3),
                                     "what": "the headline step with OSN_CONV_MODE=fp32 (fp32-input MFMA, exact fp32 products)"}
         extra["step_d512"] = {"ms": ms512, "voxels_per_s": n_vox / (ms512 * 1e-3),
