@@ -264,6 +264,12 @@ int osn_bn_stats(const float* x, int64_t n, int c, float* mean, float* var,
 int osn_bn_apply(const float* x, const float* mean, const float* var, const float* gamma,
                  const float* beta, float eps, const float* residual, int relu, float* y,
                  int64_t n, int c, osn_stream_t stream);
+/* osn_bn_stats + osn_bn_apply in one call (training-mode forward of MinkowskiBatchNorm [+ residual] [+ MinkowskiReLU],
+ * models/mink_unet.py:116-174; mean / var are outputs kept for the backward).                                      */
+int osn_bn_forward_train(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
+                         const float* residual, int relu, float momentum, float* mean, float* var,
+                         float* running_mean, float* running_var, float* y, void* ws, size_t ws_bytes,
+                         osn_stream_t stream);
 /* Backward of osn_bn_apply.  g = relu ? gy * (y > 0) : gy.
  * training != 0 (batch statistics were used):
  *   gx = gamma * invstd * (g - mean_rows(g) - xhat * mean_rows(g * xhat))

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "osn_bn_ws_bytes": (_sz, [_i64, _i32]),
     "osn_bn_stats": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _sz, _vp]),
     "osn_bn_apply": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _i64, _i32, _vp]),
+    "osn_bn_forward_train": (_i32, [_vp, _i64, _i32, _vp, _vp, _f32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "osn_bn_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32,
                                _vp, _sz, _vp]),
     "osn_cosine_query": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),

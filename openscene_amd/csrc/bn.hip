@@ -282,6 +282,18 @@ extern "C" int osn_bn_apply(const float* x, const float* mean, const float* var,
     return OSN_OK;
 }
 
+// Training-mode forward in ONE call: statistics (+ running buffers) and the fused normalise (+ residual) (+ ReLU) pass.
+// Same kernels as osn_bn_stats + osn_bn_apply; one trip through the host binding instead of two (the deep U-Net levels
+// are bound by the host's launch rate, and there are 48 of these per step).
+extern "C" int osn_bn_forward_train(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
+                                    const float* residual, int relu, float momentum, float* mean, float* var,
+                                    float* running_mean, float* running_var, float* y, void* ws, size_t ws_bytes,
+                                    osn_stream_t stream) {
+    int rc = osn_bn_stats(x, n, c, mean, var, running_mean, running_var, momentum, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return osn_bn_apply(x, mean, var, gamma, beta, eps, residual, relu, y, n, c, stream);
+}
+
 extern "C" int osn_bn_backward(const float* x, const float* y, const float* gy, const float* mean, const float* var,
                                const float* gamma, float eps, int relu, int training, float* gx, float* gres,
                                float* ggamma, float* gbeta, int64_t n, int c, void* ws, size_t ws_bytes,

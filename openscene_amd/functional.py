@@ -121,10 +121,10 @@ class BatchNormActFunction(Function):
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu):
         x = x.contiguous()
         if training:
-            mean, var = ops.bn_stats(x, running_mean, running_var, momentum)
+            y, mean, var = ops.bn_forward_train(x, gamma, beta, eps, residual, relu, running_mean, running_var, momentum)
         else:
             mean, var = running_mean, running_var
-        y = ops.bn_apply(x, mean, var, gamma, beta, eps, residual, relu)
+            y = ops.bn_apply(x, mean, var, gamma, beta, eps, residual, relu)
         ctx.save_for_backward(x, y if relu else None, mean, var, gamma)
         ctx.cfg = (bool(training), float(eps), bool(relu), residual is not None)
         return y

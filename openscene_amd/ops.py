@@ -737,6 +737,26 @@ def bn_apply(x, mean, var, gamma, beta, eps, residual=None, relu=False):
     return y
 
 
+def bn_forward_train(x, gamma, beta, eps, residual, relu, running_mean, running_var, momentum):
+    """(y, mean, var): batch statistics (running buffers updated in place) + normalise (+ residual) (+ ReLU), one C call."""
+    dev = x.device
+    lib = _prep(dev)
+    x = _f32c(x, "x")
+    n, c = x.shape
+    if residual is not None:
+        residual = _f32c(residual, "residual")
+        if residual.shape != x.shape:
+            raise ValueError("residual shape %s != %s" % (tuple(residual.shape), tuple(x.shape)))
+    mv = torch.empty((2, c), dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    ws = _ws(_cached("osn_bn_ws_bytes", n, c), dev)
+    with _Dev(dev):
+        check(lib.osn_bn_forward_train(_p(x), n, c, _p(gamma), _p(beta), float(eps), _p(residual), int(bool(relu)),
+                                       float(momentum), _p(mv[0]), _p(mv[1]), _p(running_mean), _p(running_var), _p(y),
+                                       _p(ws), ws.numel(), _stream(dev)), "osn_bn_forward_train")
+    return y, mv[0], mv[1]
+
+
 def bn_backward(x, y, gy, mean, var, gamma, eps, relu, training, want_gres):
     dev = x.device
     lib = _prep(dev)

@@ -267,6 +267,11 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1):
     return mean, var
 
 
+def bn_forward_train(x, gamma, beta, eps, residual, relu, running_mean, running_var, momentum):
+    mean, var = bn_stats(x, running_mean, running_var, momentum)
+    return bn_apply(x, mean, var, gamma, beta, eps, residual, relu), mean, var
+
+
 def bn_apply(x, mean, var, gamma, beta, eps, residual=None, relu=False):
     y = (x - mean) * torch.rsqrt(var + eps) * gamma + beta
     if residual is not None:
@@ -364,7 +369,7 @@ def weight_image(weight, flip=False, for_dgrad=False, layout=0):
 
 
 _NAMES = ["fusion_project", "fusion_accumulate", "fusion_finish", "weight_image", "stem_eligible", "stem_conv_fwd", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
-          "spconv_wgrad", "bn_stats", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
+          "spconv_wgrad", "bn_stats", "bn_forward_train", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
           "fnv_hash", "ravel_hash", "feature_remap", "batch_coords"]
 
 
