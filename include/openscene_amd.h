@@ -66,6 +66,17 @@ int osn_coords_unique(const int32_t* coords4, int64_t n, int stride,
                       int32_t* out_coords4, int32_t* inverse, int32_t* first,
                       int64_t* n_unique_host, void* ws, size_t ws_bytes, osn_stream_t stream);
 
+/* The same unique pipeline WITHOUT the host synchronisation, for chaining the levels of a coordinate pyramid
+ * (models/mink_unet.py:52-74: four stride-2 levels are created per forward): everything is sized for n_max rows;
+ * n_dev (nullable) = the actual row count in device memory (the previous level's count_dev), count_dev receives
+ * this level's number of unique rows, err_dev is a sticky flag (zeroed by the caller) set on a coordinate outside
+ * the packable range.  The caller reads all counts and the flag back ONCE.  Identical results to
+ * osn_coords_unique on the first `count` rows.                                                                */
+int osn_coords_unique_async(const int32_t* coords4, int64_t n_max, const int32_t* n_dev, int stride,
+                            uint64_t* table_keys, int32_t* table_vals, int64_t cap, int32_t* out_coords4,
+                            int32_t* inverse, int32_t* first, int32_t* count_dev, int32_t* err_dev,
+                            void* ws, size_t ws_bytes, osn_stream_t stream);
+
 /* Replaces [ME] CoordinateManager.kernel_map (HYPER_CUBE region).  Offsets
  * enumerate with x fastest; odd ksize centred, even ksize spans [0,ksize); all
  * multiplied by `offset_scale` (= dilation * tensor stride of the INPUT map).  */

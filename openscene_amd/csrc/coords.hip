@@ -25,8 +25,13 @@ __device__ inline int wave_incl_scan(int v, int lane) {
     return v;
 }
 
+// (every kernel of the unique pipeline takes the row count either from the host (n) or, when n_dev is given, from device
+// memory: a level of the coordinate pyramid can then be queued before the previous level's count has reached the host;
+// the grid is sized by an upper bound and the surplus threads leave)
 __global__ __launch_bounds__(SCAN_TPB) void scan_block_kernel(const int* __restrict__ in, int* __restrict__ out,
-                                                              int* __restrict__ sums, int64_t n) {
+                                                              int* __restrict__ sums, int64_t n,
+                                                              const int32_t* __restrict__ n_dev) {
+    if (n_dev) n = *n_dev;
     __shared__ int wave_tot[SCAN_TPB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t base = int64_t(blockIdx.x) * SCAN_BLOCK + int64_t(tid) * SCAN_IPT;
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_block_kernel(const int* __restr
 }
 
 // Single block: exclusive scan of the block sums in place; total -> sums[nb].
-__global__ __launch_bounds__(1024) void scan_sums_kernel(int* __restrict__ sums, int nb) {
+__global__ __launch_bounds__(1024) void scan_sums_kernel(int* __restrict__ sums, int nb, int32_t* __restrict__ total_out) {
     __shared__ int wave_tot[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,11 +79,15 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(int* __restrict__ sums,
         if (tid == 1023) carry_s = carry + woff + incl;
         __syncthreads();
     }
-    if (tid == 0) sums[nb] = carry_s;
+    if (tid == 0) {
+        sums[nb] = carry_s;
+        if (total_out) *total_out = carry_s;
+    }
 }
 
 __global__ __launch_bounds__(SCAN_TPB) void scan_add_kernel(int* __restrict__ out, const int* __restrict__ sums,
-                                                            int64_t n) {
+                                                            int64_t n, const int32_t* __restrict__ n_dev) {
+    if (n_dev) n = *n_dev;
     const int64_t base = int64_t(blockIdx.x) * SCAN_BLOCK + int64_t(threadIdx.x) * SCAN_IPT;
     const int off = sums[blockIdx.x];
 #pragma unroll
@@ -90,13 +99,20 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_add_kernel(int* __restrict__ ou
 // (nb + 1 = exclusive_scan_sums_count(n)).
 size_t exclusive_scan_sums_count(int64_t n) { return size_t(cdiv(n > 0 ? n : 1, SCAN_BLOCK)) + 1; }
 
-int exclusive_scan_i32(const int* in, int* out, int* sums, int64_t n, hipStream_t st) {
+// n = (upper bound of) the element count; n_dev (nullable) the actual count in device memory; total_out (nullable) also
+// receives the total
+int exclusive_scan_i32_dev(const int* in, int* out, int* sums, int64_t n, hipStream_t st, const int32_t* n_dev,
+                           int32_t* total_out) {
     const int nb = int(cdiv(n, SCAN_BLOCK));
-    hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(SCAN_TPB), 0, st, in, out, sums, n);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nb);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(SCAN_TPB), 0, st, out, sums, n);
+    hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(SCAN_TPB), 0, st, in, out, sums, n, n_dev);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nb, total_out);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(SCAN_TPB), 0, st, out, sums, n, n_dev);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
+}
+
+int exclusive_scan_i32(const int* in, int* out, int* sums, int64_t n, hipStream_t st) {
+    return exclusive_scan_i32_dev(in, out, sums, n, st, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------- unique ----
@@ -112,7 +128,9 @@ __device__ inline int4 quantise(int4 c, int stride) {
 // int4 = (b, x, y, z) in (.x, .y, .z, .w)
 __global__ void hash_insert_kernel(const int4* __restrict__ coords, int64_t n, int stride,
                                    uint64_t* __restrict__ keys, int32_t* __restrict__ vals, uint32_t mask,
-                                   int32_t* __restrict__ slot_of, int* __restrict__ err) {
+                                   int32_t* __restrict__ slot_of, int* __restrict__ err,
+                                   const int32_t* __restrict__ n_dev) {
+    if (n_dev) n = *n_dev;
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int4 c = quantise(coords[i], stride);
@@ -135,7 +153,8 @@ __global__ void hash_insert_kernel(const int4* __restrict__ coords, int64_t n, i
 }
 
 __global__ void unique_flag_kernel(const int32_t* __restrict__ vals, const int32_t* __restrict__ slot_of,
-                                   int* __restrict__ flag, int64_t n) {
+                                   int* __restrict__ flag, int64_t n, const int32_t* __restrict__ n_dev) {
+    if (n_dev) n = *n_dev;
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int s = slot_of[i];
@@ -146,7 +165,8 @@ __global__ void unique_emit_kernel(const int4* __restrict__ coords, int64_t n, i
                                    const int32_t* __restrict__ vals, const int32_t* __restrict__ slot_of,
                                    const int* __restrict__ flag, const int* __restrict__ rank,
                                    int4* __restrict__ out_coords, int32_t* __restrict__ inverse,
-                                   int32_t* __restrict__ first) {
+                                   int32_t* __restrict__ first, const int32_t* __restrict__ n_dev) {
+    if (n_dev) n = *n_dev;
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int s = slot_of[i];
@@ -162,7 +182,9 @@ __global__ void unique_emit_kernel(const int4* __restrict__ coords, int64_t n, i
 
 // After the emit pass: table value = unique row number.
 __global__ void table_renumber_kernel(int32_t* __restrict__ vals, const int32_t* __restrict__ slot_of,
-                                      const int* __restrict__ flag, const int* __restrict__ rank, int64_t n) {
+                                      const int* __restrict__ flag, const int* __restrict__ rank, int64_t n,
+                                      const int32_t* __restrict__ n_dev) {
+    if (n_dev) n = *n_dev;
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (flag[i]) vals[slot_of[i]] = rank[i];
@@ -288,6 +310,32 @@ UniqueWs carve_unique(void* ws, int64_t n) {
 
 extern "C" size_t osn_coords_unique_ws_bytes(int64_t n) { return carve_unique(nullptr, n).bytes; }
 
+namespace {
+// The unique pipeline of one level, queued on `st` without any host synchronisation.  n = (upper bound of) the row count,
+// n_dev (nullable) = the actual count in device memory, count_out (nullable) receives the number of unique rows, err = a
+// device flag (set to 1 on a coordinate outside the packable range; zeroed by the caller).
+int queue_unique(const int32_t* coords4, int64_t n, const int32_t* n_dev, int stride, uint64_t* table_keys,
+                 int32_t* table_vals, int64_t cap, int32_t* out_coords4, int32_t* inverse, int32_t* first,
+                 const UniqueWs& w, int* err, int32_t* count_out, hipStream_t st) {
+    OSN_HIP(hipMemsetAsync(table_keys, 0xFF, size_t(cap) * 8, st));
+    OSN_HIP(hipMemsetAsync(table_vals, 0x7F, size_t(cap) * 4, st));
+    const int T = 256;
+    const dim3 grid(cdiv(n, T));
+    const int4* c4 = reinterpret_cast<const int4*>(coords4);
+    hipLaunchKernelGGL(hash_insert_kernel, grid, dim3(T), 0, st, c4, n, stride, table_keys, table_vals,
+                       uint32_t(cap - 1), w.slot_of, err, n_dev);
+    hipLaunchKernelGGL(unique_flag_kernel, grid, dim3(T), 0, st, table_vals, w.slot_of, w.flag, n, n_dev);
+    OSN_LAUNCH_CHECK();
+    int rc = exclusive_scan_i32_dev(w.flag, w.rank, w.sums, n, st, n_dev, count_out);
+    if (rc) return rc;
+    hipLaunchKernelGGL(unique_emit_kernel, grid, dim3(T), 0, st, c4, n, stride, table_vals, w.slot_of, w.flag, w.rank,
+                       reinterpret_cast<int4*>(out_coords4), inverse, first, n_dev);
+    hipLaunchKernelGGL(table_renumber_kernel, grid, dim3(T), 0, st, table_vals, w.slot_of, w.flag, w.rank, n, n_dev);
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}
+}  // namespace
+
 extern "C" int osn_coords_unique(const int32_t* coords4, int64_t n, int stride, uint64_t* table_keys,
                                  int32_t* table_vals, int64_t cap, int32_t* out_coords4, int32_t* inverse,
                                  int32_t* first, int64_t* n_unique_host, void* ws, size_t ws_bytes,
@@ -299,28 +347,20 @@ extern "C" int osn_coords_unique(const int32_t* coords4, int64_t n, int stride, 
     OSN_REQUIRE(cap >= 2 * n && cap >= 2 && (cap & (cap - 1)) == 0, OSN_E_ARG,
                 "osn_coords_unique: cap=%lld must be a power of two >= 2n", (long long)cap);
     OSN_REQUIRE(table_keys && table_vals, OSN_E_ARG, "osn_coords_unique: null table");
-    OSN_HIP(hipMemsetAsync(table_keys, 0xFF, size_t(cap) * 8, st));
-    OSN_HIP(hipMemsetAsync(table_vals, 0x7F, size_t(cap) * 4, st));
     *n_unique_host = 0;
-    if (n == 0) return OSN_OK;
+    if (n == 0) {
+        OSN_HIP(hipMemsetAsync(table_keys, 0xFF, size_t(cap) * 8, st));
+        OSN_HIP(hipMemsetAsync(table_vals, 0x7F, size_t(cap) * 4, st));
+        return OSN_OK;
+    }
     OSN_REQUIRE(coords4 && out_coords4 && inverse && first, OSN_E_ARG, "osn_coords_unique: null pointer");
     OSN_REQUIRE(aligned16(coords4) && aligned16(out_coords4), OSN_E_ARG, "osn_coords_unique: coords must be 16-byte aligned");
     UniqueWs w = carve_unique(ws, n);
     OSN_REQUIRE(ws && ws_bytes >= w.bytes, OSN_E_WS, "osn_coords_unique: workspace %zu < %zu", ws_bytes, w.bytes);
     OSN_HIP(hipMemsetAsync(w.err, 0, 4, st));
-    const int T = 256;
-    const dim3 grid(cdiv(n, T));
-    const int4* c4 = reinterpret_cast<const int4*>(coords4);
-    hipLaunchKernelGGL(hash_insert_kernel, grid, dim3(T), 0, st, c4, n, stride, table_keys, table_vals,
-                       uint32_t(cap - 1), w.slot_of, w.err);
-    hipLaunchKernelGGL(unique_flag_kernel, grid, dim3(T), 0, st, table_vals, w.slot_of, w.flag, n);
-    OSN_LAUNCH_CHECK();
-    int rc = exclusive_scan_i32(w.flag, w.rank, w.sums, n, st);
+    int rc = queue_unique(coords4, n, nullptr, stride, table_keys, table_vals, cap, out_coords4, inverse, first, w, w.err,
+                          nullptr, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(unique_emit_kernel, grid, dim3(T), 0, st, c4, n, stride, table_vals, w.slot_of, w.flag, w.rank,
-                       reinterpret_cast<int4*>(out_coords4), inverse, first);
-    hipLaunchKernelGGL(table_renumber_kernel, grid, dim3(T), 0, st, table_vals, w.slot_of, w.flag, w.rank, n);
-    OSN_LAUNCH_CHECK();
     int host[2] = {0, 0};
     const int nb = int(cdiv(n, SCAN_BLOCK));
     OSN_HIP(hipMemcpyAsync(&host[0], w.sums + nb, 4, hipMemcpyDeviceToHost, st));
@@ -330,6 +370,28 @@ extern "C" int osn_coords_unique(const int32_t* coords4, int64_t n, int stride, 
                 "osn_coords_unique: coordinate outside the packable range (|x|,|y|,|z| < 32767, 0 <= batch < 65535)");
     *n_unique_host = host[0];
     return OSN_OK;
+}
+
+// The same pipeline WITHOUT the host synchronisation, for chaining the levels of a coordinate pyramid: n_max bounds the
+// row count (grid and buffer sizes), n_dev (nullable) holds the actual count in device memory (e.g. the previous
+// level's count_dev), count_dev receives this level's unique count, err_dev is a sticky device flag the caller zeroed.
+// Everything is sized for n_max rows; the caller reads the counts (and err) back once for the whole pyramid.
+extern "C" int osn_coords_unique_async(const int32_t* coords4, int64_t n_max, const int32_t* n_dev, int stride,
+                                       uint64_t* table_keys, int32_t* table_vals, int64_t cap, int32_t* out_coords4,
+                                       int32_t* inverse, int32_t* first, int32_t* count_dev, int32_t* err_dev, void* ws,
+                                       size_t ws_bytes, osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n_max >= 1 && n_max < (int64_t(1) << 31), OSN_E_ARG, "osn_coords_unique_async: n_max=%lld out of range", (long long)n_max);
+    OSN_REQUIRE(stride >= 1, OSN_E_ARG, "osn_coords_unique_async: stride must be >= 1");
+    OSN_REQUIRE(cap >= 2 * n_max && (cap & (cap - 1)) == 0, OSN_E_ARG,
+                "osn_coords_unique_async: cap=%lld must be a power of two >= 2 n_max", (long long)cap);
+    OSN_REQUIRE(table_keys && table_vals && coords4 && out_coords4 && inverse && first && count_dev && err_dev, OSN_E_ARG,
+                "osn_coords_unique_async: null pointer");
+    OSN_REQUIRE(aligned16(coords4) && aligned16(out_coords4), OSN_E_ARG, "osn_coords_unique_async: coords must be 16-byte aligned");
+    UniqueWs w = carve_unique(ws, n_max);
+    OSN_REQUIRE(ws && ws_bytes >= w.bytes, OSN_E_WS, "osn_coords_unique_async: workspace %zu < %zu", ws_bytes, w.bytes);
+    return queue_unique(coords4, n_max, n_dev, stride, table_keys, table_vals, cap, out_coords4, inverse, first, w, err_dev,
+                        count_dev, st);
 }
 
 extern "C" int osn_kmap_build(const uint64_t* in_table_keys, const int32_t* in_table_vals, int64_t cap,

@@ -191,6 +191,51 @@ def coords_unique(coords4, stride=1):
     return out[:u], inverse[:n], first[:u], table
 
 
+def coords_pyramid(coords4, strides=(1, 2, 4, 8, 16)):
+    """coords_unique for a chain of strides (level i is the unique set of level i-1 quantised to strides[i]) with ONE
+    host synchronisation for the whole chain instead of one per level: every level is queued with its row count still
+    in device memory (osn_coords_unique_async) and sized for the input's row count; the counts come back together.
+    -> [(coords [U_i, 4], inverse [U_{i-1}] (parent map), first [U_i], HashTable)] -- the tuples coords_unique returns."""
+    if coords4.dtype != torch.int32 or coords4.dim() != 2 or coords4.shape[1] != 4:
+        raise TypeError("coordinates must be int32 [N, 4] rows (batch, x, y, z)")
+    n0 = coords4.shape[0]
+    if n0 == 0 or len(strides) == 1:
+        res, cur = [], coords4
+        for s in strides:
+            r = coords_unique(cur, s)
+            res.append(r)
+            cur = r[0]
+        return res
+    dev = coords4.device
+    lib = _prep(dev)
+    coords4 = coords4.contiguous()
+    L = len(strides)
+    counts = torch.zeros(L + 1, dtype=torch.int32, device=dev)        # [0 .. L-1] unique rows per level, [L] range error
+    ws = _ws(_cached("osn_coords_unique_ws_bytes", n0), dev)
+    st = _stream(dev)
+    bufs, prev, n_dev = [], coords4, None
+    with _Dev(dev):
+        for li, s in enumerate(strides):
+            table = HashTable(n0, dev)
+            out = torch.empty((n0, 4), dtype=torch.int32, device=dev)
+            inverse = torch.empty(n0, dtype=torch.int32, device=dev)
+            first = torch.empty(n0, dtype=torch.int32, device=dev)
+            check(lib.osn_coords_unique_async(_p(prev), n0, n_dev, int(s), _p(table.keys), _p(table.vals), table.cap, _p(out),
+                                              _p(inverse), _p(first), counts.data_ptr() + 4 * li, counts.data_ptr() + 4 * L,
+                                              _p(ws), ws.numel(), st), "osn_coords_unique_async")
+            bufs.append((out, inverse, first, table))
+            prev, n_dev = out, counts.data_ptr() + 4 * li
+    host = counts.tolist()                                             # the one synchronisation
+    if host[L]:
+        raise _lib.OpenSceneAmdError("osn_coords_unique_async: coordinate outside the packable range "
+                                     "(|x|,|y|,|z| < 32767, 0 <= batch < 65535)")
+    res, u_prev = [], n0
+    for (out, inverse, first, table), u in zip(bufs, host[:L]):
+        res.append((out[:u], inverse[:u_prev], first[:u], table))
+        u_prev = u
+    return res
+
+
 def kmap_build(table, out_coords4, ksize, offset_scale, with_counts=False, self_map=False):
     """nbr int32 [K, n_out] (and, with_counts, int64 [K] pairs per offset from the same pass).  self_map: out_coords4 are
     the rows the table was built from, in row order, and ksize is odd (stride-1 convolution): the half-probe builder."""

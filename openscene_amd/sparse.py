@@ -20,8 +20,12 @@ class CoordinateManager:
     """Caches, per tensor stride, the coordinate rows + hash table, and per
     (in stride, out stride, kernel size, dilation) the k-major neighbour tables."""
 
-    def __init__(self, coordinates):
-        coords, inverse, first, table = ops.coords_unique(coordinates, 1)
+    PYRAMID = (2, 4, 8, 16)       # coarse levels built together with the stride-1 map (one host sync for all of them)
+
+    def __init__(self, coordinates, pyramid=None):
+        pyramid = self.PYRAMID if pyramid is None else tuple(pyramid)
+        levels = ops.coords_pyramid(coordinates, (1,) + pyramid)
+        coords, inverse, first, table = levels[0]
         self.n_input = coordinates.shape[0]
         self.unique_index = None          # rows kept if the caller passed duplicates
         self.inverse_mapping = None
@@ -33,6 +37,8 @@ class CoordinateManager:
         self._coords = {1: coords}
         self._tables = {1: table}
         self._parent = {}
+        for s, (c, parent, _first, t) in zip(pyramid, levels[1:]):
+            self._coords[s], self._tables[s], self._parent[s] = c, t, parent
         self._kmaps = {}
         self.device = coordinates.device
 

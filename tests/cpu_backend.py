@@ -37,6 +37,15 @@ def coords_unique(coords4, stride=1):
             torch.from_numpy(first.astype(np.int32)), HashTable(uniq))
 
 
+def coords_pyramid(coords4, strides=(1, 2, 4, 8, 16)):
+    res, cur = [], coords4
+    for s in strides:
+        r = coords_unique(cur, s)
+        res.append(r)
+        cur = r[0]
+    return res
+
+
 def kmap_build(table, out_coords4, ksize, offset_scale, with_counts=False, self_map=False):
     # kernel_offsets(ksize, tensor_stride) scales by the tensor stride; dilation folded into offset_scale
     off = oc.kernel_offsets(ksize, offset_scale)
@@ -368,7 +377,7 @@ def weight_image(weight, flip=False, for_dgrad=False, layout=0):
     return weight_prep_x6(weight, flip=flip, for_dgrad=for_dgrad)
 
 
-_NAMES = ["fusion_project", "fusion_accumulate", "fusion_finish", "weight_image", "stem_eligible", "stem_conv_fwd", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
+_NAMES = ["fusion_project", "fusion_accumulate", "fusion_finish", "weight_image", "stem_eligible", "stem_conv_fwd", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "coords_pyramid", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
           "spconv_wgrad", "bn_stats", "bn_forward_train", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
           "fnv_hash", "ravel_hash", "feature_remap", "batch_coords"]
 

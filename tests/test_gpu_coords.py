@@ -171,3 +171,29 @@ def test_half_probe_self_map_equals_the_full_probe(ksize):
         b, cb = ops.kmap_build(table, uniq, ksize, scale, with_counts=True, self_map=True)
         assert torch.equal(a, b) and torch.equal(ca, cb)
         assert torch.equal(ops.kmap_build(table, uniq, ksize, scale, self_map=True), a)      # without counts
+
+
+def test_one_sync_pyramid_equals_the_level_by_level_build():
+    """ops.coords_pyramid (all levels queued with device-side counts, one read-back) against coords_unique level by
+    level: coordinates, parent maps, first rows bit-identical; the (larger) hash tables answer every probe the same way;
+    duplicates and negative coordinates included; an unpackable coordinate is reported after the one read-back."""
+    from openscene_amd import ops
+    from openscene_amd._lib import OpenSceneAmdError
+    c = random_cloud(9, 12000, 60, batch=3, lo=-25)
+    c = np.concatenate([c, c[:500]])                       # duplicates at stride 1 too
+    x = torch.from_numpy(c).to(dev())
+    strides = (1, 2, 4, 8, 16)
+    pyr = ops.coords_pyramid(x, strides)
+    cur = x
+    for s, (pc, pi, pf, pt) in zip(strides, pyr):
+        rc, ri, rf, rt = ops.coords_unique(cur, s)
+        assert torch.equal(pc, rc) and torch.equal(pi, ri) and torch.equal(pf, rf), "stride %d" % s
+        scale = s
+        assert torch.equal(ops.kmap_build(pt, pc, 3, scale), ops.kmap_build(rt, rc, 3, scale))
+        cur = rc
+    bad = c.copy()
+    bad[7, 1] = 40000
+    with pytest.raises(OpenSceneAmdError):
+        ops.coords_pyramid(torch.from_numpy(bad).to(dev()), strides)
+    one = ops.coords_pyramid(x[:1], strides)                # a single voxel: every level has one row
+    assert [t[0].shape[0] for t in one] == [1] * 5

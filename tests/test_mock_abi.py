@@ -53,7 +53,7 @@ def mock_ops(monkeypatch):
         def __exit__(self, *a):
             pass
     monkeypatch.setattr(ops, "_Dev", NoDev)
-    for n in ("HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count"):
+    for n in ("HashTable", "coords_unique", "coords_pyramid", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count"):
         monkeypatch.setattr(ops, n, getattr(cpu_backend, n))
     return calls
 

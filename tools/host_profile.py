@@ -92,7 +92,7 @@ def main():
             b = _pool["b"] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8)
         return b
     ops._ws = ws
-    for n in ("HashTable", "coords_unique", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count"):
+    for n in ("HashTable", "coords_unique", "coords_pyramid", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count"):
         setattr(ops, n, getattr(cpu_backend, n))          # real sizes for the maps (CPU, outside the timing)
 
     from openscene_amd.disnet import DisNet
