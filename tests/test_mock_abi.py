@@ -59,7 +59,9 @@ def mock_ops(monkeypatch):
 
 
 def test_training_step_runs_through_the_real_wrappers(mock_ops):
+    from openscene_amd import ops
     from openscene_amd import synthetic as syn
+    ops.clear_weight_cache()
     from openscene_amd.disnet import DisNet
     from openscene_amd.sparse import SparseTensor
 
@@ -92,8 +94,27 @@ def test_training_step_runs_through_the_real_wrappers(mock_ops):
     assert c.get("osn_spconv_wgrad", 0) + c.get("osn_spconv_wgrad_tl", 0) == n_conv, c
     assert c.get("osn_pair_lists_build", 0) <= 10, c            # pair arrays: once per map, not per conv
     assert c["osn_bn_forward_train"] == n_bn and c["osn_bn_backward"] == n_bn, c        # one C call per BN and direction
-    assert c.get("osn_weight_prep_x6_pair", 0) + c.get("osn_weight_prep_x6", 0) + c.get("osn_weight_prep_tl", 0) <= n_conv + 8, c
+    # weight images of parameters: served from the per-device cache, refreshed by ONE batched launch per optimizer step
+    # (this is the second step: every image exists, every parameter version has changed once)
+    assert c.get("osn_weight_prep_x6_pair", 0) + c.get("osn_weight_prep_x6", 0) + c.get("osn_weight_prep_tl", 0) == 0, c
+    assert c.get("osn_weight_prep_batch", 0) == 1, c
     assert all(p.grad is not None for p in model.parameters())
+    # a third forward after the optimizer step: one refresh; an eval forward with unchanged weights: none at all
+    mock_ops.clear()
+    model(SparseTensor(feats, coords))
+    assert mock_ops.get("osn_weight_prep_batch", 0) == 1, dict(mock_ops)
+    mock_ops.clear()
+    model.eval()
+    with torch.no_grad():
+        model(SparseTensor(feats, coords))
+    assert mock_ops.get("osn_weight_prep_batch", 0) == 0 and "osn_bn_forward_train" not in mock_ops, dict(mock_ops)
+    # a write that bumps the version of ONE parameter refreshes (only what is stale, in one launch)
+    with torch.no_grad():
+        model.net3d.final.kernel.mul_(1.0)
+        mock_ops.clear()
+        model(SparseTensor(feats, coords))
+    assert mock_ops.get("osn_weight_prep_batch", 0) == 1, dict(mock_ops)
+    ops.clear_weight_cache()
 
 
 def test_loader_and_query_wrappers_run(mock_ops):
