@@ -504,7 +504,9 @@ def main():
     qres = None
     vox_res = None
     extra = None
-    if rank == 0 and not args.train_only:
+    # the side phases (query, voxeliser, inference, the other workloads) are single-GPU measurements: at N > 1 every rank
+    # goes straight to the teardown, so that no rank leaves the process group a minute before rank 0 does
+    if rank == 0 and not args.train_only and world == 1:
         model.eval()
         with torch.no_grad():
             pred = model(SparseTensor(feats, coords0))
