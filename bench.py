@@ -469,7 +469,11 @@ def main():
     survey_dom = None
     if not args.no_kernel_events:
         # untimed survey step: bracket every conv launch to find the dominant kernel instance;
-        # the timed region then brackets only that instance
+        # the timed region then brackets only that instance.  The survey needs a warm process (first steps grow the
+        # scratch pool, create the weight images and load kernel variants inside the brackets): at least three steps
+        # before it, whatever --warmup says
+        for _ in range(max(0, 3 - args.warmup)):
+            step()
         ops.set_profiler(prof)
         prof.enabled = True
         step()
