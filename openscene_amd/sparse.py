@@ -109,10 +109,10 @@ class CoordinateManager:
         return self._kmaps[key]
 
     def prebuild(self, strides=(2, 4, 8, 16), kernel_sizes=(3,), stem_kernel=5):
-        """Build the whole coordinate pyramid and every kernel map up front.  Each stride level costs one
-        host<->device sync (the unique count); paying them back to back here, before any heavy kernel is
-        queued, lets the host run ahead of the GPU for the rest of the forward/backward pass instead of
-        draining the queue at every first use of a level."""
+        """Build every kernel map (and any level of the pyramid the constructor did not create) up front, before any
+        heavy kernel is queued: the host then runs ahead of the GPU for the rest of the forward/backward pass instead of
+        stopping at every first use of a map.  (The pyramid's levels 1 ... 16 were built by the constructor with one
+        host synchronisation; a level beyond them costs one read-back of its unique count here.)"""
         for s in strides:
             self.coords(s)
         levels = (1,) + tuple(strides)
@@ -230,7 +230,7 @@ class MapPrefetcher:
         ...
         x = SparseTensor(feats, coordinate_manager=pf.take(handle))
 
-    submit() blocks the host only on the side stream (the five size read-backs of the pyramid).
+    submit() blocks the host only on the side stream (the size read-back of the pyramid).
 
     Measured on MI355X / S100k (one scene per step): 18.3 ms per step with the prefetcher vs 17.6 ms
     without -- the side-stream kernels queue behind the main stream's workgroups, the host waits on the
