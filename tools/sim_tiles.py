@@ -12,8 +12,27 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import coords as oc  # noqa: E402  (tools may use the oracle: this is an offline study, not the product)
 from openscene_amd import synthetic as syn  # noqa: E402
+
+
+def neighbour_table(xyz):
+    """nbr[k, o] = row of the voxel at xyz[o] + offset k (x fastest), or -1: plain numpy (sorted keys + searchsorted)."""
+    x = xyz.astype(np.int64) - xyz.min(0) + 1
+    span = x.max(0) + 2
+    key = (x[:, 2] * span[1] + x[:, 1]) * span[0] + x[:, 0]
+    order = np.argsort(key)
+    skey = key[order]
+    nbr = np.full((27, x.shape[0]), -1, dtype=np.int64)
+    k = 0
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                q = ((x[:, 2] + dz) * span[1] + (x[:, 1] + dy)) * span[0] + (x[:, 0] + dx)
+                pos = np.clip(np.searchsorted(skey, q), 0, skey.size - 1)
+                hit = skey[pos] == q
+                nbr[k, hit] = order[pos[hit]]
+                k += 1
+    return nbr
 
 
 def morton(c):
@@ -70,8 +89,7 @@ def stats(nbr, perm, bm=88):
 def main():
     vox = syn.shuffled(syn.grid_voxels(syn.room_points(0), 0.02), 0)
     coords = syn.batch_coords([vox])
-    cm = oc.CoordinateManager(coords)
-    nbr = cm.kmap(1, 1, 3)
+    nbr = neighbour_table(coords[:, 1:4])
     n = nbr.shape[1]
     key = pattern_key(nbr)
     mz = morton(coords[:, 1:4].astype(np.int64))
