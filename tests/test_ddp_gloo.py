@@ -206,3 +206,38 @@ def test_flat_gradient_allreduce_equals_ddp(tmp_path):
         assert torch.equal(f0["grads"][n], f1["grads"][n]), "gradient %s differs between ranks" % n
         scale = d0["grads"][n].abs().max().item() + 1e-12
         assert (f0["grads"][n] - d0["grads"][n]).abs().max().item() <= 1e-12 * scale + 1e-15, n     # == DDP's mean
+
+
+def _worker_flat_edge(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    from openscene_amd.distributed import FlatGradAllReduce
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(rank)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3), torch.nn.Linear(3, 2))
+    unused = torch.nn.Parameter(torch.full((5,), float(rank)))
+    net.register_parameter("unused", unused)
+    ex = FlatGradAllReduce(net)
+    x = torch.randn(8, 4, generator=torch.Generator().manual_seed(50 + rank))
+    net(x).sum().backward()                                 # `unused` gets no gradient; BN buffers move locally
+    ex.reduce_gradients()
+    before = {n: b.clone() for n, b in net.named_buffers()}
+    ex.sync_buffers()
+    torch.save({"g": {n: p.grad.clone() for n, p in net.named_parameters()}, "p": {n: p.detach().clone() for n, p in net.named_parameters()},
+                "buf_before": before, "buf": {n: b.clone() for n, b in net.named_buffers()}}, os.path.join(out_dir, "e%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_exchange_unused_parameter_and_buffer_sync(tmp_path):
+    mp.spawn(_worker_flat_edge, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(tmp_path, "e0.pt"))
+    b = torch.load(os.path.join(tmp_path, "e1.pt"))
+    for n in a["p"]:
+        assert torch.equal(a["p"][n], b["p"][n])            # rank 0's parameters everywhere (also the unused one: all 0.0)
+        assert torch.equal(a["g"][n], b["g"][n])
+    assert torch.equal(a["g"]["unused"], torch.zeros(5))    # no gradient anywhere -> zero, not None
+    assert any(not torch.equal(a["buf_before"][n], b["buf_before"][n]) for n in a["buf"] if "running" in n)   # local statistics ...
+    for n in a["buf"]:
+        assert torch.equal(a["buf"][n], b["buf"][n]) and torch.equal(a["buf"][n], a["buf_before"][n])         # ... until sync_buffers
