@@ -107,5 +107,24 @@ def main():
                   s["distinct_rows_per_tile"], s["reuse_within_tile"], s["window_reuse"]))
 
 
+def levels():
+    """Per level of the S100k pyramid: the product's pattern order and tile height (osn_tile_rows) -> pairs per list etc."""
+    vox = syn.shuffled(syn.grid_voxels(syn.room_points(0), 0.02), 0)
+    c = vox.astype(np.int64)
+    print("level rows  bm  tiles  lists/tile  pairs/list  half-steps16/tile  slot-eff  (pattern order, 3^3 map)")
+    for lvl in range(5):
+        s = 1 << lvl
+        q = np.unique(np.floor_divide(c, s), axis=0)              # stride-s voxels in units of s
+        nbr = neighbour_table(q)
+        n = nbr.shape[1]
+        bm = int(min(88, max(32, -(-(-(-n // 1024)) // 8) * 8)))
+        st = stats(nbr, np.argsort(pattern_key(nbr), kind="stable"), bm)
+        print("%5d %6d %3d %5d  %9.1f  %9.1f  %16.1f  %7.2f" % (lvl, n, bm, st["tiles"], st["lists_per_tile"],
+              st["pairs_per_tile"] / st["lists_per_tile"], st["half_steps16_per_tile"], st["slot_efficiency_16"]))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "levels":
+        levels()
+    else:
+        main()
