@@ -203,7 +203,7 @@ def step_algorithmic_bytes(model, sizes, pair_counts):
     return total_b, total_f
 
 
-def variant_step_ms(device, arch, feature, coords, conv_mode=None, steps=5, warmup=2, train=True):
+def variant_step_ms(device, arch, feature, coords, conv_mode=None, steps=5, warmup=2, train=True, n_sup=20000):
     """ms per step of a fresh model on `coords` (same step definition as the headline: maps + forward + cosine loss +
     backward + fused Adam; forward only if not train).  conv_mode overrides openscene_amd.functional.CONV_MODE."""
     from openscene_amd import functional as F_
@@ -223,7 +223,7 @@ def variant_step_ms(device, arch, feature, coords, conv_mode=None, steps=5, warm
         out_dim = model.net3d.final.out_channels
         n = coords.shape[0]
         feats = torch.ones(n, 3, device=device)
-        n_sup = min(20000, n)
+        n_sup = min(n_sup, n)
         g = torch.Generator().manual_seed(7)
         sel = torch.randperm(n, generator=g)[:n_sup].sort()[0].to(device)
         target = torch.nn.functional.normalize(torch.randn(n_sup, out_dim, generator=g), dim=1).half().float().to(device)
@@ -669,6 +669,21 @@ def main():
                                 "voxels_per_s": replica_coords.shape[0] / (msrep * 1e-3),
                                 "what": "configs[0] shape on the GPU: R-replica room (6 x 4.5 x 2.6 m, 250 k points, 2 cm), "
                                         "maps + eval-mode forward of %s" % args.arch}
+        # J2: the reference's shipped 1-GPU step -- batch_size 8 on one GPU (config/scannet/ours_openseg.yaml:
+        # 13-15, run/distill.py:146): eight S100k-shaped rooms in ONE batch (batch column 0 ... 7, one set of BN
+        # statistics), 20 000 supervised voxels per scene
+        rooms8 = [syn.shuffled(syn.grid_voxels(syn.room_points(sd, n_pts=args.scene_points), 0.02), sd) for sd in range(8)]
+        coords8 = torch.from_numpy(syn.batch_coords(rooms8)).to(device)
+        ms8 = variant_step_ms(device, args.arch, args.feature, coords8, steps=3, warmup=2, n_sup=160000)
+        ms8i = variant_step_ms(device, args.arch, args.feature, coords8, steps=3, warmup=1, train=False)
+        extra["batch8_step"] = {"ms": ms8, "voxels": int(coords8.shape[0]), "scenes": 8,
+                                "voxels_per_s": coords8.shape[0] / (ms8 * 1e-3),
+                                "what": "the reference's 1-GPU configuration: 8 scenes per step (batch_size 8, train_gpu [0]), "
+                                        "%s, %d-d head, maps + forward + cosine loss on 8 x 20 000 voxels + backward + Adam"
+                                        % (args.arch, out_dim)}
+        extra["batch8_inference"] = {"ms": ms8i, "voxels_per_s": coords8.shape[0] / (ms8i * 1e-3),
+                                     "what": "8 scenes per batch: maps + eval-mode forward"}
+        del coords8
         extra["conv_mode"] = F_.CONV_MODE
         # multi-view feature fusion: one 320 x 240 view of a 200 k-point scene, 768-d pixel features
         from openscene_amd.fusion import FeatureFusion, PointCloudToImageMapper, adjust_intrinsic, make_intrinsic

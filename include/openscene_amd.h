@@ -291,6 +291,20 @@ int osn_bn_backward(const float* x, const float* y, const float* gy, const float
                     float* gx, float* gres, float* ggamma, float* gbeta,
                     int64_t n, int c, void* ws, size_t ws_bytes, osn_stream_t stream);
 
+/* ---- row-aligned elementwise pieces --------------------------------------- *
+ * Replaces the stand-alone [ME] MinkowskiReLU (models/mink_unet.py:114, used un-fused by the reference's own module
+ * chain), the BasicBlock residual `out += residual` when it is not fused into a batch norm, and ME.cat of two tensors
+ * on one coordinate map (models/mink_unet.py:147,155,163,171) with its backward split.  `total` = rows x channels.
+ *   osn_relu_fwd   y = max(x, 0)                       osn_relu_bwd   gx = y > 0 ? gy : 0
+ *   osn_add        out = a + b  (out may alias a or b)
+ *   osn_cat2       out[r] = (a[r, 0:ca], b[r, 0:cb])   osn_cat2_bwd   ga[r] = gout[r, 0:ca], gb[r] = gout[r, ca:ca+cb]
+ * cat: ca and cb multiples of 4 (every width of the MinkUNet family is).                                          */
+int osn_relu_fwd(const float* x, float* y, int64_t total, osn_stream_t stream);
+int osn_relu_bwd(const float* y, const float* gy, float* gx, int64_t total, osn_stream_t stream);
+int osn_add(const float* a, const float* b, float* out, int64_t total, osn_stream_t stream);
+int osn_cat2(const float* a, int ca, const float* b, int cb, float* out, int64_t n, osn_stream_t stream);
+int osn_cat2_bwd(const float* gout, float* ga, int ca, float* gb, int cb, int64_t n, osn_stream_t stream);
+
 /* ---- open-vocabulary query ---------------------------------------------- *
  * Replaces run/evaluate.py:290-292 (and run/distill.py:423-425):
  *   pred = feats[inds_reverse].half() @ text.t();  label = argmax(pred, 1)

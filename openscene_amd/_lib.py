@@ -61,6 +61,11 @@ PROTOTYPES = {
     "osn_bn_forward_train": (_i32, [_vp, _i64, _i32, _vp, _vp, _f32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "osn_bn_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32,
                                _vp, _sz, _vp]),
+    "osn_relu_fwd": (_i32, [_vp, _vp, _i64, _vp]),
+    "osn_relu_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "osn_add": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "osn_cat2": (_i32, [_vp, _i32, _vp, _i32, _vp, _i64, _vp]),
+    "osn_cat2_bwd": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _vp]),
     "osn_cosine_query": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "osn_query_ensemble_ws_bytes": (_sz, [_i64]),
     "osn_query_ensemble": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _sz, _vp]),

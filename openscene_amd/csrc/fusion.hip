@@ -72,7 +72,12 @@ __global__ __launch_bounds__(256) void fusion_accumulate_kernel(const float* __r
     if (tid < FA_P) {
         const int64_t p = p0 + tid;
         int px = -1;
-        if (p < n && mapping[3 * p + 2] != 0) px = int(mapping[3 * p + 0]) * W + int(mapping[3 * p + 1]);
+        if (p < n && mapping[3 * p + 2] != 0) {
+            // a mapping computed for another image size must never read outside feat[D][H][W]: such a point is skipped
+            // (the host wrapper refuses mismatched sizes up front; the reference raises IndexError)
+            const int64_t y = mapping[3 * p + 0], x = mapping[3 * p + 1];
+            if (y >= 0 && y < H && x >= 0 && x < W) px = int(y) * W + int(x);
+        }
         pix[tid] = px;
         if (px >= 0 && blockIdx.y == 0) counter[p] += 1.f;
     }

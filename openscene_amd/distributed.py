@@ -40,9 +40,11 @@ class FlatGradAllReduce(object):
             off += p.numel()
         self.buffers = [b for b in module.buffers() if b.is_floating_point()] if broadcast_buffers else []
         self.int_buffers = [b for b in module.buffers() if not b.is_floating_point()] if broadcast_buffers else []
-        # rank 0's parameters and buffers everywhere (DDP does the same when it wraps the module)
-        self._broadcast([p.data for p in self.params])
-        self._broadcast([b.data for b in module.buffers()])
+        # rank 0's parameters (ALL of them, frozen ones included: DDP syncs the whole module state) and buffers
+        # everywhere; a real one-rank job has nothing to receive and skips the collectives
+        if self.collectives:
+            self._broadcast(list(module.parameters()))
+            self._broadcast(list(module.buffers()))
 
     def _broadcast(self, tensors):
         """rank 0's values into `tensors` on every rank: one flat buffer, one collective and one multi-tensor copy per dtype."""
@@ -58,21 +60,31 @@ class FlatGradAllReduce(object):
             for t in ts:
                 views.append(flat[off:off + t.numel()].view_as(t))
                 off += t.numel()
-            torch._foreach_copy_(ts, views)
+            # in place on the parameters / buffers themselves (not on `.data`): the copy bumps their version counters,
+            # which is what keys the convolution weight-image cache of openscene_amd.ops (a forward that ran before this
+            # exchange was built must not leave images of the pre-broadcast weights behind)
+            with torch.no_grad():
+                torch._foreach_copy_(ts, views)
+        from . import ops
+        ops.clear_weight_cache()
 
     def sync_buffers(self):
         """Before a forward: rank 0's buffers (BN running statistics, counters) on every rank, as DDP's
         broadcast_buffers=True does.  One collective per dtype."""
         if self.collectives and (self.buffers or self.int_buffers):
-            self._broadcast([b.data for b in self.buffers])
-            self._broadcast([b.data for b in self.int_buffers])
+            self._broadcast(self.buffers)
+            self._broadcast(self.int_buffers)
 
     def reduce_gradients(self):
-        """After backward: p.grad <- mean over ranks, as views of the flat buffer (no copy back)."""
+        """After backward: p.grad <- mean over ranks, as views of the flat buffer (no copy back).
+        A parameter without a gradient on this rank contributes zeros (DDP with find_unused_parameters) and, like
+        there, ends up with the (possibly all-zero) mean as its gradient: an optimizer with momentum / weight decay
+        then still advances its state for a parameter NO rank used -- a documented deviation from a single-process
+        run, where such a parameter keeps grad None (no parameter of the MinkUNet family is unused)."""
         grads = []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
-                v.zero_()                           # unused parameter: contributes zero, like DDP with find_unused_parameters
+                v.zero_()
                 grads.append(None)
             else:
                 grads.append(p.grad)

@@ -45,6 +45,10 @@ class SparseConvFunction(Function):
         tbl, rows, gm = (tiles_fwd[1], tiles_fwd[0], tiles_fwd[2]) if tiles_fwd is not None else (nbr_fwd, None, None)
         ctx.wp_dgrad = None
         ctx.tl_bwd = None
+        # the cached weight images are shared and refreshed in place: remember which version of the kernel the image kept
+        # for the backward pass belongs to (a weight changed through .data between forward and backward bypasses autograd's
+        # own saved-tensor check)
+        ctx.kver = (kernel._version, kernel.data_ptr())
         mode = "bf16x6" if CONV_MODE == "tl" else CONV_MODE
         ctx.stem = CONV_MODE != "fp32" and nbr_fwd is not None and ops.stem_eligible(K, cin, cout)
         if ctx.stem:
@@ -76,6 +80,9 @@ class SparseConvFunction(Function):
         gout = gout.contiguous()
         gin = gk = None
         K = 1 if kernel.dim() == 2 else kernel.shape[0]
+        if ctx.wp_dgrad is not None and ctx.kver != (kernel._version, kernel.data_ptr()):
+            raise RuntimeError("a convolution kernel changed between its forward and its backward pass (version %d -> %d): "
+                               "the input-gradient weight image kept from the forward is stale" % (ctx.kver[0], kernel._version))
 
         def weight_grad():
             cin, cout = kernel.shape[-2], kernel.shape[-1]
@@ -137,6 +144,68 @@ class BatchNormActFunction(Function):
         gx, gres, ggamma, gbeta = ops.bn_backward(x, y, gy.contiguous(), mean, var, gamma, eps, relu, training,
                                                   want_gres)
         return gx, ggamma, gbeta, None, None, gres, None, None, None, None
+
+
+class ReluFunction(Function):
+    """Stand-alone ME.MinkowskiReLU (models/mink_unet.py:114) of the un-fused module chain."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.relu_fwd(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return ops.relu_bwd(y, gy)
+
+
+class AddFunction(Function):
+    """Row-aligned a + b of two feature matrices on one coordinate map (the un-fused residual `out += residual`)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class Cat2Function(Function):
+    """ME.cat of two tensors (models/mink_unet.py:147,155,163,171): one launch forward, one launch backward."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.widths = (a.shape[1], b.shape[1])
+        return ops.cat2(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        ca, cb = ctx.widths
+        if not ctx.needs_input_grad[0] or not ctx.needs_input_grad[1]:
+            g = g.contiguous()
+            return (g[:, :ca].contiguous() if ctx.needs_input_grad[0] else None,
+                    g[:, ca:].contiguous() if ctx.needs_input_grad[1] else None)
+        return ops.cat2_bwd(g, ca, cb)
+
+
+def relu(x):
+    return ReluFunction.apply(x)
+
+
+def add(a, b):
+    return AddFunction.apply(a, b)
+
+
+def cat(ts):
+    """Column concat of feature matrices on one coordinate map, left to right: one HIP launch per pair (the
+    reference only ever concatenates two tensors; widths must be multiples of 4, as every MinkUNet width is)."""
+    out = ts[0]
+    for t in ts[1:]:
+        out = Cat2Function.apply(out, t)
+    return out
 
 
 def sparse_conv(feats, kernel, maps, n_out, tiles=None, counts=None, lists=None, transposed=False):

@@ -56,8 +56,10 @@ class PointCloudToImageMapper(object):
         coords = _dev_f64(coords, self.device)
         depth = None if depth is None else _dev_f64(depth, self.device)
         k = np.asarray(intrinsic, dtype=np.float64)
-        return ops.fusion_project(coords, world_to_camera, (k[0][0], k[1][1], k[0][2], k[1][2]), depth,
-                                  (self.image_dim[1], self.image_dim[0]), self.cut_bound, self.vis_thres)
+        mapping = ops.fusion_project(coords, world_to_camera, (k[0][0], k[1][1], k[0][2], k[1][2]), depth,
+                                     (self.image_dim[1], self.image_dim[0]), self.cut_bound, self.vis_thres)
+        mapping.image_hw = (int(self.image_dim[1]), int(self.image_dim[0]))     # lets add_view refuse a feature map of another size
+        return mapping
 
 
 class FeatureFusion(object):
@@ -69,8 +71,10 @@ class FeatureFusion(object):
 
     def add_view(self, feat_2d, mapping):
         """feat_2d float [D, H, W] (the extractor's output, permuted as in fusion_util.py:57-66), mapping from
-        compute_mapping.  Returns False (and does nothing) when no point is visible (:90-91)."""
-        ops.fusion_accumulate(feat_2d, mapping, self.sum_features, self.counter)
+        compute_mapping (its image size must be feat_2d's H x W: IndexError otherwise, as the reference's indexing).
+        Always accumulates and returns True: a view without visible points adds nothing (the reference skips it,
+        :90-91, after a host-side `mapping[:, 2].sum() == 0` -- the same result without the read-back)."""
+        ops.fusion_accumulate(feat_2d, mapping, self.sum_features, self.counter, getattr(mapping, "image_hw", None))
         return True
 
     def finish(self):

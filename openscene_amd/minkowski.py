@@ -127,7 +127,7 @@ class MinkowskiReLU(nn.Module):
 
     def forward(self, x):
         # stand-alone ReLU of the unfused module chain (fused paths: BasicBlock, openscene_amd.mink_unet)
-        return x._like(torch.relu(x.F))
+        return x._like(F_.relu(x.F))
 
 
 def _outside_path(name):

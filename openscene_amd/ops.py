@@ -820,6 +820,65 @@ def bn_backward(x, y, gy, mean, var, gamma, eps, relu, training, want_gres):
     return gx, gres, ggamma, gbeta
 
 
+# ------------------------------------------------------- elementwise (a11)
+def relu_fwd(x):
+    dev = x.device
+    lib = _prep(dev)
+    x = _f32c(x, "x")
+    y = torch.empty_like(x)
+    with _Dev(dev):
+        check(lib.osn_relu_fwd(_p(x), _p(y), x.numel(), _stream(dev)), "osn_relu_fwd")
+    return y
+
+
+def relu_bwd(y, gy):
+    dev = y.device
+    lib = _prep(dev)
+    gy = _f32c(gy, "grad_output")
+    gx = torch.empty_like(y)
+    with _Dev(dev):
+        check(lib.osn_relu_bwd(_p(y), _p(gy), _p(gx), y.numel(), _stream(dev)), "osn_relu_bwd")
+    return gx
+
+
+def add(a, b):
+    dev = a.device
+    lib = _prep(dev)
+    a, b = _f32c(a, "a"), _f32c(b, "b")
+    if a.shape != b.shape:
+        raise ValueError("add: shapes %s and %s differ" % (tuple(a.shape), tuple(b.shape)))
+    out = torch.empty_like(a)
+    with _Dev(dev):
+        check(lib.osn_add(_p(a), _p(b), _p(out), a.numel(), _stream(dev)), "osn_add")
+    return out
+
+
+def cat2(a, b):
+    """[n, ca] ++ [n, cb] -> [n, ca + cb] in one launch (channel counts multiples of 4)."""
+    dev = a.device
+    lib = _prep(dev)
+    a, b = _f32c(a, "a"), _f32c(b, "b")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0]:
+        raise ValueError("cat2: need two [n, c] matrices with equal n")
+    n, ca, cb = a.shape[0], a.shape[1], b.shape[1]
+    out = torch.empty((n, ca + cb), dtype=torch.float32, device=dev)
+    with _Dev(dev):
+        check(lib.osn_cat2(_p(a), ca, _p(b), cb, _p(out), n, _stream(dev)), "osn_cat2")
+    return out
+
+
+def cat2_bwd(gout, ca, cb):
+    dev = gout.device
+    lib = _prep(dev)
+    gout = _f32c(gout, "grad_output")
+    n = gout.shape[0]
+    ga = torch.empty((n, ca), dtype=torch.float32, device=dev)
+    gb = torch.empty((n, cb), dtype=torch.float32, device=dev)
+    with _Dev(dev):
+        check(lib.osn_cat2_bwd(_p(gout), _p(ga), ca, _p(gb), cb, n, _stream(dev)), "osn_cat2_bwd")
+    return ga, gb
+
+
 # ----------------------------------------------------------------------- query
 def cosine_query(feats, text_half, gather=None, want_scores=True):
     """(scores fp16 [n, C] or None, argmax int64 [n]) of feats[gather].half() @ text.t()."""
@@ -989,12 +1048,19 @@ def fusion_project(coords3, world_to_camera, intrinsic4, depth, image_hw, cut_bo
     return mapping
 
 
-def fusion_accumulate(feat2d, mapping, sum_features, counter):
-    """One view: counter[p] += 1 and sum_features[p] += feat2d[:, row, col] for the visible points (in place)."""
+def fusion_accumulate(feat2d, mapping, sum_features, counter, image_hw=None):
+    """One view: counter[p] += 1 and sum_features[p] += feat2d[:, row, col] for the visible points (in place).
+    image_hw: the (H, W) the mapping was computed for; a feature map of another size is refused (the reference's
+    indexing raises IndexError there).  Without it the kernel still never reads outside feat2d: pixels beyond its
+    H x W are skipped."""
     dev = feat2d.device
     lib = _prep(dev)
     feat2d = _f32c(feat2d, "feat_2d")
     D, H, W = feat2d.shape
+    if image_hw is not None and (int(image_hw[0]), int(image_hw[1])) != (H, W):
+        raise IndexError("feat_2d is %d x %d but the mapping was computed for a %d x %d image" % (H, W, image_hw[0], image_hw[1]))
+    if mapping.device != dev or sum_features.device != dev or counter.device != dev:
+        raise ValueError("feat_2d, mapping, sum_features and counter must live on one device")
     n = mapping.shape[0]
     if mapping.dtype != torch.int64 or tuple(mapping.shape) != (n, 3):
         raise TypeError("mapping must be an int64 [n, 3] tensor")

@@ -16,6 +16,11 @@ import torch
 from . import ops
 
 
+def _F_mod():
+    from . import functional       # late: functional imports ops, which this module imports too
+    return functional
+
+
 class CoordinateManager:
     """Caches, per tensor stride, the coordinate rows + hash table, and per
     (in stride, out stride, kernel size, dilation) the k-major neighbour tables."""
@@ -344,7 +349,7 @@ class SparseTensor:
     def __add__(self, other):
         if isinstance(other, SparseTensor):
             self._same_map(other)
-            return self._like(self._F + other._F)
+            return self._like(_F_mod().add(self._F, other._F))
         return self._like(self._F + other)
 
     def __iadd__(self, other):
@@ -352,7 +357,7 @@ class SparseTensor:
         # matrix so autograd never sees an in-place edit of a saved tensor
         if isinstance(other, SparseTensor):
             self._same_map(other)
-            self._F = self._F + other._F
+            self._F = _F_mod().add(self._F, other._F)
         else:
             self._F = self._F + other
         return self
@@ -369,4 +374,4 @@ def cat(*tensors):
     first = tensors[0]
     for t in tensors[1:]:
         first._same_map(t)
-    return first._like(torch.cat([t.F for t in tensors], dim=1))
+    return first._like(_F_mod().cat([t.F for t in tensors]))

@@ -359,7 +359,7 @@ def fusion_project(coords3, world_to_camera, intrinsic4, depth, image_hw, cut_bo
     return torch.from_numpy(m)
 
 
-def fusion_accumulate(feat2d, mapping, sum_features, counter):
+def fusion_accumulate(feat2d, mapping, sum_features, counter, image_hw=None):
     from oracle import fusion as of
     of.accumulate(sum_features, counter.view(-1, 1), feat2d, mapping)
 
@@ -377,7 +377,27 @@ def weight_image(weight, flip=False, for_dgrad=False, layout=0):
     return weight_prep_x6(weight, flip=flip, for_dgrad=for_dgrad)
 
 
-_NAMES = ["fusion_project", "fusion_accumulate", "fusion_finish", "weight_image", "stem_eligible", "stem_conv_fwd", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "coords_pyramid", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
+def relu_fwd(x):
+    return torch.relu(x)
+
+
+def relu_bwd(y, gy):
+    return gy * (y > 0).to(gy.dtype)
+
+
+def add(a, b):
+    return a + b
+
+
+def cat2(a, b):
+    return torch.cat([a, b], dim=1)
+
+
+def cat2_bwd(gout, ca, cb):
+    return gout[:, :ca].contiguous(), gout[:, ca:ca + cb].contiguous()
+
+
+_NAMES = ["relu_fwd", "relu_bwd", "add", "cat2", "cat2_bwd", "fusion_project", "fusion_accumulate", "fusion_finish", "weight_image", "stem_eligible", "stem_conv_fwd", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "coords_pyramid", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
           "spconv_wgrad", "bn_stats", "bn_forward_train", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
           "fnv_hash", "ravel_hash", "feature_remap", "batch_coords"]
 

@@ -10,6 +10,8 @@ with the NUMBER of pattern elements that differ from the float64 pattern asserte
 <= 2e-3 absolute (fp16 outputs), labels identical wherever the reference's top-2 margin exceeds
 4e-3; convolution elements within 2e-6 * sum_k |a_k| |b_k| of the float64 value (an fp32 fmaf chain
 over n terms is only bounded by n * 6e-8 of that sum)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -20,6 +22,16 @@ from oracle import sparse_ops as so
 from openscene_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _oracle_threads():
+    """The float64 oracle is BLAS + index_add on the host: with the default thread count (= every core of the box, 256
+    on the MI355X hosts) it runs slower than with a few dozen (bench.py's thread ladder: 16 fastest)."""
+    old = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    yield
+    torch.set_num_threads(old)
 
 
 def dev():
@@ -61,83 +73,161 @@ def _s100k():
 def test_s100k_minkunet18a_768_training_step_vs_oracle():
     """configs[2] / the bench workload itself: S100k, MinkUNet18A, 768-d head, train-mode BN, cosine loss on
     20 000 supervised voxels (run/distill.py:316-328) -- forward, every parameter gradient, running stats."""
+    _training_step_vs_oracle("S100k/18A/768", _s100k(), "MinkUNet18A", 768, 1463, 20000)
+
+
+def _training_step_vs_oracle(tag, coords, arch, out_dim, seed, n_sup, flip_frac=2e-5):
+    """One training step (train-mode BN, cosine loss on n_sup supervised voxels, run/distill.py:316-328) of `arch` on
+    `coords` against the float64 oracle: output, ReLU decisions, EVERY parameter gradient on the run's own activation
+    pattern, running statistics.  Returns (output rel-L2, flipped, total, worst gradient rel-L2)."""
     from openscene_amd.mink_unet import mink_unet
     from openscene_amd.sparse import SparseTensor
-    coords = _s100k()
     n = coords.shape[0]
-    torch.manual_seed(1463)                                           # config/scannet/ours_openseg.yaml:25
-    model = mink_unet(3, 768, 3, "MinkUNet18A").train()
-    feats = torch.ones(n, 3)                                          # input_color: False (feature_loader.py:183-184)
-    g = torch.Generator().manual_seed(100)
-    sel = torch.randperm(n, generator=g)[:20000].sort()[0]
-    target = torch.nn.functional.normalize(torch.randn(20000, 768, generator=g), dim=1).half().float()
+    torch.manual_seed(seed)
+    model = mink_unet(3, out_dim, 3, arch).train()
+    feats = torch.ones(n, 3)
+    g = torch.Generator().manual_seed(100 + seed)
+    sel = torch.randperm(n, generator=g)[:n_sup].sort()[0]
+    target = torch.nn.functional.normalize(torch.randn(n_sup, out_dim, generator=g), dim=1).half().float()
     p = _oracle_params(model)
     cm = oc.CoordinateManager(coords)
     own = []
     with torch.no_grad():
-        free = so.unet_forward({k: v.detach().clone() for k, v in p.items()}, feats.double(), coords, "MinkUNet18A",
-                               train=True, cm=cm, record_masks=own)     # clones: BN updates running stats in place
-
+        free = so.unet_forward({k: v.detach().clone() for k, v in p.items()}, feats.double(), coords, arch,
+                               train=True, cm=cm, record_masks=own)
     model = model.to(dev())
     masks = _observe_relu()
     try:
         out = model(SparseTensor(feats.to(dev()), torch.from_numpy(coords).to(dev())))
     finally:
         _stop_observing()
-    assert out.shape == (n, 768) and out.dtype == torch.float32
+    assert out.shape == (n, out_dim) and out.dtype == torch.float32
     e = rel_l2(out, free)
-    assert e <= 2e-4, "output rel-L2 %.3e" % e
+    assert e <= 2e-4, "%s: output rel-L2 %.3e" % (tag, e)
     assert (out.double().cpu() - free).abs().max().item() <= 1e-3 * free.abs().max().item()
-
-    # how many ReLU decisions of the fp32 run differ from the float64 run (pre-activations within fp32
-    # rounding of zero): stated, asserted, and then taken out of the gradient comparison
     assert len(masks) == len(own)
     flipped = sum(int((a != b).sum()) for a, b in zip(masks, own))
     total = sum(a.numel() for a in masks)
-    print("S100k/18A/768: output rel-L2 %.2e; %d of %d ReLU decisions differ from float64" % (e, flipped, total))
-    assert flipped <= 2e-5 * total, "%d of %d ReLU decisions flipped" % (flipped, total)
-
-    ref = so.unet_forward(p, feats.double(), coords, "MinkUNet18A", train=True, cm=cm, relu_masks=masks)
+    assert flipped <= flip_frac * total, "%s: %d of %d ReLU decisions flipped" % (tag, flipped, total)
+    del own
+    ref = so.unet_forward(p, feats.double(), coords, arch, train=True, cm=cm, relu_masks=masks)
     assert rel_l2(ref, free) <= 1e-5, "prescribing the fp32 activation pattern changed the oracle output"
     cos = torch.nn.CosineSimilarity()
     (1 - cos(ref[sel], target.double())).mean().backward()
     (1 - cos(out.index_select(0, sel.to(dev())), target.to(dev()))).mean().backward()
     worst = ("", 0.0)
     for name, prm in model.named_parameters():
+        assert prm.grad is not None, name
         gerr = rel_l2(prm.grad, p[name].grad)
         if gerr > worst[1]:
             worst = (name, gerr)
-    print("S100k/18A/768: worst parameter-gradient rel-L2 %.2e (%s)" % (worst[1], worst[0]))
-    assert worst[1] <= 2e-4, "gradient of %s rel-L2 %.3e" % worst
+    print("%s: %d voxels, output rel-L2 %.2e; %d of %d ReLU decisions differ from float64; worst parameter-gradient "
+          "rel-L2 %.2e (%s)" % (tag, n, e, flipped, total, worst[1], worst[0]))
+    assert worst[1] <= 2e-4, "%s: gradient of %s rel-L2 %.3e" % ((tag,) + worst)
     for name, buf in model.named_buffers():
         if "running" in name:
             assert rel_l2(buf, p[name]) <= 1e-5, name
+    return e, flipped, total, worst[1]
 
 
-def test_l235k_minkunet34c_forward_vs_oracle():
-    """configs[4]: nuScenes-shaped sweep stack (32 beams x 1090 azimuths x 10 sweeps, 5 cm voxels, SURVEY.md 8(d)
-    L235k; this generator gives 236 418 voxels), MinkUNet34C (config/nuscenes/ours_openseg.yaml:12), 768-d head."""
-    from openscene_amd.mink_unet import mink_unet
-    from openscene_amd.sparse import SparseTensor
+LIDAR_VOXELS = 236418      # this generator at 5 cm; SURVEY.md 8(d) quotes 234 838 for its own (uncommitted) script --
+# the survey gives the beam table, sweep count, walls, range and noise but no code or RNG order for the lidar cloud
+# (appendix A only restates the room generator), and none of the readings tried (azimuth end point / origin, noise per
+# sweep or per stack, beam-major or azimuth-major rays: 236 392 ... 236 777) lands on its figure; the 0.7 % difference
+# is a property of the input specification, not of the path.  This file pins OUR generator exactly.
+LIDAR_LEVELS = None        # filled by the first test that builds the pyramid (printed into the log)
+
+
+def _l235k():
     vox = syn.shuffled(syn.grid_voxels(syn.lidar_points(0), 0.05), 0)
-    assert 225000 < vox.shape[0] < 245000
-    coords = syn.batch_coords([vox])
-    torch.manual_seed(5)
-    model = mink_unet(3, 768, 3, "MinkUNet34C").train()
-    feats = torch.ones(coords.shape[0], 3)
-    p = {k: v.detach().clone().double() for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+    assert vox.shape[0] == LIDAR_VOXELS
+    return syn.batch_coords([vox])
+
+
+def test_l235k_minkunet34c_training_step_vs_oracle():
+    """configs[4]: nuScenes-shaped sweep stack (32 beams x 1090 azimuths x 10 sweeps, 5 cm voxels, SURVEY.md 8(d)
+    L235k), MinkUNet34C (config/nuscenes/ours_openseg.yaml:12), 768-d head: the training step the bench quotes
+    (`phases.l235k_34c_step`) -- forward, flipped-ReLU count, every parameter gradient, running statistics."""
+    _training_step_vs_oracle("L235k/34C/768", _l235k(), "MinkUNet34C", 768, 5, 20000)
+
+
+def _rooms(n_scenes, n_pts):
+    return [syn.shuffled(syn.grid_voxels(syn.room_points(s, n_pts=n_pts), 0.02), s) for s in range(n_scenes)]
+
+
+def test_batch8_training_step_vs_oracle():
+    """The reference's shipped 1-GPU batch (config/scannet/ours_openseg.yaml:13-15: train_gpu [0], batch_size 8;
+    run/distill.py:146): EIGHT scenes per step, batch column 0 ... 7 (dataset/feature_loader.py:178-179), ONE set of
+    BN statistics over all scenes -- against the float64 oracle, forward and every parameter gradient.  Scenes of
+    15 000 points each (~100 k voxels in total) so that the oracle costs what the S100k case costs; the 8 x S100k
+    batch itself is covered by the structural test below and benched as `phases.batch8_step`."""
+    rooms = _rooms(8, 15000)
+    coords = syn.batch_coords(rooms)
+    assert set(np.unique(coords[:, 0]).tolist()) == set(range(8))
+    _training_step_vs_oracle("batch8 x 15k points/18A/768", coords, "MinkUNet18A", 768, 1463, 20000)
+
+
+def test_batch8_s100k_structure_and_scene_independence():
+    """8 S100k-shaped rooms in ONE batch (~800 k voxels, the reference's real step): (1) every level of the pyramid
+    and every kernel map of the batch is the disjoint union of the scenes' own (sizes and pair counts add up, no pair
+    joins two scenes); (2) eval-mode forward (running statistics: nothing couples the scenes) of the batch equals
+    the single-scene forwards row for row; (3) train-mode batch statistics are the statistics POOLED over all scenes
+    (bn0's running buffers after one step vs the per-scene stem outputs); (4) one full training step at this size
+    runs and gives finite gradients for every parameter."""
+    from openscene_amd import ops
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import CoordinateManager, SparseTensor
+    d = dev()
+    rooms = _rooms(8, 120000)
+    assert rooms[0].shape[0] == 100999
+    coords = torch.from_numpy(syn.batch_coords(rooms)).to(d)
+    n = coords.shape[0]
+    assert 780000 < n < 830000
+    starts = np.cumsum([0] + [r.shape[0] for r in rooms])
+    cm = CoordinateManager(coords)
+    singles = [CoordinateManager(torch.from_numpy(syn.batch_coords([r])).to(d)) for r in rooms]
+    for s in (1, 2, 4, 8, 16):
+        assert cm.size(s) == sum(c.size(s) for c in singles), "stride %d" % s
+    for si, so_, k in [(1, 1, 3), (2, 2, 3), (16, 16, 3), (1, 2, 2), (8, 16, 2), (1, 1, 5)]:
+        fwd = cm.kmap(si, so_, k)[0]
+        tot = int(ops.kmap_count(fwd).sum())
+        assert tot == sum(int(ops.kmap_count(c.kmap(si, so_, k)[0]).sum()) for c in singles), (si, so_, k)
+        b_in, b_out = cm.coords(si)[:, 0], cm.coords(so_)[:, 0]
+        for kk in range(0, fwd.shape[0], max(1, fwd.shape[0] // 9)):
+            ok = fwd[kk] >= 0
+            assert torch.equal(b_in[fwd[kk][ok].long()], b_out[ok]), "a pair of map %r joins two scenes" % ((si, so_, k),)
+    del cm, singles
+    torch.manual_seed(1463)
+    model = mink_unet(3, 768, 3, "MinkUNet18A").to(d)
+    feats = torch.ones(n, 3, device=d)
+    model.eval()
     with torch.no_grad():
-        ref = so.unet_forward(p, feats.double(), coords, "MinkUNet34C", train=True)
-    model = model.to(dev())
-    with torch.no_grad():
-        out = model(SparseTensor(feats.to(dev()), torch.from_numpy(coords).to(dev())))
-    e = rel_l2(out, ref)
-    print("L235k/34C/768: %d voxels, output rel-L2 %.2e" % (coords.shape[0], e))
-    assert e <= 2e-4, "output rel-L2 %.3e" % e
-    assert (out.double().cpu() - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()
-    for name, buf in model.named_buffers():
-        if "running" in name:
-            assert rel_l2(buf, p[name]) <= 1e-5, name
+        out = model(SparseTensor(feats, coords))
+        for b in (0, 5):
+            one = model(SparseTensor(feats[:rooms[b].shape[0]], torch.from_numpy(syn.batch_coords([rooms[b]])).to(d)))
+            e = rel_l2(out[starts[b]:starts[b + 1]], one)
+            assert e <= 1e-5, "scene %d inside the batch differs from the scene alone: rel-L2 %.3e" % (b, e)
+        del out, one
+        # pooled statistics of the first batch norm (train mode): sum over scenes of the per-scene stem outputs
+        s1 = torch.zeros(32, dtype=torch.float64, device=d)
+        s2 = torch.zeros(32, dtype=torch.float64, device=d)
+        for b in range(8):
+            y = model.conv0p1s1(SparseTensor(feats[:rooms[b].shape[0]], torch.from_numpy(syn.batch_coords([rooms[b]])).to(d))).F.double()
+            s1 += y.sum(0)
+            s2 += (y * y).sum(0)
+        mean = s1 / n
+        var_unbiased = (s2 / n - mean * mean) * n / (n - 1)
+    model.train()
+    g = torch.Generator().manual_seed(3)
+    sel = torch.randperm(n, generator=g)[:20000].sort()[0].to(d)
+    target = torch.nn.functional.normalize(torch.randn(20000, 768, generator=g), dim=1).to(d)
+    out = model(SparseTensor(feats, coords))
+    assert rel_l2(model.bn0.bn.running_mean, 0.1 * mean) <= 1e-5
+    assert rel_l2(model.bn0.bn.running_var, 0.9 + 0.1 * var_unbiased) <= 1e-5
+    (1 - torch.nn.CosineSimilarity()(out.index_select(0, sel), target)).mean().backward()
+    for name, prm in model.named_parameters():
+        assert prm.grad is not None and bool(torch.isfinite(prm.grad).all()), name
+        assert float(prm.grad.abs().max()) > 0, name
 
 
 def _query_inputs(n_vox, n_pts, d, c, seed):
@@ -185,15 +275,35 @@ def _adversarial(kind, n, cin, g):
     return x
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x6"])
+class _KindRecorder:
+    """ops profiler hook that only notes which C-ABI convolution entry points ran."""
+
+    def __init__(self):
+        self.kinds = []
+
+    def start(self, kind, dev, **meta):
+        self.kinds.append(kind)
+        return None
+
+    def stop(self, tok):
+        pass
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "tl"])
 @pytest.mark.parametrize("kind", ["row_scales", "cancellation", "gradient_sized", "wide_elements"])
 def test_conv_adversarial_operands(kind, mode, monkeypatch):
     """bf16x6 drops product terms <= 2^-24 of |a||b| and rounds each operand's third piece at 2^-25 of the
     operand, so EVERY output element must sit within fp32-chain distance of the float64 value measured against
     sum_k |a_k||b_k| -- whatever the dynamic range of the operands (bf16 pieces keep fp32's exponent range).
-    Forward, input gradient and weight gradient, both arithmetic modes, same bound."""
+    Forward, input gradient and weight gradient, all three arithmetic modes, same bound.  "tl" is the product
+    default: the tile-list kernel (16x16x32 MFMA, LDS read-add-write accumulation) for forward and input gradient
+    and the pair-array weight gradient (transpose-read fragments) -- forced onto this 60 k-point cloud by
+    TL_FWD_MIN_ROWS = 0, with the tile-ordered table and lists the coordinate manager would hand them."""
     from openscene_amd import functional as F_
+    from openscene_amd import ops
     monkeypatch.setattr(F_, "CONV_MODE", mode)
+    if mode == "tl":
+        monkeypatch.setattr(F_, "TL_FWD_MIN_ROWS", 0)
     v = syn.shuffled(syn.grid_voxels(syn.room_points(3, n_pts=60000), 0.02), 3)
     cm = oc.CoordinateManager(syn.batch_coords([v]))
     nbr_np = cm.kmap(1, 1, 3)
@@ -224,8 +334,21 @@ def test_conv_adversarial_operands(kind, mode, monkeypatch):
     nbr = torch.from_numpy(nbr_np).to(d)
     fg = feats.to(d).requires_grad_(True)
     wg = w.to(d).requires_grad_(True)
-    out = F_.sparse_conv(fg, wg, (nbr, nbr, True), n)
-    out.backward(gout.to(d))
+    if mode == "tl":
+        counts = ops.kmap_count(nbr)
+        tiles = ops.kmap_sort(nbr, counts)                            # (order, sorted table, group masks)
+        tl = ops.tile_lists(tiles[1], out_rows=tiles[0])
+        rec = _KindRecorder()
+        ops.set_profiler(rec)
+        try:
+            out = F_.sparse_conv(fg, wg, (nbr, nbr, True), n, tiles=(tiles, tiles), counts=counts, lists=(tl, tl))
+            out.backward(gout.to(d))
+        finally:
+            ops.set_profiler(None)
+        assert rec.kinds.count("spconv_fwd_tl") == 2 and rec.kinds.count("spconv_wgrad_tl") == 1, rec.kinds
+    else:
+        out = F_.sparse_conv(fg, wg, (nbr, nbr, True), n)
+        out.backward(gout.to(d))
 
     def within(got, want, bound, what, c):
         err = (got.detach().double().cpu() - want.detach()).abs()
