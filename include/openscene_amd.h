@@ -291,6 +291,21 @@ int osn_bn_backward(const float* x, const float* y, const float* gy, const float
                     float* gx, float* gres, float* ggamma, float* gbeta,
                     int64_t n, int c, void* ws, size_t ws_bytes, osn_stream_t stream);
 
+/* osn_bn_apply with a SECOND destination: the same rows also stored as a column window of a wider matrix
+ * (y2 = first element of the window, ld2 = that matrix's row stride in floats) -- ME.cat (models/mink_unet.py:147,155,
+ * 163,171) written in place by the producers of its two halves.  y2 null = osn_bn_apply.                           */
+int osn_bn_apply2(const float* x, const float* mean, const float* var, const float* gamma,
+                  const float* beta, float eps, const float* residual, int relu, float* y,
+                  float* y2, int64_t ld2, int64_t n, int c, osn_stream_t stream);
+/* osn_bn_backward whose incoming gradient is the SUM of n_gy (1..3) row-aligned matrices, each with its own row
+ * stride (HOST arrays of device pointers / strides in floats): a block input feeds conv1 and the residual, an encoder
+ * output feeds the next stride-2 convolution and -- through ME.cat -- two convolutions of the decoder
+ * (models/mink_unet.py:116-174); the sum autograd would form with separate add kernels is formed while reading.   */
+int osn_bn_backward_multi(const float* x, const float* y, const float* const* gy_host, const int64_t* gy_ld_host,
+                          int n_gy, const float* mean, const float* var, const float* gamma, float eps, int relu,
+                          int training, float* gx, float* gres, float* ggamma, float* gbeta,
+                          int64_t n, int c, void* ws, size_t ws_bytes, osn_stream_t stream);
+
 /* ---- row-aligned elementwise pieces --------------------------------------- *
  * Replaces the stand-alone [ME] MinkowskiReLU (models/mink_unet.py:114, used un-fused by the reference's own module
  * chain), the BasicBlock residual `out += residual` when it is not fused into a batch norm, and ME.cat of two tensors
@@ -382,6 +397,102 @@ int osn_fusion_accumulate(const float* feat2d, int D, int H, int W, const int64_
                           float* sum_features, float* counter, osn_stream_t stream);
 int osn_fusion_finish(const float* sum_features, const float* counter, int64_t n, int D, float* feat_bank,
                       osn_stream_t stream);
+
+/* ---- network executor: one call per forward / backward pass of a MinkUNet -------------------------------- *
+ * Replaces the Python-level walk of models/mink_unet.py:116-174 (MinkUNetBase.forward: conv0 .. block8, final) and
+ * of its autograd graph.  The module tree is compiled ONCE into a linear program of stages
+ *   x = conv(src)  [-> BN (batch or running statistics) (+ residual) (+ ReLU)]  -> dst  [-> second store into a cat buffer]
+ * and the library issues every launch of a pass from one call: kernel choice per stage, scratch, the training-mode
+ * statistics kept for the backward pass, the gradient routing (sums of up to three sources are formed inside the
+ * batch-norm backward, ME.cat is written in place by its producers).  Same kernels and same results as the per-module
+ * entry points above; what disappears is the host work between launches (~40 us per stage of Python + autograd).
+ * All `const T*` members of the descriptors are HOST arrays unless noted; activations live in caller-provided arenas. */
+#define OSN_NET_MAX_LEVELS 8
+typedef struct osn_net_op {
+    int32_t K, cin, cout;        /* kernel volume (1, 8, 27, 125), channels                                      */
+    int32_t lvl_in, lvl_out;     /* pyramid levels (index into level_rows) of the input / output rows           */
+    int32_t map;                 /* index into osn_net_run.maps, -1 <=> K == 1 (identity map)                     */
+    int32_t transposed;          /* 1: MinkowskiConvolutionTranspose (runs on the mirrored tables of `map`)       */
+    int32_t src;                 /* activation buffer read, -1 = the network input                                */
+    int32_t dst;                 /* activation buffer written, -1 = the network output (no batch norm: `final`)   */
+    int32_t bn;                  /* index into osn_net_run.bns, -1 = none                                         */
+    int32_t relu;                /* ReLU after the batch norm (+ residual)                                        */
+    int32_t res;                 /* residual buffer added before the ReLU, -1 = none                              */
+    int32_t copy_buf, copy_col;  /* second store of dst: columns [copy_col, copy_col + cout) of buffer copy_buf   */
+    int32_t weight;              /* index into osn_net_run.weights                                                */
+    int32_t need_dgrad;          /* 0: the input needs no gradient (stem)                                         */
+} osn_net_op;                    /* 64 bytes */
+typedef struct osn_net_buf { int32_t level, channels; } osn_net_buf;
+typedef struct osn_net_desc {
+    int32_t n_ops, n_bufs, n_bns, n_weights, n_maps, n_levels;
+    int32_t tl_min_rows;         /* tile-list forward / input gradient on tables of at least this many rows       */
+    int32_t bn_small_rows;       /* single-launch batch norm up to this many rows (0 = never)                     */
+    const osn_net_op* ops;
+    const osn_net_buf* bufs;
+} osn_net_desc;
+enum { OSN_NET_K_NONE = 0, OSN_NET_K_STEM = 1, OSN_NET_K_TL = 2, OSN_NET_K_X6 = 3, OSN_NET_K_WGRAD_TL = 4, OSN_NET_K_WGRAD = 5 };
+enum { OSN_NET_IMG_X6_FWD = 1, OSN_NET_IMG_X6_DGRAD = 2, OSN_NET_IMG_TL_FWD = 4, OSN_NET_IMG_TL_DGRAD = 8 };
+typedef struct osn_net_plan {                 /* every array is caller-provided HOST memory                       */
+    uint64_t fwd_arena_bytes, bwd_arena_bytes, ws_bytes;
+    uint64_t* x_off;             /* [n_ops]  conv output (pre batch norm) in the forward arena                    */
+    uint64_t* stat_off;          /* [n_ops]  mean | var (2 x cout floats) of the training-mode statistics          */
+    uint64_t* y_off;             /* [n_bufs] activation buffers in the forward arena                              */
+    int32_t* fwd_kernel;         /* [n_ops]  OSN_NET_K_*                                                          */
+    int32_t* dgrad_kernel;       /* [n_ops]                                                                       */
+    int32_t* wgrad_kernel;       /* [n_ops]                                                                       */
+    int32_t* images;             /* [n_ops]  OSN_NET_IMG_* bit mask of the weight images the pass reads            */
+} osn_net_plan;
+typedef struct osn_net_map {                  /* one kernel map of the coordinate manager (device pointers)       */
+    const int32_t* nbr_fwd;      /* [K, rows_out]                                                                 */
+    const int32_t* nbr_bwd;      /* [K, rows_in] table of the input gradient (= nbr_fwd for odd stride-1 kernels)  */
+    const int32_t* tiles_fwd_rows; const int32_t* tiles_fwd_tbl; const uint32_t* tiles_fwd_gmask;   /* osn_kmap_sort, or null */
+    const int32_t* tiles_bwd_rows; const int32_t* tiles_bwd_tbl; const uint32_t* tiles_bwd_gmask;
+    const int64_t* counts;       /* [K] pairs per offset                                                          */
+    const void* tl_fwd; const int32_t* tl_fwd_rows;     /* osn_tile_lists_build of the forward table (+ permutation) */
+    const void* tl_bwd; const int32_t* tl_bwd_rows;
+    const void* pl_fwd;          /* osn_pair_lists_build of tl_fwd (weight gradient), null in inference            */
+    int32_t K, flip, tl_fwd_bm, tl_bwd_bm;
+} osn_net_map;
+typedef struct osn_net_weight {
+    const float* W;              /* [K, cin, cout]                                                                */
+    const void* x6_fwd; const void* x6_dgrad; const void* tl_fwd; const void* tl_dgrad;    /* images (OSN_NET_IMG_*) */
+    float* gW;                   /* backward: receives the weight gradient                                        */
+} osn_net_weight;
+typedef struct osn_net_bn {
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var;
+    float* ggamma; float* gbeta; /* backward                                                                      */
+    float eps, momentum;
+} osn_net_bn;
+typedef struct osn_prof osn_prof_t;           /* optional launch timer, see osn_prof_create                       */
+typedef struct osn_net_run {
+    const int64_t* level_rows;   /* [n_levels] rows of every pyramid level                                        */
+    const osn_net_map* maps;
+    const osn_net_weight* weights;
+    const osn_net_bn* bns;
+    const float* input;          /* [rows(level of op 0), cin of op 0]                                            */
+    float* output;               /* forward: [rows, cout] of the op with dst == -1 (may be null if not run)       */
+    const float* goutput;        /* backward: gradient of `output`                                                */
+    void* fwd_arena; uint64_t fwd_arena_bytes;
+    void* bwd_arena; uint64_t bwd_arena_bytes;
+    void* ws; uint64_t ws_bytes;
+    int32_t* tl_counters;        /* 128 persistent tile counters of this stream (osn_spconv_fwd_tl_pc)            */
+    int32_t training;            /* batch statistics + running update (1) or running statistics (0)               */
+    int32_t first_op, end_op;    /* ops [first_op, end_op) are executed                                           */
+    int32_t reserved;
+    osn_prof_t* prof;            /* nullable                                                                      */
+} osn_net_run;
+int osn_net_plan_query(const osn_net_desc* net, const int64_t* level_rows, int training, osn_net_plan* plan);
+int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, osn_stream_t stream);
+int osn_net_backward(const osn_net_desc* net, const osn_net_run* run, osn_stream_t stream);
+
+/* Launch timer for the executor (bench.py's roofline entry): HIP events recorded on the launch stream around the
+ * convolution launches of selected stages.  tag = op * 4 + phase (0 forward, 1 input gradient, 2 weight gradient).
+ * filter_op < 0 brackets every stage.  osn_prof_read synchronises the events and returns the number of records.   */
+osn_prof_t* osn_prof_create(int capacity);
+void osn_prof_destroy(osn_prof_t* p);
+int osn_prof_filter(osn_prof_t* p, int filter_op, int filter_phase);
+int osn_prof_read(osn_prof_t* p, int32_t* tags, float* ms, int capacity, int reset);
 
 #ifdef __cplusplus
 }

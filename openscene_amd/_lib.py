@@ -61,6 +61,16 @@ PROTOTYPES = {
     "osn_bn_forward_train": (_i32, [_vp, _i64, _i32, _vp, _vp, _f32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "osn_bn_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32,
                                _vp, _sz, _vp]),
+    "osn_bn_apply2": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "osn_bn_backward_multi": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32,
+                                     _vp, _sz, _vp]),
+    "osn_net_plan_query": (_i32, [_vp, _vp, _i32, _vp]),
+    "osn_net_forward": (_i32, [_vp, _vp, _vp]),
+    "osn_net_backward": (_i32, [_vp, _vp, _vp]),
+    "osn_prof_create": (_vp, [_i32]),
+    "osn_prof_destroy": (None, [_vp]),
+    "osn_prof_filter": (_i32, [_vp, _i32, _i32]),
+    "osn_prof_read": (_i32, [_vp, _vp, _vp, _i32, _i32]),
     "osn_relu_fwd": (_i32, [_vp, _vp, _i64, _vp]),
     "osn_relu_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "osn_add": (_i32, [_vp, _vp, _vp, _i64, _vp]),

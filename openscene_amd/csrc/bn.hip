@@ -13,6 +13,28 @@ constexpr int CR_COLS = 64;    // columns per block (16 lanes x float4)
 constexpr int CR_RL = 16;      // row lanes per block
 constexpr int CR_MAX_BLOCKS = 512;
 
+// The gradient arriving at a batch norm's output may be the SUM of several row-aligned matrices (a block input feeds
+// conv1 and the residual; an encoder output feeds the next stride-2 conv and, through ME.cat, two convs of the decoder --
+// models/mink_unet.py:116-174), each possibly a column window of a wider matrix (ld = row stride in floats).  The
+// backward kernels add them while they read: no separate accumulation pass, no torch add.
+constexpr int BN_MAX_SRC = 3;
+struct GySrc {
+    const float* p[BN_MAX_SRC];
+    int64_t ld[BN_MAX_SRC];
+    int n;
+};
+
+__device__ inline float4 gy_load(const GySrc& s, int64_t r, int col) {
+    float4 g = *reinterpret_cast<const float4*>(s.p[0] + r * s.ld[0] + col);
+#pragma unroll
+    for (int i = 1; i < BN_MAX_SRC; ++i)
+        if (i < s.n) {
+            const float4 v = *reinterpret_cast<const float4*>(s.p[i] + r * s.ld[i] + col);
+            g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+        }
+    return g;
+}
+
 struct ColReducePlan {
     int n_rb;            // row blocks
     int n_cg;            // column groups
@@ -34,7 +56,7 @@ static ColReducePlan plan_colreduce(int64_t n, int c) {
 // MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat), g = relu ? gy*(y>0) : gy
 template <int MODE>
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                         const float* __restrict__ gy, const float* __restrict__ mean,
+                                                         const GySrc gy, const float* __restrict__ mean,
                                                          const float* __restrict__ var, float eps, int relu, int64_t n,
                                                          int c, int rows_per_block, double* __restrict__ partial) {
     __shared__ double red[2][CR_RL][CR_COLS];
@@ -59,7 +81,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
                 s2[0] += double(xv.x) * xv.x; s2[1] += double(xv.y) * xv.y;
                 s2[2] += double(xv.z) * xv.z; s2[3] += double(xv.w) * xv.w;
             } else {
-                float4 g = *reinterpret_cast<const float4*>(gy + r * c + col);
+                float4 g = gy_load(gy, r, col);
                 if (relu) {
                     const float4 yv = *reinterpret_cast<const float4*>(y + r * c + col);
                     g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
@@ -176,7 +198,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ var, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps,
                                                        const float* __restrict__ residual, int relu,
-                                                       float* __restrict__ y, int64_t total4, int c4) {
+                                                       float* __restrict__ y, float* __restrict__ y2, int64_t ld2,
+                                                       int64_t total4, int c4) {
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total4; e += int64_t(gridDim.x) * blockDim.x) {
         const int col = int(e % c4) * 4;
         const float4 xv = ld4(x + e * 4), mu = ld4(mean + col), vv = ld4(var + col), ga = ld4(gamma + col),
@@ -194,11 +217,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         }
         *reinterpret_cast<float4*>(y + e * 4) = o;
+        // second store: the same rows as a column window of a wider matrix (ME.cat written in place by its producers)
+        if (y2) *reinterpret_cast<float4*>(y2 + (e / c4) * ld2 + col) = o;
     }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                           const float* __restrict__ gy, const float* __restrict__ mean,
+                                                           const GySrc gy, const float* __restrict__ mean,
                                                            const float* __restrict__ var, const float* __restrict__ gamma,
                                                            float eps, int relu, int training,
                                                            const float* __restrict__ sum_g,
@@ -207,7 +232,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int64_t total4, int c4) {
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total4; e += int64_t(gridDim.x) * blockDim.x) {
         const int col = int(e % c4) * 4;
-        float4 g = ld4(gy + e * 4);
+        float4 g = gy_load(gy, e / c4, col);
         if (relu) {
             const float4 yv = ld4(y + e * 4);
             g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
@@ -257,7 +282,7 @@ extern "C" int osn_bn_stats(const float* x, int64_t n, int c, float* mean, float
     OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_bn_stats: workspace %zu < %zu", ws_bytes, need);
     double* partial = static_cast<double*>(ws);
     hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(p.n_rb, p.n_cg), dim3(256), 0, st, x, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, 0, n, c,
+                       GySrc{}, (const float*)nullptr, (const float*)nullptr, 0.f, 0, n, c,
                        p.rows_per_block, partial);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(c, FIN_COLS)), dim3(FIN_COLS * FIN_PARTS), 0, st, partial, p.n_rb, n, c, mean, var,
                        running_mean, running_var, momentum);
@@ -265,9 +290,9 @@ extern "C" int osn_bn_stats(const float* x, int64_t n, int c, float* mean, float
     return OSN_OK;
 }
 
-extern "C" int osn_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
-                            float eps, const float* residual, int relu, float* y, int64_t n, int c,
-                            osn_stream_t stream) {
+extern "C" int osn_bn_apply2(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                             float eps, const float* residual, int relu, float* y, float* y2, int64_t ld2, int64_t n, int c,
+                             osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n >= 0 && c >= 4 && (c & 3) == 0, OSN_E_ARG, "osn_bn_apply: need c %% 4 == 0 (c=%d)", c);
     if (n == 0) return OSN_OK;
@@ -275,11 +300,19 @@ extern "C" int osn_bn_apply(const float* x, const float* mean, const float* var,
     OSN_REQUIRE(aligned16(x) && aligned16(y) && aligned16(mean) && aligned16(var) && aligned16(gamma) && aligned16(beta) &&
                     (!residual || aligned16(residual)),
                 OSN_E_ARG, "osn_bn_apply: pointers must be 16-byte aligned");
+    OSN_REQUIRE(!y2 || (aligned16(y2) && ld2 >= c && (ld2 & 3) == 0), OSN_E_ARG,
+                "osn_bn_apply2: the second destination needs a 16-byte aligned pointer and a row stride >= c, %% 4 == 0");
     const int64_t total4 = n * (c / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, mean, var, gamma, beta, eps,
-                       residual, relu, y, total4, c / 4);
+                       residual, relu, y, y2, ld2, total4, c / 4);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
+}
+
+extern "C" int osn_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                            float eps, const float* residual, int relu, float* y, int64_t n, int c,
+                            osn_stream_t stream) {
+    return osn_bn_apply2(x, mean, var, gamma, beta, eps, residual, relu, y, nullptr, 0, n, c, stream);
 }
 
 // Training-mode forward in ONE call: statistics (+ running buffers) and the fused normalise (+ residual) (+ ReLU) pass.
@@ -294,28 +327,48 @@ extern "C" int osn_bn_forward_train(const float* x, int64_t n, int c, const floa
     return osn_bn_apply(x, mean, var, gamma, beta, eps, residual, relu, y, n, c, stream);
 }
 
-extern "C" int osn_bn_backward(const float* x, const float* y, const float* gy, const float* mean, const float* var,
-                               const float* gamma, float eps, int relu, int training, float* gx, float* gres,
-                               float* ggamma, float* gbeta, int64_t n, int c, void* ws, size_t ws_bytes,
-                               osn_stream_t stream) {
+extern "C" int osn_bn_backward_multi(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,
+                                     const float* mean, const float* var, const float* gamma, float eps, int relu,
+                                     int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c,
+                                     void* ws, size_t ws_bytes, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n >= 1 && c >= 4 && (c & 3) == 0, OSN_E_ARG, "osn_bn_backward: need n >= 1 and c %% 4 == 0");
-    OSN_REQUIRE(x && gy && mean && var && gamma && gx && ggamma && gbeta && (!relu || y), OSN_E_ARG,
+    OSN_REQUIRE(gy && gy_ld && n_gy >= 1 && n_gy <= BN_MAX_SRC, OSN_E_ARG,
+                "osn_bn_backward: %d gradient sources (1 .. %d are supported)", n_gy, BN_MAX_SRC);
+    OSN_REQUIRE(x && mean && var && gamma && gx && ggamma && gbeta && (!relu || y), OSN_E_ARG,
                 "osn_bn_backward: null pointer");
-    OSN_REQUIRE(aligned16(x) && aligned16(gy) && aligned16(gx) && aligned16(mean) && aligned16(var) && aligned16(gamma) &&
+    OSN_REQUIRE(aligned16(x) && aligned16(gx) && aligned16(mean) && aligned16(var) && aligned16(gamma) &&
                     aligned16(ggamma) && aligned16(gbeta) && (!y || aligned16(y)) && (!gres || aligned16(gres)),
                 OSN_E_ARG, "osn_bn_backward: pointers must be 16-byte aligned");
+    GySrc src{};
+    src.n = n_gy;
+    for (int i = 0; i < BN_MAX_SRC; ++i) {
+        const int j = i < n_gy ? i : 0;                  // unused slots repeat source 0 (never read)
+        OSN_REQUIRE(gy[j] && aligned16(gy[j]) && gy_ld[j] >= c && (gy_ld[j] & 3) == 0, OSN_E_ARG,
+                    "osn_bn_backward: gradient source %d needs a 16-byte aligned pointer and a row stride >= c, %% 4 == 0", j);
+        src.p[i] = gy[j];
+        src.ld[i] = gy_ld[j];
+    }
     ColReducePlan p = plan_colreduce(n, c);
     const size_t need = size_t(p.n_rb) * 2 * size_t(c) * 8;
     OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_bn_backward: workspace %zu < %zu", ws_bytes, need);
     double* partial = static_cast<double*>(ws);
-    hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(p.n_rb, p.n_cg), dim3(256), 0, st, x, y, gy, mean, var, eps, relu, n,
+    hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(p.n_rb, p.n_cg), dim3(256), 0, st, x, y, src, mean, var, eps, relu, n,
                        c, p.rows_per_block, partial);
     // ggamma = sum g*xhat, gbeta = sum g  (also the two column sums the apply pass needs)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, FIN_COLS)), dim3(FIN_COLS * FIN_PARTS), 0, st, partial, p.n_rb, c, gbeta, ggamma);
     const int64_t total4 = n * (c / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, y, gy, mean, var, gamma, eps,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, y, src, mean, var, gamma, eps,
                        relu, training, gbeta, ggamma, 1.f / float(n), gx, gres, total4, c / 4);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
+}
+
+extern "C" int osn_bn_backward(const float* x, const float* y, const float* gy, const float* mean, const float* var,
+                               const float* gamma, float eps, int relu, int training, float* gx, float* gres,
+                               float* ggamma, float* gbeta, int64_t n, int c, void* ws, size_t ws_bytes,
+                               osn_stream_t stream) {
+    const int64_t ld = c;
+    return osn_bn_backward_multi(x, y, &gy, &ld, 1, mean, var, gamma, eps, relu, training, gx, gres, ggamma, gbeta, n, c, ws,
+                                 ws_bytes, stream);
 }

@@ -1,0 +1,448 @@
+// Network executor: every launch of a MinkUNet forward / backward pass from ONE C call.
+//
+// Replaces the Python-level walk of models/mink_unet.py:116-174 and of its autograd graph: the host
+// side compiles the module tree once into a linear program of stages (include/openscene_amd.h: osn_net_op) and this
+// file plays it -- per stage the same kernel choice the per-module path makes (stem / tile-list / split-bf16
+// output-stationary kernel; pair-array or table weight gradient), training-mode statistics kept for the backward
+// pass, gradient sums formed inside the batch-norm backward (osn_bn_backward_multi), ME.cat written in place by its
+// two producers (osn_bn_apply2).  Host-only code: no kernels here, only calls into the library's own entry points,
+// so results are those of the per-module path (same kernels, same order; only the gradient SUMS are associated
+// differently: (a + b) inside the consumer instead of a separate add).
+#include "common.h"
+#include <vector>
+
+namespace osn {
+
+constexpr uint64_t NO_OFF = ~uint64_t(0);
+
+struct Prof {
+    std::vector<hipEvent_t> ev;        // 2 per record
+    std::vector<int32_t> tag;
+    int cap = 0, n = 0, filter_op = -1, filter_phase = -1;
+};
+
+static inline uint64_t up256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
+
+static bool stem_eligible(int K, int cin, int cout) { return cin <= 4 && cout == 32 && K > 1 && K <= 125; }
+static bool tl_eligible(int K, int cin, int cout, int64_t n_in) {
+    return (cin & 3) == 0 && cin >= 8 && (cout & 3) == 0 && K <= 128 && n_in <= (int64_t(1) << 24);
+}
+static bool x6_eligible(int K, int cin, int cout, int64_t n_out) {
+    if ((cin & 3) || cin < 8) return false;
+    if (int64_t(3) * K * cout * ((cin + 31) / 32 * 32) >= (int64_t(1) << 30)) return false;
+    int32_t plan[6];
+    if (osn_spconv_fwd_plan(n_out, K, cin, cout, plan) != OSN_OK) return false;
+    const int S = plan[4] > 0 ? plan[4] : 1;
+    return (K + S - 1) / S <= 32;
+}
+
+// Everything the passes derive from (program, level sizes): kernel per stage, arena offsets, scratch size.
+struct Layout {
+    std::vector<uint64_t> x_off, stat_off, y_off, gx_off, gres_off, gin_off;
+    std::vector<int32_t> fwd_k, dgrad_k, wgrad_k, images;
+    std::vector<int32_t> producer;       // buffer -> op with dst == buffer
+    uint64_t fwd_bytes = 0, bwd_bytes = 0, ws_bytes = 0;
+};
+
+static int check_desc(const osn_net_desc* net, const int64_t* rows) {
+    OSN_REQUIRE(net && rows && net->ops && net->bufs, OSN_E_ARG, "osn_net: null descriptor");
+    OSN_REQUIRE(net->n_ops >= 1 && net->n_bufs >= 0 && net->n_levels >= 1 && net->n_levels <= OSN_NET_MAX_LEVELS, OSN_E_ARG,
+                "osn_net: %d ops, %d buffers, %d levels", net->n_ops, net->n_bufs, net->n_levels);
+    for (int l = 0; l < net->n_levels; ++l)
+        OSN_REQUIRE(rows[l] >= 1 && rows[l] < (int64_t(1) << 31), OSN_E_ARG, "osn_net: level %d has %lld rows", l, (long long)rows[l]);
+    for (int b = 0; b < net->n_bufs; ++b)
+        OSN_REQUIRE(net->bufs[b].level >= 0 && net->bufs[b].level < net->n_levels && net->bufs[b].channels >= 4 &&
+                        (net->bufs[b].channels & 3) == 0,
+                    OSN_E_ARG, "osn_net: buffer %d (level %d, %d channels)", b, net->bufs[b].level, net->bufs[b].channels);
+    for (int i = 0; i < net->n_ops; ++i) {
+        const osn_net_op& o = net->ops[i];
+        OSN_REQUIRE(o.K >= 1 && o.K <= 125 && o.cin >= 1 && o.cout >= 4 && (o.cout & 3) == 0, OSN_E_ARG, "osn_net: op %d shape (K=%d, %d -> %d)", i, o.K, o.cin, o.cout);
+        OSN_REQUIRE(o.lvl_in >= 0 && o.lvl_in < net->n_levels && o.lvl_out >= 0 && o.lvl_out < net->n_levels, OSN_E_ARG, "osn_net: op %d levels", i);
+        OSN_REQUIRE((o.K == 1) == (o.map < 0) && o.map < net->n_maps, OSN_E_ARG, "osn_net: op %d map index %d for K=%d", i, o.map, o.K);
+        OSN_REQUIRE(o.K > 1 || o.lvl_in == o.lvl_out, OSN_E_ARG, "osn_net: op %d is a 1x1 conv across levels", i);
+        OSN_REQUIRE(o.src >= -1 && o.src < net->n_bufs && o.dst >= -1 && o.dst < net->n_bufs && o.res >= -1 && o.res < net->n_bufs &&
+                        o.copy_buf >= -1 && o.copy_buf < net->n_bufs,
+                    OSN_E_ARG, "osn_net: op %d buffer index", i);
+        OSN_REQUIRE(o.weight >= 0 && o.weight < net->n_weights && o.bn >= -1 && o.bn < net->n_bns, OSN_E_ARG, "osn_net: op %d weight / bn index", i);
+        OSN_REQUIRE((o.dst >= 0) == (o.bn >= 0), OSN_E_ARG, "osn_net: op %d: exactly the stages with a batch norm write an activation buffer", i);
+        if (o.src >= 0)
+            OSN_REQUIRE(net->bufs[o.src].level == o.lvl_in && net->bufs[o.src].channels == o.cin, OSN_E_ARG, "osn_net: op %d reads buffer %d of another shape", i, o.src);
+        if (o.dst >= 0)
+            OSN_REQUIRE(net->bufs[o.dst].level == o.lvl_out && net->bufs[o.dst].channels == o.cout, OSN_E_ARG, "osn_net: op %d writes buffer %d of another shape", i, o.dst);
+        if (o.res >= 0)
+            OSN_REQUIRE(net->bufs[o.res].level == o.lvl_out && net->bufs[o.res].channels == o.cout, OSN_E_ARG, "osn_net: op %d residual buffer %d of another shape", i, o.res);
+        if (o.copy_buf >= 0)
+            OSN_REQUIRE(net->bufs[o.copy_buf].level == o.lvl_out && o.copy_col >= 0 && (o.copy_col & 3) == 0 &&
+                            o.copy_col + o.cout <= net->bufs[o.copy_buf].channels,
+                        OSN_E_ARG, "osn_net: op %d second store outside buffer %d", i, o.copy_buf);
+    }
+    return OSN_OK;
+}
+
+static int make_layout(const osn_net_desc* net, const int64_t* rows, int training, Layout& L) {
+    int rc = check_desc(net, rows);
+    if (rc) return rc;
+    const int n = net->n_ops;
+    L.x_off.assign(n, NO_OFF); L.stat_off.assign(n, NO_OFF); L.gx_off.assign(n, NO_OFF); L.gres_off.assign(n, NO_OFF);
+    L.gin_off.assign(n, NO_OFF);
+    L.y_off.assign(net->n_bufs, NO_OFF);
+    L.fwd_k.assign(n, 0); L.dgrad_k.assign(n, 0); L.wgrad_k.assign(n, 0); L.images.assign(n, 0);
+    L.producer.assign(net->n_bufs, -1);
+    uint64_t f = 0, b = 0, ws = 4096;
+    auto need_ws = [&](uint64_t v) { if (v > ws) ws = v; };
+    for (int i = 0; i < n; ++i) {
+        const osn_net_op& o = net->ops[i];
+        const int64_t n_in = rows[o.lvl_in], n_out = rows[o.lvl_out];
+        if (o.dst >= 0) {
+            OSN_REQUIRE(L.producer[o.dst] < 0, OSN_E_ARG, "osn_net: buffer %d has two producers", o.dst);
+            L.producer[o.dst] = i;
+            L.x_off[i] = f; f += up256(uint64_t(n_out) * o.cout * 4);
+            L.stat_off[i] = f; f += up256(uint64_t(2) * o.cout * 4);
+            L.gx_off[i] = b; b += up256(uint64_t(n_out) * o.cout * 4);
+            need_ws(osn_bn_ws_bytes(n_out, o.cout));
+        }
+        if (o.res >= 0) { L.gres_off[i] = b; b += up256(uint64_t(n_out) * o.cout * 4); }
+        if (o.need_dgrad) { L.gin_off[i] = b; b += up256(uint64_t(n_in) * o.cin * 4); }
+        // ---- forward kernel
+        if (stem_eligible(o.K, o.cin, o.cout)) {
+            OSN_REQUIRE(!o.transposed, OSN_E_ARG, "osn_net: op %d: transposed stem", i);
+            L.fwd_k[i] = OSN_NET_K_STEM;
+        } else if (o.K > 1 && tl_eligible(o.K, o.cin, o.cout, n_in) && n_out >= net->tl_min_rows) {
+            L.fwd_k[i] = OSN_NET_K_TL;
+            L.images[i] |= OSN_NET_IMG_TL_FWD;
+            need_ws(osn_spconv_fwd_tl_ws_bytes(n_out, o.K, o.cout, osn_tile_rows(n_out)));
+        } else if (x6_eligible(o.K, o.cin, o.cout, n_out)) {
+            L.fwd_k[i] = OSN_NET_K_X6;
+            L.images[i] |= OSN_NET_IMG_X6_FWD;
+            need_ws(osn_spconv_fwd_ws_bytes(n_out, o.K, o.cin, o.cout));
+        } else {
+            OSN_REQUIRE(false, OSN_E_ARG, "osn_net: op %d (K=%d, %d -> %d) fits none of the executor's forward kernels", i, o.K, o.cin, o.cout);
+        }
+        if (!training) continue;
+        // ---- input gradient: a convolution of the output gradient with the transposed weights, [n_in, cin]
+        if (o.need_dgrad) {
+            if (o.K > 1 && tl_eligible(o.K, o.cout, o.cin, n_out) && tl_eligible(o.K, o.cin, o.cout, n_in) && n_in >= net->tl_min_rows) {
+                L.dgrad_k[i] = OSN_NET_K_TL;
+                L.images[i] |= OSN_NET_IMG_TL_DGRAD;
+                need_ws(osn_spconv_fwd_tl_ws_bytes(n_in, o.K, o.cin, osn_tile_rows(n_in)));
+            } else if (x6_eligible(o.K, o.cout, o.cin, n_in)) {
+                L.dgrad_k[i] = OSN_NET_K_X6;
+                L.images[i] |= OSN_NET_IMG_X6_DGRAD;
+                need_ws(osn_spconv_fwd_ws_bytes(n_in, o.K, o.cout, o.cin));
+            } else {
+                OSN_REQUIRE(false, OSN_E_ARG, "osn_net: op %d (K=%d, %d -> %d) fits none of the executor's input-gradient kernels", i, o.K, o.cin, o.cout);
+            }
+        }
+        // ---- weight gradient
+        if (o.K > 1 && tl_eligible(o.K, o.cin, o.cout, n_in) && !stem_eligible(o.K, o.cin, o.cout)) {
+            L.wgrad_k[i] = OSN_NET_K_WGRAD_TL;
+            need_ws(osn_spconv_wgrad_tl_ws_bytes(o.K, o.cin, o.cout));
+        } else {
+            L.wgrad_k[i] = OSN_NET_K_WGRAD;
+            need_ws(osn_spconv_wgrad_ws_bytes(n_out, o.K, o.cin, o.cout));
+        }
+    }
+    for (int bf = 0; bf < net->n_bufs; ++bf) {
+        L.y_off[bf] = f;
+        f += up256(uint64_t(rows[net->bufs[bf].level]) * net->bufs[bf].channels * 4);
+    }
+    L.fwd_bytes = f + 256;
+    L.bwd_bytes = b + 256;
+    L.ws_bytes = up256(ws);
+    return OSN_OK;
+}
+
+struct Bracket {
+    Prof* p;
+    hipStream_t st;
+    int slot;
+    Bracket(osn_prof_t* prof, int op, int phase, hipStream_t s) : p(reinterpret_cast<Prof*>(prof)), st(s), slot(-1) {
+        if (!p || p->n >= p->cap) return;
+        if (p->filter_op >= 0 && (p->filter_op != op || (p->filter_phase >= 0 && p->filter_phase != phase))) return;
+        slot = p->n++;
+        p->tag[slot] = op * 4 + phase;
+        (void)hipEventRecord(p->ev[2 * slot], st);
+    }
+    ~Bracket() {
+        if (slot >= 0) (void)hipEventRecord(p->ev[2 * slot + 1], st);
+    }
+};
+
+// effective tables of a stage: a transposed convolution runs on the mirrored tables of the strided conv's map
+struct MapView {
+    const int32_t *nbr_f, *nbr_b, *tf_rows, *tf_tbl, *tb_rows, *tb_tbl;
+    const uint32_t *tf_g, *tb_g;
+    const void *tl_f, *tl_b;
+    const int32_t *tl_f_rows, *tl_b_rows;
+    int tl_f_bm, tl_b_bm;
+};
+static MapView view_of(const osn_net_map& m, bool transposed) {
+    MapView v;
+    if (!transposed) {
+        v.nbr_f = m.nbr_fwd; v.nbr_b = m.nbr_bwd;
+        v.tf_rows = m.tiles_fwd_rows; v.tf_tbl = m.tiles_fwd_tbl; v.tf_g = m.tiles_fwd_gmask;
+        v.tb_rows = m.tiles_bwd_rows; v.tb_tbl = m.tiles_bwd_tbl; v.tb_g = m.tiles_bwd_gmask;
+        v.tl_f = m.tl_fwd; v.tl_f_rows = m.tl_fwd_rows; v.tl_f_bm = m.tl_fwd_bm;
+        v.tl_b = m.tl_bwd; v.tl_b_rows = m.tl_bwd_rows; v.tl_b_bm = m.tl_bwd_bm;
+    } else {
+        v.nbr_f = m.nbr_bwd; v.nbr_b = m.nbr_fwd;
+        v.tf_rows = m.tiles_bwd_rows; v.tf_tbl = m.tiles_bwd_tbl; v.tf_g = m.tiles_bwd_gmask;
+        v.tb_rows = m.tiles_fwd_rows; v.tb_tbl = m.tiles_fwd_tbl; v.tb_g = m.tiles_fwd_gmask;
+        v.tl_f = m.tl_bwd; v.tl_f_rows = m.tl_bwd_rows; v.tl_f_bm = m.tl_bwd_bm;
+        v.tl_b = m.tl_fwd; v.tl_b_rows = m.tl_fwd_rows; v.tl_b_bm = m.tl_fwd_bm;
+    }
+    return v;
+}
+
+// out[n_out, cout] = conv(in[n_in, cin]) over table side `fwd` of the view, with weight images `x6` / `tl`
+static int run_conv(int kernel, const float* in, int64_t n_in, float* out, int64_t n_out, int K, int cin, int cout,
+                    const float* W, const void* img_x6, const void* img_tl, const int32_t* nbr, const int32_t* t_rows,
+                    const int32_t* t_tbl, const uint32_t* t_g, const void* tl, const int32_t* tl_rows, int tl_bm,
+                    const osn_net_run* run, osn_stream_t stream, int op) {
+    switch (kernel) {
+        case OSN_NET_K_STEM:
+            OSN_REQUIRE(nbr && W, OSN_E_ARG, "osn_net: op %d: the stem kernel needs the plain table and the fp32 weight", op);
+            return osn_stem_conv_fwd(in, W, nbr, out, n_out, K, cin, cout, stream);
+        case OSN_NET_K_TL:
+            OSN_REQUIRE(tl && img_tl && run->tl_counters, OSN_E_ARG, "osn_net: op %d: tile lists / tile-list weight image / counters missing", op);
+            return osn_spconv_fwd_tl_pc(in, n_in, img_tl, tl, tl_rows, out, nullptr, n_out, K, cin, cout, tl_bm, run->ws,
+                                        size_t(run->ws_bytes), run->tl_counters, stream);
+        case OSN_NET_K_X6: {
+            OSN_REQUIRE(img_x6 && (K == 1 || nbr), OSN_E_ARG, "osn_net: op %d: split-bf16 weight image / table missing", op);
+            const int32_t* tbl = K == 1 ? nullptr : (t_tbl ? t_tbl : nbr);
+            const int32_t* rows = (K > 1 && t_tbl) ? t_rows : nullptr;
+            const uint32_t* gm = (K > 1 && t_tbl) ? t_g : nullptr;
+            return osn_spconv_fwd_x6(in, img_x6, tbl, rows, gm, out, n_out, K, cin, cout, run->ws, size_t(run->ws_bytes), stream);
+        }
+        default:
+            OSN_REQUIRE(false, OSN_E_ARG, "osn_net: op %d has no kernel", op);
+    }
+    return OSN_OK;
+}
+
+static int check_run(const osn_net_desc* net, const osn_net_run* run, const Layout& L, bool backward) {
+    OSN_REQUIRE(run && run->level_rows && run->weights && (net->n_bns == 0 || run->bns) && (net->n_maps == 0 || run->maps) && run->input,
+                OSN_E_ARG, "osn_net: null run descriptor member");
+    OSN_REQUIRE(run->first_op >= 0 && run->first_op <= run->end_op && run->end_op <= net->n_ops, OSN_E_ARG, "osn_net: op range [%d, %d)", run->first_op, run->end_op);
+    OSN_REQUIRE(run->fwd_arena && run->fwd_arena_bytes >= L.fwd_bytes && aligned16(run->fwd_arena), OSN_E_WS,
+                "osn_net: forward arena %llu < %llu bytes", (unsigned long long)run->fwd_arena_bytes, (unsigned long long)L.fwd_bytes);
+    OSN_REQUIRE(run->ws && run->ws_bytes >= L.ws_bytes, OSN_E_WS, "osn_net: workspace %llu < %llu bytes",
+                (unsigned long long)run->ws_bytes, (unsigned long long)L.ws_bytes);
+    if (backward)
+        OSN_REQUIRE(run->bwd_arena && run->bwd_arena_bytes >= L.bwd_bytes && aligned16(run->bwd_arena), OSN_E_WS,
+                    "osn_net: backward arena %llu < %llu bytes", (unsigned long long)run->bwd_arena_bytes, (unsigned long long)L.bwd_bytes);
+    return OSN_OK;
+}
+
+}  // namespace osn
+
+using namespace osn;
+
+extern "C" int osn_net_plan_query(const osn_net_desc* net, const int64_t* level_rows, int training, osn_net_plan* plan) {
+    OSN_REQUIRE(plan, OSN_E_ARG, "osn_net_plan_query: null plan");
+    Layout L;
+    int rc = make_layout(net, level_rows, training, L);
+    if (rc) return rc;
+    plan->fwd_arena_bytes = L.fwd_bytes;
+    plan->bwd_arena_bytes = L.bwd_bytes;
+    plan->ws_bytes = L.ws_bytes;
+    for (int i = 0; i < net->n_ops; ++i) {
+        if (plan->x_off) plan->x_off[i] = L.x_off[i];
+        if (plan->stat_off) plan->stat_off[i] = L.stat_off[i];
+        if (plan->fwd_kernel) plan->fwd_kernel[i] = L.fwd_k[i];
+        if (plan->dgrad_kernel) plan->dgrad_kernel[i] = L.dgrad_k[i];
+        if (plan->wgrad_kernel) plan->wgrad_kernel[i] = L.wgrad_k[i];
+        if (plan->images) plan->images[i] = L.images[i];
+    }
+    if (plan->y_off)
+        for (int b = 0; b < net->n_bufs; ++b) plan->y_off[b] = L.y_off[b];
+    return OSN_OK;
+}
+
+extern "C" int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, osn_stream_t stream) {
+    OSN_REQUIRE(net && run, OSN_E_ARG, "osn_net_forward: null argument");
+    Layout L;
+    int rc = make_layout(net, run->level_rows, run->training, L);
+    if (rc) return rc;
+    rc = check_run(net, run, L, false);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* A = static_cast<char*>(run->fwd_arena);
+    const int64_t* rows = run->level_rows;
+    for (int i = run->first_op; i < run->end_op; ++i) {
+        const osn_net_op& o = net->ops[i];
+        const int64_t n_in = rows[o.lvl_in], n_out = rows[o.lvl_out];
+        const osn_net_weight& w = run->weights[o.weight];
+        const float* in = o.src < 0 ? run->input : reinterpret_cast<const float*>(A + L.y_off[o.src]);
+        float* x = o.dst < 0 ? run->output : reinterpret_cast<float*>(A + L.x_off[i]);
+        OSN_REQUIRE(x, OSN_E_ARG, "osn_net_forward: op %d writes the network output but run->output is null", i);
+        MapView v{};
+        if (o.map >= 0) {
+            OSN_REQUIRE(run->maps[o.map].K == o.K, OSN_E_ARG, "osn_net_forward: op %d (K=%d) got a map with K=%d", i, o.K, run->maps[o.map].K);
+            v = view_of(run->maps[o.map], o.transposed != 0);
+        }
+        {
+            Bracket br(run->prof, i, 0, st);
+            rc = run_conv(L.fwd_k[i], in, n_in, x, n_out, o.K, o.cin, o.cout, w.W, w.x6_fwd, w.tl_fwd, v.nbr_f, v.tf_rows, v.tf_tbl,
+                          v.tf_g, v.tl_f, v.tl_f_rows, v.tl_f_bm, run, stream, i);
+        }
+        if (rc) return rc;
+        if (o.bn < 0) continue;
+        const osn_net_bn& bn = run->bns[o.bn];
+        float* y = reinterpret_cast<float*>(A + L.y_off[o.dst]);
+        const float* res = o.res >= 0 ? reinterpret_cast<const float*>(A + L.y_off[o.res]) : nullptr;
+        float* y2 = nullptr;
+        int64_t ld2 = 0;
+        if (o.copy_buf >= 0) {
+            ld2 = net->bufs[o.copy_buf].channels;
+            y2 = reinterpret_cast<float*>(A + L.y_off[o.copy_buf]) + o.copy_col;
+        }
+        const float *mean = bn.running_mean, *var = bn.running_var;
+        if (run->training) {
+            float* mv = reinterpret_cast<float*>(A + L.stat_off[i]);
+            rc = osn_bn_stats(x, n_out, o.cout, mv, mv + o.cout, bn.running_mean, bn.running_var, bn.momentum, run->ws,
+                              size_t(run->ws_bytes), stream);
+            if (rc) return rc;
+            mean = mv; var = mv + o.cout;
+        }
+        OSN_REQUIRE(mean && var, OSN_E_ARG, "osn_net_forward: op %d: evaluation-mode batch norm without running statistics", i);
+        rc = osn_bn_apply2(x, mean, var, bn.gamma, bn.beta, bn.eps, res, o.relu, y, y2, ld2, n_out, o.cout, stream);
+        if (rc) return rc;
+    }
+    (void)st;
+    return OSN_OK;
+}
+
+extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run, osn_stream_t stream) {
+    OSN_REQUIRE(net && run, OSN_E_ARG, "osn_net_backward: null argument");
+    Layout L;
+    int rc = make_layout(net, run->level_rows, 1, L);
+    if (rc) return rc;
+    rc = check_run(net, run, L, true);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* A = static_cast<char*>(run->fwd_arena);
+    char* B = static_cast<char*>(run->bwd_arena);
+    const int64_t* rows = run->level_rows;
+    for (int i = run->end_op - 1; i >= run->first_op; --i) {
+        const osn_net_op& o = net->ops[i];
+        const int64_t n_in = rows[o.lvl_in], n_out = rows[o.lvl_out];
+        const osn_net_weight& w = run->weights[o.weight];
+        // ---- the gradient arriving at this stage's output: every consumer of dst (and of its copy inside a cat buffer)
+        const float* gsrc[4];
+        int64_t gld[4];
+        int ng = 0;
+        if (o.dst < 0) {
+            OSN_REQUIRE(run->goutput, OSN_E_ARG, "osn_net_backward: null output gradient");
+            gsrc[ng] = run->goutput; gld[ng] = o.cout; ++ng;
+        } else {
+            for (int j = i + 1; j < run->end_op && ng < 4; ++j) {
+                const osn_net_op& c = net->ops[j];
+                if (c.src == o.dst && c.need_dgrad) { gsrc[ng] = reinterpret_cast<const float*>(B + L.gin_off[j]); gld[ng] = c.cin; ++ng; }
+                if (ng < 4 && c.res == o.dst) { gsrc[ng] = reinterpret_cast<const float*>(B + L.gres_off[j]); gld[ng] = c.cout; ++ng; }
+                if (ng < 4 && o.copy_buf >= 0 && c.src == o.copy_buf && c.need_dgrad) {
+                    gsrc[ng] = reinterpret_cast<const float*>(B + L.gin_off[j]) + o.copy_col; gld[ng] = c.cin; ++ng;
+                }
+            }
+            OSN_REQUIRE(ng >= 1 && ng <= 3, OSN_E_ARG, "osn_net_backward: the output of op %d has %s consumers inside the executed range (1 .. 3 supported)",
+                        i, ng == 0 ? "no" : "more than three");
+        }
+        const float* gx;
+        if (o.bn >= 0) {
+            const osn_net_bn& bn = run->bns[o.bn];
+            const float* x = reinterpret_cast<const float*>(A + L.x_off[i]);
+            const float* y = reinterpret_cast<const float*>(A + L.y_off[o.dst]);
+            const float *mean = bn.running_mean, *var = bn.running_var;
+            if (run->training) {
+                const float* mv = reinterpret_cast<const float*>(A + L.stat_off[i]);
+                mean = mv; var = mv + o.cout;
+            }
+            float* gxw = reinterpret_cast<float*>(B + L.gx_off[i]);
+            float* gres = o.res >= 0 ? reinterpret_cast<float*>(B + L.gres_off[i]) : nullptr;
+            OSN_REQUIRE(bn.ggamma && bn.gbeta, OSN_E_ARG, "osn_net_backward: op %d: null batch-norm gradient pointers", i);
+            rc = osn_bn_backward_multi(x, y, gsrc, gld, ng, mean, var, bn.gamma, bn.eps, o.relu, run->training, gxw, gres,
+                                       bn.ggamma, bn.gbeta, n_out, o.cout, run->ws, size_t(run->ws_bytes), stream);
+            if (rc) return rc;
+            gx = gxw;
+        } else {
+            OSN_REQUIRE(ng == 1 && gld[0] == o.cout, OSN_E_ARG, "osn_net_backward: op %d without a batch norm needs one contiguous gradient", i);
+            gx = gsrc[0];
+        }
+        const float* in = o.src < 0 ? run->input : reinterpret_cast<const float*>(A + L.y_off[o.src]);
+        MapView v{};
+        const osn_net_map* m = o.map >= 0 ? &run->maps[o.map] : nullptr;
+        if (m) v = view_of(*m, o.transposed != 0);
+        // ---- weight gradient
+        OSN_REQUIRE(w.gW, OSN_E_ARG, "osn_net_backward: op %d: null weight-gradient pointer", i);
+        {
+            Bracket br(run->prof, i, 2, st);
+            if (L.wgrad_k[i] == OSN_NET_K_WGRAD_TL) {
+                // pair arrays of the map's forward table; a transposed conv uses the strided conv's arrays, roles swapped
+                OSN_REQUIRE(m && m->pl_fwd, OSN_E_ARG, "osn_net_backward: op %d: pair lists missing", i);
+                rc = osn_spconv_wgrad_tl(in, gx, m->pl_fwd, o.transposed ? 1 : 0, w.gW, n_in, n_out, o.K, o.cin, o.cout, run->ws,
+                                         size_t(run->ws_bytes), stream);
+            } else {
+                rc = osn_spconv_wgrad(in, gx, o.K > 1 ? v.nbr_f : nullptr, o.K > 1 && m ? m->counts : nullptr, nullptr, w.gW, n_out, o.K,
+                                      o.cin, o.cout, run->ws, size_t(run->ws_bytes), stream);
+            }
+        }
+        if (rc) return rc;
+        // ---- input gradient
+        if (o.need_dgrad) {
+            float* gin = reinterpret_cast<float*>(B + L.gin_off[i]);
+            Bracket br(run->prof, i, 1, st);
+            rc = run_conv(L.dgrad_k[i], gx, n_out, gin, n_in, o.K, o.cout, o.cin, nullptr, w.x6_dgrad, w.tl_dgrad, v.nbr_b, v.tb_rows,
+                          v.tb_tbl, v.tb_g, v.tl_b, v.tl_b_rows, v.tl_b_bm, run, stream, i);
+            if (rc) return rc;
+        }
+    }
+    return OSN_OK;
+}
+
+// ------------------------------------------------------------------------------------------- launch timer
+extern "C" osn_prof_t* osn_prof_create(int capacity) {
+    if (capacity < 1) return nullptr;
+    Prof* p = new (std::nothrow) Prof();
+    if (!p) return nullptr;
+    p->ev.resize(size_t(2) * capacity, nullptr);
+    p->tag.assign(capacity, 0);
+    for (int i = 0; i < 2 * capacity; ++i) {
+        if (hipEventCreate(&p->ev[i]) != hipSuccess) {
+            for (int j = 0; j < i; ++j) (void)hipEventDestroy(p->ev[j]);
+            delete p;
+            return nullptr;
+        }
+    }
+    p->cap = capacity;
+    return reinterpret_cast<osn_prof_t*>(p);
+}
+
+extern "C" void osn_prof_destroy(osn_prof_t* h) {
+    Prof* p = reinterpret_cast<Prof*>(h);
+    if (!p) return;
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    delete p;
+}
+
+extern "C" int osn_prof_filter(osn_prof_t* h, int filter_op, int filter_phase) {
+    Prof* p = reinterpret_cast<Prof*>(h);
+    OSN_REQUIRE(p, OSN_E_ARG, "osn_prof_filter: null handle");
+    p->filter_op = filter_op;
+    p->filter_phase = filter_phase;
+    return OSN_OK;
+}
+
+extern "C" int osn_prof_read(osn_prof_t* h, int32_t* tags, float* ms, int capacity, int reset) {
+    Prof* p = reinterpret_cast<Prof*>(h);
+    if (!p || !tags || !ms) return 0;
+    int n = p->n < capacity ? p->n : capacity;
+    for (int i = 0; i < n; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(p->ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&t, p->ev[2 * i], p->ev[2 * i + 1]) != hipSuccess)
+            t = -1.f;
+        tags[i] = p->tag[i];
+        ms[i] = t;
+    }
+    if (reset) p->n = 0;
+    return n;
+}

@@ -1,0 +1,391 @@
+"""Host side of the network executor (csrc/net.hip, include/openscene_amd.h "network executor").
+
+``MinkUNetBase.forward`` (the mirror of models/mink_unet.py:116-174) is compiled ONCE into a linear program of stages
+-- conv [-> BN (+ residual) (+ ReLU)] [-> second store into a cat buffer] -- and every forward / backward pass is then
+ONE C call that issues all its launches, instead of ~250 trips through Python, autograd and ctypes per training step.
+Same kernels, same results as the module-by-module path (``minkowski.py`` / ``functional.py``), which stays the drop-in
+surface for the reference's own ``models/mink_unet.py`` and the path of every configuration the executor does not take
+(``OSN_EXECUTOR=0``, an arithmetic mode other than "tl", BN variants the reference never builds).
+
+What Python still does per pass: build the coordinate manager's maps (``CoordinateManager.prebuild``), hand their
+device pointers over, allocate the activation arena and the flat gradient buffer, refresh the weight images.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from . import _lib, ops
+from ._lib import check
+
+ENABLED = os.environ.get("OSN_EXECUTOR", "1") != "0"
+
+_OP = np.dtype([(n, "<i4") for n in ("K", "cin", "cout", "lvl_in", "lvl_out", "map", "transposed", "src", "dst", "bn", "relu",
+                                     "res", "copy_buf", "copy_col", "weight", "need_dgrad")])
+_BUF = np.dtype([("level", "<i4"), ("channels", "<i4")])
+_MAP = np.dtype([(n, "<u8") for n in ("nbr_fwd", "nbr_bwd", "tiles_fwd_rows", "tiles_fwd_tbl", "tiles_fwd_gmask",
+                                      "tiles_bwd_rows", "tiles_bwd_tbl", "tiles_bwd_gmask", "counts", "tl_fwd", "tl_fwd_rows",
+                                      "tl_bwd", "tl_bwd_rows", "pl_fwd")] +
+                [(n, "<i4") for n in ("K", "flip", "tl_fwd_bm", "tl_bwd_bm")])
+_WEIGHT = np.dtype([(n, "<u8") for n in ("W", "x6_fwd", "x6_dgrad", "tl_fwd", "tl_dgrad", "gW")])
+_BN = np.dtype([(n, "<u8") for n in ("gamma", "beta", "running_mean", "running_var", "ggamma", "gbeta")] +
+               [("eps", "<f4"), ("momentum", "<f4")])
+assert _OP.itemsize == 64 and _MAP.itemsize == 128 and _WEIGHT.itemsize == 48 and _BN.itemsize == 56
+
+IMG_X6_FWD, IMG_X6_DGRAD, IMG_TL_FWD, IMG_TL_DGRAD = 1, 2, 4, 8
+K_NAMES = {0: "none", 1: "stem", 2: "tl", 3: "x6", 4: "wgrad_tl", 5: "wgrad"}
+
+
+class _Desc(ctypes.Structure):
+    _fields_ = [("n_ops", ctypes.c_int32), ("n_bufs", ctypes.c_int32), ("n_bns", ctypes.c_int32), ("n_weights", ctypes.c_int32),
+                ("n_maps", ctypes.c_int32), ("n_levels", ctypes.c_int32), ("tl_min_rows", ctypes.c_int32),
+                ("bn_small_rows", ctypes.c_int32), ("ops", ctypes.c_void_p), ("bufs", ctypes.c_void_p)]
+
+
+class _Plan(ctypes.Structure):
+    _fields_ = [("fwd_arena_bytes", ctypes.c_uint64), ("bwd_arena_bytes", ctypes.c_uint64), ("ws_bytes", ctypes.c_uint64),
+                ("x_off", ctypes.c_void_p), ("stat_off", ctypes.c_void_p), ("y_off", ctypes.c_void_p),
+                ("fwd_kernel", ctypes.c_void_p), ("dgrad_kernel", ctypes.c_void_p), ("wgrad_kernel", ctypes.c_void_p),
+                ("images", ctypes.c_void_p)]
+
+
+class _Run(ctypes.Structure):
+    _fields_ = [("level_rows", ctypes.c_void_p), ("maps", ctypes.c_void_p), ("weights", ctypes.c_void_p), ("bns", ctypes.c_void_p),
+                ("input", ctypes.c_void_p), ("output", ctypes.c_void_p), ("goutput", ctypes.c_void_p),
+                ("fwd_arena", ctypes.c_void_p), ("fwd_arena_bytes", ctypes.c_uint64),
+                ("bwd_arena", ctypes.c_void_p), ("bwd_arena_bytes", ctypes.c_uint64),
+                ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_uint64),
+                ("tl_counters", ctypes.c_void_p), ("training", ctypes.c_int32), ("first_op", ctypes.c_int32),
+                ("end_op", ctypes.c_int32), ("reserved", ctypes.c_int32), ("prof", ctypes.c_void_p)]
+
+
+def _ptr(a):
+    return a.ctypes.data
+
+
+class Program:
+    """The stage program of one MinkUNet (pure data: built from the module tree, independent of any input)."""
+
+    STRIDES = (1, 2, 4, 8, 16)
+
+    def __init__(self, model):
+        from . import mink_unet as mu
+        from .minkowski import BasicBlock
+        self.ops, self.bufs, self.convs, self.bns, self.map_keys = [], [], [], [], []
+        self.relu_bufs = []                      # buffers behind a ReLU, in call order (test hook)
+        P, L, E = model.PLANES, model.LAYERS, model.BLOCK.expansion
+        if model.BLOCK is not BasicBlock:
+            raise NotImplementedError("the executor compiles BasicBlock networks (every shipped MinkUNet variant)")
+        init = model.INIT_DIM
+        skip_width = (P[2] * E, P[1] * E, P[0] * E, init)
+        # cat buffers of the four decoder stages: [up-branch | encoder skip] at levels 3, 2, 1, 0
+        cat = [self._buf(3 - i, P[4 + i] + skip_width[i]) for i in range(4)]
+        skip_copy = {3 - i: (cat[i], P[4 + i]) for i in range(4)}            # encoder level -> (cat buffer, first column)
+        x = self._stage(model.conv0p1s1, model.bn0, -1, 0, 0, relu=True, need_dgrad=False, copy=skip_copy[0])
+        for i in range(4):
+            x = self._stage(getattr(model, mu._DOWN[i]), getattr(model, "bn%d" % (i + 1)), x, i, i + 1, relu=True)
+            x = self._blocks(getattr(model, "block%d" % (i + 1)), x, i + 1, copy=skip_copy.get(i + 1))
+        for i in range(4):
+            lvl = 4 - i
+            self._stage(getattr(model, mu._UP[i]), getattr(model, "bntr%d" % (4 + i)), x, lvl, lvl - 1, relu=True, transposed=True,
+                        copy=(cat[i], 0))
+            x = self._blocks(getattr(model, "block%d" % (5 + i)), cat[i], lvl - 1, copy=None)
+        self.feature_buf = x
+        self._stage(model.final, None, x, 0, 0, relu=False)
+        self.n_levels = 5
+        self.op_arr = np.zeros(len(self.ops), dtype=_OP)
+        for i, o in enumerate(self.ops):
+            self.op_arr[i] = tuple(o[n] for n in _OP.names)
+        self.buf_arr = np.array(self.bufs, dtype=_BUF)
+        self.params = [c.kernel for c in self.convs]
+        for b in self.bns:
+            self.params += [b.bn.weight, b.bn.bias]
+
+    def _buf(self, level, channels):
+        self.bufs.append((level, channels))
+        return len(self.bufs) - 1
+
+    def _map(self, conv, lvl_in, lvl_out, transposed):
+        if conv.kernel_volume == 1:
+            return -1
+        s_in, s_out = self.STRIDES[lvl_in], self.STRIDES[lvl_out]
+        key = (s_out, s_in, conv.kernel_size, conv.dilation) if transposed else (s_in, s_out, conv.kernel_size, conv.dilation)
+        if key not in self.map_keys:
+            self.map_keys.append(key)
+        return self.map_keys.index(key)
+
+    def _stage(self, conv, norm, src, lvl_in, lvl_out, relu, res=-1, transposed=False, copy=None, need_dgrad=True):
+        from .minkowski import MinkowskiConvolutionTranspose
+        if conv.bias is not None:
+            raise NotImplementedError("the executor compiles bias-free convolutions (the reference builds no other)")
+        if isinstance(conv, MinkowskiConvolutionTranspose) != bool(transposed) or conv.dilation != 1:
+            raise NotImplementedError("unexpected convolution type / dilation in the MinkUNet tree")
+        dst = self._buf(lvl_out, conv.out_channels) if norm is not None else -1
+        self.convs.append(conv)
+        bn = -1
+        if norm is not None:
+            self.bns.append(norm)
+            bn = len(self.bns) - 1
+        self.ops.append(dict(K=conv.kernel_volume, cin=conv.in_channels, cout=conv.out_channels, lvl_in=lvl_in, lvl_out=lvl_out,
+                             map=self._map(conv, lvl_in, lvl_out, transposed), transposed=int(transposed), src=src, dst=dst, bn=bn,
+                             relu=int(relu), res=res, copy_buf=copy[0] if copy else -1, copy_col=copy[1] if copy else 0,
+                             weight=len(self.convs) - 1, need_dgrad=int(need_dgrad)))
+        if relu and dst >= 0:
+            self.relu_bufs.append(dst)
+        return dst
+
+    def _blocks(self, stage, x, lvl, copy):
+        from .minkowski import MinkowskiBatchNorm
+        blocks = list(stage)
+        for bi, blk in enumerate(blocks):
+            y = self._stage(blk.conv1, blk.norm1, x, lvl, lvl, relu=True)
+            res = x
+            ds = blk.downsample
+            if ds is not None:
+                if not (isinstance(ds, torch.nn.Sequential) and len(ds) == 2 and isinstance(ds[1], MinkowskiBatchNorm)):
+                    raise NotImplementedError("BasicBlock shortcut is not conv + batch norm")
+                res = self._stage(ds[0], ds[1], x, lvl, lvl, relu=False)
+            x = self._stage(blk.conv2, blk.norm2, y, lvl, lvl, relu=True, res=res,
+                            copy=copy if bi == len(blocks) - 1 else None)
+        return x
+
+
+class _PassState:
+    """What a forward pass leaves for its backward pass (kept alive by the autograd node)."""
+    __slots__ = ("rows", "maps", "weights", "bns", "arena", "keep", "training", "feats", "plan_fwd_bytes", "cm")
+
+
+class UNetExecutor:
+    def __init__(self, model):
+        self.program = Program(model)
+        p = self.program
+        self.desc = _Desc(len(p.ops), len(p.bufs), len(p.bns), len(p.convs), len(p.map_keys), p.n_levels, 0, 0,
+                          _ptr(p.op_arr), _ptr(p.buf_arr))
+        n = len(p.ops)
+        self._x_off = np.zeros(n, np.uint64)
+        self._stat_off = np.zeros(n, np.uint64)
+        self._y_off = np.zeros(len(p.bufs), np.uint64)
+        self._kf = np.zeros(n, np.int32)
+        self._kd = np.zeros(n, np.int32)
+        self._kw = np.zeros(n, np.int32)
+        self._img = np.zeros(n, np.int32)
+        self._plan = _Plan(0, 0, 0, _ptr(self._x_off), _ptr(self._stat_off), _ptr(self._y_off), _ptr(self._kf), _ptr(self._kd),
+                           _ptr(self._kw), _ptr(self._img))
+        self._rows = np.zeros(8, np.int64)
+        self.prof = None                  # osn_prof_t* (bench.py), or None
+        # gradient layout: one flat fp32 buffer, every parameter's slice starts on a 16-byte boundary
+        self.grad_off, off = [], 0
+        for prm in p.params:
+            self.grad_off.append(off)
+            off += (prm.numel() + 3) // 4 * 4
+        self.grad_total = off
+
+    # -------------------------------------------------------------------------------------------- eligibility
+    def usable(self, x):
+        from . import functional as F_
+        if not ENABLED or F_.CONV_MODE != "tl":
+            return False
+        f = x.F
+        if not (f.is_cuda and f.dtype == torch.float32 and x.tensor_stride == 1):
+            return False
+        p = self.program
+        if f.shape[1] != p.convs[0].in_channels:
+            return False
+        for m in p.bns:
+            b = m.bn
+            if b.momentum is None or not b.affine or not b.track_running_stats or b.weight.device != f.device:
+                return False
+        return all(c.kernel.device == f.device and c.kernel.dtype == torch.float32 for c in p.convs)
+
+    # -------------------------------------------------------------------------------------------- marshalling
+    def _plan_query(self, lib, rows, training):
+        from . import functional as F_
+        self.desc.tl_min_rows = int(F_.TL_FWD_MIN_ROWS)
+        self._rows[:len(rows)] = rows
+        check(lib.osn_net_plan_query(ctypes.addressof(self.desc), _ptr(self._rows), int(training), ctypes.addressof(self._plan)),
+              "osn_net_plan_query")
+
+    def _maps(self, cm, training):
+        p = self.program
+        arr = np.zeros(max(len(p.map_keys), 1), dtype=_MAP)
+        keep = []
+        dp = lambda t: t.data_ptr() if t is not None else 0
+        for i, (s_in, s_out, k, dil) in enumerate(p.map_keys):
+            fwd, bwd, flip = cm.kmap(s_in, s_out, k, dil)
+            tf, tb = cm.kmap_tiles(s_in, s_out, k, dil)
+            counts = cm.kmap_counts(s_in, s_out, k, dil)
+            lf = lb = None
+            if ops.tl_eligible(k ** 3, 8, 8):                       # K <= 128: every map but none is excluded; channel test per op
+                lists = cm.kmap_lists(s_in, s_out, k, dil) if k ** 3 <= 32 else (None, None)
+                lf, lb = lists
+            a = arr[i]
+            a["nbr_fwd"], a["nbr_bwd"], a["flip"], a["K"] = dp(fwd), dp(bwd), int(bool(flip)), k ** 3
+            if tf is not None:
+                a["tiles_fwd_rows"], a["tiles_fwd_tbl"], a["tiles_fwd_gmask"] = dp(tf[0]), dp(tf[1]), dp(tf[2])
+            if tb is not None:
+                a["tiles_bwd_rows"], a["tiles_bwd_tbl"], a["tiles_bwd_gmask"] = dp(tb[0]), dp(tb[1]), dp(tb[2])
+            a["counts"] = dp(counts)
+            if lf is not None:
+                a["tl_fwd"], a["tl_fwd_rows"], a["tl_fwd_bm"] = dp(lf.buf), dp(lf.out_rows), lf.bm
+                if training:
+                    a["pl_fwd"] = dp(ops.pair_lists(lf))
+            if lb is not None:
+                a["tl_bwd"], a["tl_bwd_rows"], a["tl_bwd_bm"] = dp(lb.buf), dp(lb.out_rows), lb.bm
+            keep.append((fwd, bwd, tf, tb, counts, lf, lb))
+        return arr, keep
+
+    def _weights(self, cm, need_images):
+        p = self.program
+        arr = np.zeros(len(p.convs), dtype=_WEIGHT)
+        keep = []
+        flips = {}
+        for i, (s_in, s_out, k, dil) in enumerate(p.map_keys):
+            flips[i] = bool(cm.kmap(s_in, s_out, k, dil)[2])
+        for i, conv in enumerate(p.convs):
+            w = conv.kernel
+            a = arr[i]
+            a["W"] = w.data_ptr()
+            bits = int(need_images[i])
+            flip = flips.get(int(p.op_arr[i]["map"]), False)
+            if bits & IMG_X6_FWD:
+                t = ops.weight_image(w, False, False, ops.PREP_X6); a["x6_fwd"] = t.data_ptr(); keep.append(t)
+            if bits & IMG_TL_FWD:
+                t = ops.weight_image(w, False, False, ops.PREP_TL); a["tl_fwd"] = t.data_ptr(); keep.append(t)
+            if bits & IMG_X6_DGRAD:
+                t = ops.weight_image(w, flip, True, ops.PREP_X6); a["x6_dgrad"] = t.data_ptr(); keep.append(t)
+            if bits & IMG_TL_DGRAD:
+                t = ops.weight_image(w, flip, True, ops.PREP_TL); a["tl_dgrad"] = t.data_ptr(); keep.append(t)
+        return arr, keep
+
+    def _bns(self, training):
+        p = self.program
+        arr = np.zeros(max(len(p.bns), 1), dtype=_BN)
+        for i, m in enumerate(p.bns):
+            b = m.bn
+            a = arr[i]
+            a["gamma"], a["beta"] = b.weight.data_ptr(), b.bias.data_ptr()
+            a["running_mean"], a["running_var"] = b.running_mean.data_ptr(), b.running_var.data_ptr()
+            a["eps"], a["momentum"] = b.eps, b.momentum
+        return arr
+
+    # -------------------------------------------------------------------------------------------- passes
+    def forward(self, model, x, features_only=False):
+        """-> the network output [N_0, out_channels] (or, features_only, the input of the final 1x1 conv)."""
+        p = self.program
+        grad = torch.is_grad_enabled() and (x.F.requires_grad or any(q.requires_grad for q in p.params))
+        if grad and features_only:
+            return None                                          # training through the folded head: module path
+        if grad:
+            return _UNetFunction.apply(self, model, x, *p.params)
+        with torch.no_grad():
+            out, st = self._run_forward(model, x, features_only)
+        return out
+
+    def _run_forward(self, model, x, features_only=False):
+        p = self.program
+        cm = x.coordinate_manager
+        feats = ops._f32c(x.F, "features")
+        dev = feats.device
+        lib = ops._prep(dev)
+        training = bool(model.training)
+        cm.prebuild()
+        rows = [cm.size(s) for s in p.STRIDES]
+        if feats.shape[0] != rows[0]:
+            raise ValueError("%d feature rows for %d voxels" % (feats.shape[0], rows[0]))
+        grad = torch.is_grad_enabled()
+        self._plan_query(lib, rows, grad)
+        st = _PassState()
+        st.rows, st.training, st.feats, st.cm = rows, training, feats, cm
+        st.maps, keep_m = self._maps(cm, grad)
+        st.weights, keep_w = self._weights(cm, self._img)
+        st.bns = self._bns(training)
+        st.arena = torch.empty(int(self._plan.fwd_arena_bytes), dtype=torch.uint8, device=dev)
+        st.plan_fwd_bytes = int(self._plan.fwd_arena_bytes)
+        st.keep = (keep_m, keep_w)
+        ws = ops._ws(int(self._plan.ws_bytes), dev)
+        n_ops = len(p.ops)
+        end = n_ops - 1 if features_only else n_ops
+        out = None if features_only else torch.empty((rows[0], p.convs[-1].out_channels), dtype=torch.float32, device=dev)
+        run = _Run(_ptr(self._rows), _ptr(st.maps), _ptr(st.weights), _ptr(st.bns), feats.data_ptr(),
+                   out.data_ptr() if out is not None else None, None, st.arena.data_ptr(), st.arena.numel(), None, 0,
+                   ws.data_ptr(), ws.numel(), ops.tl_counters(dev).data_ptr(), int(training), 0, end, 0, self.prof)
+        with ops._Dev(dev):
+            check(lib.osn_net_forward(ctypes.addressof(self.desc), ctypes.addressof(run), ops._stream(dev)), "osn_net_forward")
+        if training:
+            torch._foreach_add_([m.bn.num_batches_tracked for m in p.bns], 1)
+        from . import functional as F_
+        if F_._relu_observer is not None:
+            for b in p.relu_bufs:
+                F_._relu_observer(self._view(st, b))
+        if features_only:
+            out = self._view(st, p.feature_buf)
+        return out, st
+
+    def _view(self, st, buf):
+        p = self.program
+        lvl, ch = p.bufs[buf]
+        n = st.rows[lvl]
+        off = int(self._y_off[buf])
+        return st.arena[off:off + n * ch * 4].view(torch.float32).view(n, ch)
+
+    def _run_backward(self, st, gout):
+        p = self.program
+        dev = gout.device
+        lib = ops._prep(dev)
+        gout = ops._f32c(gout, "grad_output")
+        self._plan_query(lib, st.rows, True)
+        if int(self._plan.fwd_arena_bytes) != st.plan_fwd_bytes:
+            raise RuntimeError("the executor's arena layout changed between a forward pass and its backward pass")
+        grads = torch.empty(self.grad_total, dtype=torch.float32, device=dev)
+        base = grads.data_ptr()
+        nc = len(p.convs)
+        st.weights["gW"] = base + 4 * np.asarray(self.grad_off[:nc], dtype=np.uint64)
+        if p.bns:
+            st.bns["ggamma"][:len(p.bns)] = base + 4 * np.asarray(self.grad_off[nc::2], dtype=np.uint64)
+            st.bns["gbeta"][:len(p.bns)] = base + 4 * np.asarray(self.grad_off[nc + 1::2], dtype=np.uint64)
+        barena = torch.empty(int(self._plan.bwd_arena_bytes), dtype=torch.uint8, device=dev)
+        ws = ops._ws(int(self._plan.ws_bytes), dev)
+        self._rows[:len(st.rows)] = st.rows
+        run = _Run(_ptr(self._rows), _ptr(st.maps), _ptr(st.weights), _ptr(st.bns), st.feats.data_ptr(), None, gout.data_ptr(),
+                   st.arena.data_ptr(), st.arena.numel(), barena.data_ptr(), barena.numel(), ws.data_ptr(), ws.numel(),
+                   ops.tl_counters(dev).data_ptr(), int(st.training), 0, len(p.ops), 0, self.prof)
+        with ops._Dev(dev):
+            check(lib.osn_net_backward(ctypes.addressof(self.desc), ctypes.addressof(run), ops._stream(dev)), "osn_net_backward")
+        return [grads[o:o + q.numel()].view_as(q) for o, q in zip(self.grad_off, p.params)]
+
+    def kernels(self, rows, training=True):
+        """[(op index, forward kernel, input-gradient kernel, weight-gradient kernel)] names for the given level sizes."""
+        self._plan_query(_lib.load(), rows, training)
+        return [(i, K_NAMES[int(self._kf[i])], K_NAMES[int(self._kd[i])], K_NAMES[int(self._kw[i])]) for i in range(len(self.program.ops))]
+
+
+class _UNetFunction(Function):
+    """The whole U-Net as ONE autograd node: forward = osn_net_forward, backward = osn_net_backward."""
+
+    @staticmethod
+    def forward(ctx, ex, model, x, *params):
+        out, st = ex._run_forward(model, x)
+        ctx.ex, ctx.st = ex, st
+        ctx.save_for_backward(*params)           # autograd's version check guards the weight images kept for the backward
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        _ = ctx.saved_tensors                    # raises if a parameter was modified in place since the forward pass
+        grads = ctx.ex._run_backward(ctx.st, gout)
+        ctx.st = None
+        return (None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:]))
+
+
+def for_model(model):
+    """The (cached) executor of a MinkUNetBase instance, or None when its tree is not compilable."""
+    ex = model.__dict__.get("_osn_executor", False)
+    if ex is False:
+        try:
+            ex = UNetExecutor(model)
+        except NotImplementedError:
+            ex = None
+        model.__dict__["_osn_executor"] = ex
+    return ex
