@@ -127,6 +127,115 @@ class LaunchProfiler:
         return groups
 
 
+class ExecProfiler:
+    """Launch timer of the network executor (osn_prof_*: HIP events recorded by the library on the launch stream around
+    the convolution launches of a pass).  Records carry the stage's shape and the kernel the library planned for it."""
+
+    PHASE = ("fwd", "dgrad", "wgrad")
+
+    def __init__(self, ex, capacity=16384):
+        import ctypes
+        from openscene_amd import _lib
+        self.ex, self.lib, self.ct = ex, _lib.load(), ctypes
+        self.handle = self.lib.osn_prof_create(capacity)
+        if not self.handle:
+            raise RuntimeError("osn_prof_create failed")
+        self.capacity = capacity
+        self._tags = (ctypes.c_int32 * capacity)()
+        self._ms = (ctypes.c_float * capacity)()
+        self._names = {}
+
+    def attach(self, on):
+        self.ex.prof = self.handle if on else None
+
+    def only(self, tags):
+        arr = (self.ct.c_int32 * max(len(tags), 1))(*tags)
+        self.lib.osn_prof_filter(self.handle, arr, len(tags))
+
+    def read(self):
+        n = self.lib.osn_prof_read(self.handle, self._tags, self._ms, self.capacity, 1)
+        return [(int(self._tags[i]) // 4, int(self._tags[i]) % 4, float(self._ms[i])) for i in range(n)]
+
+    def close(self):
+        self.ex.prof = None
+        self.lib.osn_prof_destroy(self.handle)
+        self.handle = None
+
+    def name_of(self, kernel, K, cin, cout, n_out):
+        """Kernel instance of a planned launch (template arguments as the library picks them)."""
+        key = (kernel, K, cin, cout, n_out)
+        n = self._names.get(key)
+        if n is None:
+            from openscene_amd import ops
+            if kernel == "x6":
+                wm, wn, tn, bk, S, wgs = ops.spconv_fwd_plan(n_out, K, cin, cout)
+                n = "spconv_fwd_x6_kernel<%d,%d,%d>" % (wm, wn, tn) + ("+reduce" if S > 1 else "")
+            elif kernel == "tl":
+                best, pad_best = 1, 1 << 30
+                for nw in (4, 3, 2, 1):                       # osn::tl_waves: least padding, wider on ties
+                    pd = -(-cout // (32 * nw)) * 32 * nw - cout
+                    if pd < pad_best:
+                        best, pad_best = nw, pd
+                n = "spconv_tl_kernel<%d>" % best
+            elif kernel == "wgrad_tl":
+                blk = lambda c: min((c + 31) // 32, 4)
+                n = "wgrad_tl_kernel<%d,%d>" % (blk(cin), blk(cout))
+            elif kernel == "stem":
+                n = "stem_fwd_kernel"
+            else:
+                pad = lambda c: min((c + 31) // 32 * 32, 128)
+                n = "spconv_wgrad_kernel<%d>" % (((pad(cin) // 32) * (pad(cout) // 32) + 3) // 4,)
+            self._names[key] = n
+        return n
+
+    def records_of_step(self, rows, map_pairs):
+        """[(shape key, tag, ms, algorithmic bytes, flops, meta)] of the pass(es) recorded since the last read.
+        rows: level sizes of the step; map_pairs[map index] = pairs of that map (exact, from the step's own maps)."""
+        ex = self.ex
+        kern = {i: (kf, kd, kw) for i, kf, kd, kw in ex.kernels(rows, training=True)}
+        out = []
+        for op, phase, ms in self.read():
+            o = ex.program.ops[op]
+            n_in, n_out = rows[o["lvl_in"]], rows[o["lvl_out"]]
+            K, cin, cout = o["K"], o["cin"], o["cout"]
+            pairs = n_out if K == 1 else map_pairs[o["map"]]
+            byts = 4.0 * (n_in * cin + n_out * cout + K * cin * cout) + (8.0 * pairs if K > 1 else 0.0)
+            flops = 2.0 * pairs * cin * cout
+            if phase == 1:          # input gradient = a convolution [n_out, cout] -> [n_in, cin]
+                name = self.name_of(kern[op][1], K, cout, cin, n_in)
+                meta = {"K": K, "cin": cout, "cout": cin, "n_in": n_out, "n_out": n_in, "level": o["lvl_in"]}
+            elif phase == 0:
+                name = self.name_of(kern[op][0], K, cin, cout, n_out)
+                meta = {"K": K, "cin": cin, "cout": cout, "n_in": n_in, "n_out": n_out, "level": o["lvl_out"]}
+            else:
+                name = self.name_of(kern[op][2], K, cin, cout, n_out)
+                meta = {"K": K, "cin": cin, "cout": cout, "n_in": n_in, "n_out": n_out, "level": o["lvl_out"]}
+            key = (name, meta["K"], meta["cin"], meta["cout"], meta["level"])
+            out.append((key, op * 4 + phase, ms, byts, flops, meta))
+        return out
+
+
+def exec_map_pairs(ex, cm):
+    """Pairs of every kernel map of the executor's program, counted on the step's OWN coordinate manager."""
+    res = {}
+    for i, (s_in, s_out, k, dil) in enumerate(ex.program.map_keys):
+        res[i] = int(cm.kmap_counts(s_in, s_out, k, dil).sum())
+    return res
+
+
+def group_records(recs, by_shape):
+    groups = {}
+    for key, tag, ms, byts, flops, meta in recs:
+        k = key if by_shape else key[0]
+        g = groups.setdefault(k, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0, "meta": meta, "tags": set()})
+        g["launches"] += 1
+        g["ms"] += ms
+        g["bytes"] += byts
+        g["flops"] += flops
+        g["tags"].add(tag)
+    return groups
+
+
 def build_scene(seed, device, n_pts=120000):
     from openscene_amd import synthetic as syn
     vox = syn.shuffled(syn.grid_voxels(syn.room_points(seed, n_pts=n_pts), 0.02), seed)
@@ -462,39 +571,84 @@ def main():
             torch.cuda.synchronize(device)
 
     pair_counts, sizes = all_pair_counts(coords0)
+    last = {}                                   # the coordinate manager of the most recent step (survey bookkeeping)
     for _ in range(args.warmup):
         step()
-    prof = LaunchProfiler()
-    survey = {}
-    survey_dom = None
-    if not args.no_kernel_events:
-        # untimed survey step: bracket every conv launch to find the dominant kernel instance;
-        # the timed region then brackets only that instance.  The survey needs a warm process (first steps grow the
-        # scratch pool, create the weight images and load kernel variants inside the brackets): at least three steps
-        # before it, whatever --warmup says
+    from openscene_amd import executor as _ex
+    ex = _ex.for_model(model.net3d) if _ex.ENABLED else None
+    prof = ExecProfiler(ex) if (ex is not None and not args.no_kernel_events and not prefetch) else None
+    legacy = LaunchProfiler() if (ex is None and not args.no_kernel_events) else None
+    survey_groups, survey_shapes, dom_key, dom_tags = {}, {}, None, []
+    N_SURVEY = 3
+    if prof is not None:
+        # untimed survey: N_SURVEY fully bracketed steps (every convolution launch of both passes), each counted with the
+        # pair numbers of ITS OWN maps; the dominant launch shape = the one with the largest summed time over these steps
+        # (stable across --steps / --warmup).  The timed region then brackets only that shape's launches.
         for _ in range(max(0, 3 - args.warmup)):
             step()
-        ops.set_profiler(prof)
-        prof.enabled = True
+        prof.attach(True)
+        prof.only([])
+        recs = []
+        real_prebuild = SparseTensor.__init__
+
+        def spy_init(self_, *a, **k):
+            real_prebuild(self_, *a, **k)
+            last["cm"] = self_.coordinate_manager
+        SparseTensor.__init__ = spy_init
+        try:
+            for _ in range(N_SURVEY):
+                step()
+                torch.cuda.synchronize(device)
+                cm_ = last["cm"]
+                rows_ = [cm_.size(s_) for s_ in (1, 2, 4, 8, 16)]
+                recs += prof.records_of_step(rows_, exec_map_pairs(ex, cm_))
+        finally:
+            SparseTensor.__init__ = real_prebuild
+        survey_groups = group_records(recs, by_shape=False)
+        survey_shapes = group_records(recs, by_shape=True)
+        if survey_shapes:
+            dom_key, d_g = max(survey_shapes.items(), key=lambda kv: kv[1]["ms"])
+            dom_tags = sorted(d_g["tags"])
+            prof.only(dom_tags)
+    elif legacy is not None:
+        for _ in range(max(0, 3 - args.warmup)):
+            step()
+        ops.set_profiler(legacy)
+        legacy.enabled = True
         step()
         torch.cuda.synchronize(device)
-        survey = prof.summarise(pair_counts)
-        shapes = prof.summarise(pair_counts, by_shape=True)
-        prof.records = []
+        survey_groups = legacy.summarise(pair_counts)
+        shapes = legacy.summarise(pair_counts, by_shape=True)
+        legacy.records = []
         if shapes:
-            # the dominant launch shape: one kernel instance on one (K, cin, cout, map) -- a well-defined launch whose
-            # algorithmic bytes / flops, duration and PMC traffic refer to the same thing
             (d_name, d_K, d_cin, d_cout, _), d_g = max(shapes.items(), key=lambda kv: kv[1]["ms"])
-            prof.only = (d_name, d_K, d_cin, d_cout, d_g["meta"]["n_out"])
-            survey_dom = (d_name, d_g)
+            legacy.only = (d_name, d_K, d_cin, d_cout, d_g["meta"]["n_out"])
+            dom_key = (d_name, d_K, d_cin, d_cout, 0)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     sync()
     dt = time.perf_counter() - t0
-    prof.enabled = False
-    ops.set_profiler(None)
+    timed_groups = None
+    if prof is not None:
+        prof.attach(False)
+        if dom_key is not None:
+            # pairs of the dominant shape: exact for level-0 shapes (translation invariant); a coarse level's table moves by a
+            # few rows with the per-step lattice shift, there the survey's pairs are scaled by the row count
+            timed = prof.records_of_step(sizes, {i: 0 for i in range(len(ex.program.map_keys))})
+            ref = survey_shapes[dom_key]
+            per_launch_b, per_launch_f = ref["bytes"] / ref["launches"], ref["flops"] / ref["launches"]
+            g = {"launches": len(timed), "ms": sum(r[2] for r in timed), "bytes": per_launch_b * len(timed),
+                 "flops": per_launch_f * len(timed), "meta": ref["meta"]}
+            if g["launches"]:
+                timed_groups = {dom_key[0]: g}
+        prof.close()
+    elif legacy is not None:
+        legacy.enabled = False
+        ops.set_profiler(None)
+        if legacy.records:
+            timed_groups = legacy.summarise(pair_counts)
 
     tt = torch.tensor([dt, float(n_vox)], dtype=torch.float64, device=device)
     if dist_on:
@@ -730,27 +884,23 @@ def main():
             dist.destroy_process_group()
         return
 
-    if os.environ.get("OSN_BENCH_DEBUG") == "1":
-        print("debug: records %d only %r survey %d" % (len(prof.records), prof.only, len(survey)), file=sys.stderr)
     step_bytes, step_flops = step_algorithmic_bytes(model, sizes, pair_counts)
     ms_per_step = dt_max * 1e3 / args.steps
     roofline = None
     kernels = {}
-    for name, gk in survey.items():          # one untimed, fully bracketed step (context for the roofline entry)
-        kernels[name] = {"launches_per_step": gk["launches"], "ms_per_step": gk["ms"],
+    n_sv = N_SURVEY if survey_shapes else 1
+    for name, gk in survey_groups.items():          # untimed, fully bracketed survey steps (context for the roofline entry)
+        if gk["ms"] <= 0:
+            continue
+        kernels[name] = {"launches_per_step": gk["launches"] / float(n_sv), "ms_per_step": gk["ms"] / n_sv,
                          "avg_us": 1e3 * gk["ms"] / gk["launches"],
                          "GBps": gk["bytes"] / (gk["ms"] * 1e-3) / 1e9,
                          "TFLOPs": gk["flops"] / (gk["ms"] * 1e-3) / 1e12}
     n_steps_rf = args.steps
-    if not prof.records and survey_dom is not None:
-        # the dominant shape of the survey step did not recur in the timed steps (a coarse level whose size moved with the
-        # per-step lattice shift): fall back to the survey step's own bracketed launches
-        groups = {survey_dom[0]: survey_dom[1]}
-        n_steps_rf = 1
-    elif prof.records:
-        groups = prof.summarise(pair_counts)
-    else:
-        groups = None
+    groups = timed_groups
+    if not groups and dom_key is not None and survey_shapes.get(dom_key):
+        groups = {dom_key[0]: survey_shapes[dom_key]}        # no bracketed launch in the timed steps: the survey's own
+        n_steps_rf = n_sv
     if groups:
         dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
         name, gk = dom
@@ -770,9 +920,11 @@ def main():
         t_mfma = gk["flops"] / (mfma_peak * 1e12)
         common = {"kernel": name,
                   "shape": {"K": dm["K"], "cin": dm["cin"], "cout": dm["cout"], "n_in": dm["n_in"], "n_out": dm["n_out"]},
+                  "selection": "largest summed time over %d fully bracketed survey steps; the timed region brackets only this "
+                               "shape's launches (HIP events recorded by the library on the launch stream)" % n_sv,
                   "traffic": (pmc or {}).get("hbm_bytes"), "traffic_unit": "bytes per launch (PMC, profiles/pmc_traffic.json)",
                   "traffic_detail": pmc,
-                  "avg_launch_us": 1e3 * gk["ms"] / gk["launches"], "launches_per_step": gk["launches"] / n_steps_rf,
+                  "avg_launch_us": 1e3 * gk["ms"] / gk["launches"], "launches_per_step": gk["launches"] / float(n_steps_rf),
                   "bytes_per_launch": gk["bytes"] / gk["launches"], "flops_per_launch": gk["flops"] / gk["launches"],
                   "flop_per_byte": gk["flops"] / gk["bytes"], "ridge_flop_per_byte": mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9),
                   "hbm_GBps": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
@@ -780,6 +932,7 @@ def main():
                   "mfma_peak_note": ("dense bf16 peak / 6 (six bf16 MFMAs per fp32-equivalent product)"
                                      if ("x6" in name or "_tl_" in name) else "fp32 MFMA peak"),
                   "step_hbm_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "step_mfma_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / X6_PEAK_TFLOPS,
                   "step_fp32_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
         if t_mfma >= t_hbm:
             roofline = dict({"bound": "mfma", "achieved": tflops, "peak": mfma_peak, "unit": "TFLOP/s",
@@ -815,6 +968,7 @@ def main():
                    "step_algorithmic_GB": step_bytes / 1e9, "step_GFLOP": step_flops / 1e9},
         "query": qres, "voxelizer": vox_res, "phases": extra, "roofline": roofline, "cpu_baseline": cpu, "comm": comm,
         "kernels": kernels, "loss": float(loss.detach()),
+        "host_path": "network executor (one C call per forward / backward pass)" if ex is not None else "per-module (Python autograd)",
     }
     print(json.dumps(line))
     if dist_on:

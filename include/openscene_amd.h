@@ -488,10 +488,11 @@ int osn_net_backward(const osn_net_desc* net, const osn_net_run* run, osn_stream
 
 /* Launch timer for the executor (bench.py's roofline entry): HIP events recorded on the launch stream around the
  * convolution launches of selected stages.  tag = op * 4 + phase (0 forward, 1 input gradient, 2 weight gradient).
- * filter_op < 0 brackets every stage.  osn_prof_read synchronises the events and returns the number of records.   */
+ * osn_prof_filter: bracket only the listed tags (HOST array; n_tags = 0: every launch).  osn_prof_read synchronises
+ * the events and returns the number of records (tags / ms: HOST arrays of `capacity` entries).                     */
 osn_prof_t* osn_prof_create(int capacity);
 void osn_prof_destroy(osn_prof_t* p);
-int osn_prof_filter(osn_prof_t* p, int filter_op, int filter_phase);
+int osn_prof_filter(osn_prof_t* p, const int32_t* tags, int n_tags);
 int osn_prof_read(osn_prof_t* p, int32_t* tags, float* ms, int capacity, int reset);
 
 #ifdef __cplusplus

@@ -69,7 +69,7 @@ PROTOTYPES = {
     "osn_net_backward": (_i32, [_vp, _vp, _vp]),
     "osn_prof_create": (_vp, [_i32]),
     "osn_prof_destroy": (None, [_vp]),
-    "osn_prof_filter": (_i32, [_vp, _i32, _i32]),
+    "osn_prof_filter": (_i32, [_vp, _vp, _i32]),
     "osn_prof_read": (_i32, [_vp, _vp, _vp, _i32, _i32]),
     "osn_relu_fwd": (_i32, [_vp, _vp, _i64, _vp]),
     "osn_relu_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp]),

@@ -18,7 +18,8 @@ constexpr uint64_t NO_OFF = ~uint64_t(0);
 struct Prof {
     std::vector<hipEvent_t> ev;        // 2 per record
     std::vector<int32_t> tag;
-    int cap = 0, n = 0, filter_op = -1, filter_phase = -1;
+    std::vector<int32_t> only;         // tags to bracket; empty = every launch
+    int cap = 0, n = 0;
 };
 
 static inline uint64_t up256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
@@ -158,7 +159,11 @@ struct Bracket {
     int slot;
     Bracket(osn_prof_t* prof, int op, int phase, hipStream_t s) : p(reinterpret_cast<Prof*>(prof)), st(s), slot(-1) {
         if (!p || p->n >= p->cap) return;
-        if (p->filter_op >= 0 && (p->filter_op != op || (p->filter_phase >= 0 && p->filter_phase != phase))) return;
+        if (!p->only.empty()) {
+            bool hit = false;
+            for (int32_t t : p->only) hit = hit || t == op * 4 + phase;
+            if (!hit) return;
+        }
         slot = p->n++;
         p->tag[slot] = op * 4 + phase;
         (void)hipEventRecord(p->ev[2 * slot], st);
@@ -424,11 +429,10 @@ extern "C" void osn_prof_destroy(osn_prof_t* h) {
     delete p;
 }
 
-extern "C" int osn_prof_filter(osn_prof_t* h, int filter_op, int filter_phase) {
+extern "C" int osn_prof_filter(osn_prof_t* h, const int32_t* tags, int n_tags) {
     Prof* p = reinterpret_cast<Prof*>(h);
-    OSN_REQUIRE(p, OSN_E_ARG, "osn_prof_filter: null handle");
-    p->filter_op = filter_op;
-    p->filter_phase = filter_phase;
+    OSN_REQUIRE(p && n_tags >= 0 && (n_tags == 0 || tags), OSN_E_ARG, "osn_prof_filter: bad arguments");
+    p->only.assign(tags, tags + n_tags);
     return OSN_OK;
 }
 

@@ -21,6 +21,7 @@ from . import _lib, ops
 from ._lib import check
 
 ENABLED = os.environ.get("OSN_EXECUTOR", "1") != "0"
+_DRY_RUN = False        # tools/dryrun only: accept host tensors (a null HIP runtime logs the launches instead of running them)
 
 _OP = np.dtype([(n, "<i4") for n in ("K", "cin", "cout", "lvl_in", "lvl_out", "map", "transposed", "src", "dst", "bn", "relu",
                                      "res", "copy_buf", "copy_col", "weight", "need_dgrad")])
@@ -95,6 +96,9 @@ class Program:
         self.feature_buf = x
         self._stage(model.final, None, x, 0, 0, relu=False)
         self.n_levels = 5
+        # maps that some tile-list-eligible convolution runs on get tile / pair lists (the 3-channel stem's 5^3 map does not)
+        self.map_lists = [any(o["map"] == mi and ops.tl_eligible(o["K"], o["cin"], o["cout"]) for o in self.ops)
+                          for mi in range(len(self.map_keys))]
         self.op_arr = np.zeros(len(self.ops), dtype=_OP)
         for i, o in enumerate(self.ops):
             self.op_arr[i] = tuple(o[n] for n in _OP.names)
@@ -188,7 +192,7 @@ class UNetExecutor:
         if not ENABLED or F_.CONV_MODE != "tl":
             return False
         f = x.F
-        if not (f.is_cuda and f.dtype == torch.float32 and x.tensor_stride == 1):
+        if not ((f.is_cuda or _DRY_RUN) and f.dtype == torch.float32 and x.tensor_stride == 1):
             return False
         p = self.program
         if f.shape[1] != p.convs[0].in_channels:
@@ -216,10 +220,7 @@ class UNetExecutor:
             fwd, bwd, flip = cm.kmap(s_in, s_out, k, dil)
             tf, tb = cm.kmap_tiles(s_in, s_out, k, dil)
             counts = cm.kmap_counts(s_in, s_out, k, dil)
-            lf = lb = None
-            if ops.tl_eligible(k ** 3, 8, 8):                       # K <= 128: every map but none is excluded; channel test per op
-                lists = cm.kmap_lists(s_in, s_out, k, dil) if k ** 3 <= 32 else (None, None)
-                lf, lb = lists
+            lf, lb = cm.kmap_lists(s_in, s_out, k, dil) if p.map_lists[i] else (None, None)
             a = arr[i]
             a["nbr_fwd"], a["nbr_bwd"], a["flip"], a["K"] = dp(fwd), dp(bwd), int(bool(flip)), k ** 3
             if tf is not None:
@@ -283,7 +284,7 @@ class UNetExecutor:
             out, st = self._run_forward(model, x, features_only)
         return out
 
-    def _run_forward(self, model, x, features_only=False):
+    def _run_forward(self, model, x, features_only=False, grad=False):
         p = self.program
         cm = x.coordinate_manager
         feats = ops._f32c(x.F, "features")
@@ -294,8 +295,7 @@ class UNetExecutor:
         rows = [cm.size(s) for s in p.STRIDES]
         if feats.shape[0] != rows[0]:
             raise ValueError("%d feature rows for %d voxels" % (feats.shape[0], rows[0]))
-        grad = torch.is_grad_enabled()
-        self._plan_query(lib, rows, grad)
+        self._plan_query(lib, rows, grad)        # grad: a backward pass will follow (its images and pair lists are prepared now)
         st = _PassState()
         st.rows, st.training, st.feats, st.cm = rows, training, feats, cm
         st.maps, keep_m = self._maps(cm, grad)
@@ -366,7 +366,7 @@ class _UNetFunction(Function):
 
     @staticmethod
     def forward(ctx, ex, model, x, *params):
-        out, st = ex._run_forward(model, x)
+        out, st = ex._run_forward(model, x, grad=True)
         ctx.ex, ctx.st = ex, st
         ctx.save_for_backward(*params)           # autograd's version check guards the weight images kept for the backward
         return out

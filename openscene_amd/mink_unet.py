@@ -11,6 +11,7 @@ BN/ReLU kernel pass, residual blocks fuse BN + add + ReLU.
 """
 import torch.nn as nn
 
+from . import executor
 from . import functional as F_
 from . import minkowski as ME
 from .minkowski import BasicBlock
@@ -85,12 +86,22 @@ class MinkUNetBase(nn.Module):
         return y._like(F_.batch_norm_act(y.F, norm.bn, relu=True))
 
     def forward(self, x):
+        # one C call per pass (openscene_amd/executor.py) when the configuration allows it; otherwise -- and for the
+        # reference's own models/mink_unet.py running through the MinkowskiEngine alias -- module by module
+        ex = executor.for_model(self)
+        if ex is not None and ex.usable(x):
+            return ex.forward(self, x)
         with F_.deferred_bn_counters():
             return self.final(self._forward(x)).F
 
     def forward_features(self, x):
         """The input of the final 1x1 convolution (float32 [N_0, PLANES[7]], input row order): what
         ``openscene_amd.query.query_distill_fused`` folds the head into."""
+        ex = executor.for_model(self)
+        if ex is not None and ex.usable(x):
+            out = ex.forward(self, x, features_only=True)
+            if out is not None:
+                return out
         with F_.deferred_bn_counters():
             return self._forward(x).F
 

@@ -549,6 +549,15 @@ def weight_image(weight, flip=False, for_dgrad=False, layout=PREP_X6):
 _tl_counters = {}
 
 
+def tl_counters(dev):
+    """The 128 persistent tile counters of (device, current stream): zero once, the tile-list kernel leaves them zero."""
+    ck = (_idx(dev), _stream(dev))
+    c = _tl_counters.get(ck)
+    if c is None:
+        c = _tl_counters[ck] = torch.zeros(128, dtype=torch.int32, device=dev)
+    return c
+
+
 def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
     """out[o] = sum_k feats[list rows] @ B[k] with B given as a weight_prep_tl image; tl None <=> K == 1 identity.
     bn_partial: optional float64 [n_tiles, 2, cout] receiving per-tile column sums / sums of squares."""

@@ -1,0 +1,112 @@
+"""Network executor (csrc/net.hip, openscene_amd/executor.py), checked WITHOUT a GPU:
+  * the stage program compiled from each MinkUNet variant covers the module tree (one stage per convolution, one
+    producer per buffer, ME.cat buffers fully written by their two producers) and the library accepts it;
+  * the C side plans the same kernels the per-module path picks (functional.py), for the S100k level sizes;
+  * DRY RUN: with a null HIP runtime linked in (tools/dryrun), one training step through the executor issues exactly
+    the convolution and batch-norm launches (kernel instance + grid) the per-module path issues."""
+import collections
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+S100K = [100999, 47618, 12868, 3052, 700]
+
+
+@pytest.mark.parametrize("arch", ["MinkUNet14A", "MinkUNet18A", "MinkUNet18D", "MinkUNet34A", "MinkUNet34C"])
+def test_program_covers_the_module_tree(arch):
+    import __graft_entry__ as ge
+    ge.build()
+    from openscene_amd import executor as E
+    from openscene_amd import minkowski as ME
+    from openscene_amd.mink_unet import mink_unet
+    model = mink_unet(3, 768, 3, arch)
+    ex = E.for_model(model)
+    assert ex is not None
+    p = ex.program
+    convs = [m for m in model.modules() if isinstance(m, ME.MinkowskiConvolutionBase)]
+    norms = [m for m in model.modules() if isinstance(m, ME.MinkowskiBatchNorm)]
+    assert len(p.ops) == len(convs) and set(map(id, p.convs)) == set(map(id, convs))
+    assert len(p.bns) == len(norms) and set(map(id, p.bns)) == set(map(id, norms))
+    assert {id(q) for q in p.params} == {id(q) for q in model.parameters()}
+    producers = collections.Counter(o["dst"] for o in p.ops if o["dst"] >= 0)
+    assert all(v == 1 for v in producers.values())
+    # every ME.cat buffer (never a dst) is written column-complete by exactly two second stores: [up-branch | skip]
+    cats = set(range(len(p.bufs))) - set(producers)
+    assert len(cats) == 4
+    for c in cats:
+        parts = sorted((o["copy_col"], o["cout"], o["transposed"]) for o in p.ops if o["copy_buf"] == c)
+        assert len(parts) == 2 and parts[0][0] == 0 and parts[0][2] == 1                 # the transposed conv's half first
+        assert parts[0][1] == parts[1][0] and parts[1][0] + parts[1][1] == p.bufs[c][1]
+        readers = [o for o in p.ops if o["src"] == c]
+        assert len(readers) == 2 and {o["K"] for o in readers} == {27, 1}                  # conv1 and the 1x1 shortcut
+    # every buffer that is read has a producer or is a cat buffer; residuals are row-aligned with their stage
+    for o in p.ops:
+        for b in (o["src"], o["res"]):
+            assert b == -1 or b in producers or b in cats
+    assert p.ops[-1]["dst"] == -1 and p.ops[-1]["K"] == 1 and p.ops[0]["src"] == -1 and p.ops[0]["need_dgrad"] == 0
+    # the library accepts the program and plans every stage
+    ks = ex.kernels(S100K, training=True)
+    assert len(ks) == len(p.ops) and all(k[1] != "none" and k[3] != "none" for k in ks)
+    assert ks[0][1:] == ("stem", "none", "wgrad")
+    assert int(ex._plan.fwd_arena_bytes) > 4 * S100K[0] * 96 * 10
+
+
+def test_planned_kernels_are_the_per_module_choice():
+    """functional.SparseConvFunction's dispatch, restated: tile-list kernels from TL_FWD_MIN_ROWS table rows on, the
+    split-bf16 output-stationary kernel below, the stem kernel for 3 -> 32, pair-array weight gradient on every
+    3^3 / 2^3 map, the table weight gradient for the stem and the 1x1 convs."""
+    from openscene_amd import executor as E
+    from openscene_amd import functional as F_
+    from openscene_amd.mink_unet import mink_unet
+    ex = E.for_model(mink_unet(3, 768, 3, "MinkUNet18A"))
+    ks = ex.kernels(S100K, training=True)
+    for (i, kf, kd, kw), o in zip(ks, ex.program.ops):
+        n_in, n_out = S100K[o["lvl_in"]], S100K[o["lvl_out"]]
+        if o["K"] == 125:
+            continue
+        want_f = "tl" if (o["K"] > 1 and n_out >= F_.TL_FWD_MIN_ROWS) else "x6"
+        want_d = "tl" if (o["K"] > 1 and n_in >= F_.TL_FWD_MIN_ROWS) else "x6"
+        assert (kf, kd) == (want_f, want_d), (i, o, kf, kd)
+        assert kw == ("wgrad_tl" if o["K"] > 1 else "wgrad")
+    assert sum(k[1] == "tl" for k in ks) == 5 and sum(k[2] == "tl" for k in ks) == 5      # the 10 tile-list launches of a step
+
+
+def test_executor_is_not_used_outside_its_configuration(monkeypatch):
+    from openscene_amd import executor as E
+    from openscene_amd import functional as F_
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import SparseTensor
+
+    class FakeX:
+        tensor_stride = 1
+        F = torch.ones(5, 3)
+    ex = E.for_model(mink_unet(3, 20, 3, "MinkUNet14A"))
+    assert not ex.usable(FakeX())                       # host tensor: the executor (like every op) needs device memory
+    monkeypatch.setattr(E, "_DRY_RUN", True)
+    assert ex.usable(FakeX())
+    monkeypatch.setattr(F_, "CONV_MODE", "fp32")
+    assert not ex.usable(FakeX())
+    monkeypatch.setattr(F_, "CONV_MODE", "tl")
+    monkeypatch.setattr(E, "ENABLED", False)
+    assert not ex.usable(FakeX())
+
+
+@pytest.mark.parametrize("arch", ["MinkUNet18A", "MinkUNet34C"])
+def test_dry_run_executor_issues_the_launches_of_the_module_path(arch, monkeypatch):
+    sys.path.insert(0, os.path.join(ROOT, "tools", "dryrun"))
+    import dry_step
+    lib = dry_step.install(dry_step.build_dry_lib(), monkeypatch.setattr)
+    logs, _step, sizes = dry_step.step_logs(lib, arch, points=12000, setattr_=monkeypatch.setattr)
+    assert sizes[0] > 6000
+    a, b = dry_step.conv_launches(logs["modules"]), dry_step.conv_launches(logs["executor"])
+    assert len(a) > 100 and collections.Counter(a) == collections.Counter(b)
+    assert any("spconv_tl_kernel" in l for l in b) and any("wgrad_tl_kernel" in l for l in b) and any("stem_fwd" in l for l in b)
+    assert collections.Counter(dry_step.bn_launches(logs["modules"])) == collections.Counter(dry_step.bn_launches(logs["executor"]))
+    # same order up to the first BasicBlock shortcut (the executor issues a block's 1x1 shortcut before its second conv)
+    assert a[:5] == b[:5]
+    # what the executor does NOT launch: the elementwise add / cat kernels of the module path
+    assert "cat2_kernel" in logs["modules"] and "cat2_kernel" not in logs["executor"]

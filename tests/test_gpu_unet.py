@@ -29,24 +29,25 @@ def rel_l2(got, ref):
 
 
 class record_relu_masks:
-    """Record (y > 0) of every fused BN(+residual)+ReLU call, in call order (= the oracle's ReLU order)."""
+    """Record (y > 0) of every fused BN(+residual)+ReLU, in call order (= the oracle's ReLU order), through the
+    observer hook both the per-module path and the network executor honour."""
 
     def __init__(self):
         from openscene_amd import functional as F_
         self.F_ = F_
-        self.real = F_.batch_norm_act
         self.masks = []
-
-        def spy(x, bn, residual=None, relu=False):
-            y = self.real(x, bn, residual=residual, relu=relu)
-            if relu:
-                self.masks.append((y.detach() > 0).cpu())
-            return y
-        F_.batch_norm_act = spy
+        F_.set_relu_observer(lambda y: self.masks.append((y.detach() > 0).cpu()))
 
     def stop(self):
-        self.F_.batch_norm_act = self.real
+        self.F_.set_relu_observer(None)
         return self.masks
+
+
+@pytest.fixture
+def modules_only(monkeypatch):
+    """Run the model module by module (minkowski.py / functional.py), not through the network executor."""
+    from openscene_amd import executor
+    monkeypatch.setattr(executor, "ENABLED", False)
 
 
 def scene_coords(seed, n_pts, voxel, batch=1):
@@ -54,11 +55,17 @@ def scene_coords(seed, n_pts, voxel, batch=1):
                              for b in range(batch)])
 
 
-@pytest.mark.parametrize("arch,out_dim,train", [("MinkUNet14A", 16, True), ("MinkUNet18A", 20, False),
-                                                ("MinkUNet18A", 64, True), ("MinkUNet34C", 32, True)])
-def test_unet_vs_oracle(arch, out_dim, train):
+@pytest.mark.parametrize("arch,out_dim,train,path", [("MinkUNet14A", 16, True, "executor"), ("MinkUNet18A", 20, False, "executor"),
+                                                     ("MinkUNet18A", 64, True, "executor"), ("MinkUNet34C", 32, True, "executor"),
+                                                     ("MinkUNet14A", 16, True, "modules"), ("MinkUNet18A", 20, False, "modules"),
+                                                     ("MinkUNet18A", 64, True, "modules")])
+def test_unet_vs_oracle(arch, out_dim, train, path, monkeypatch):
+    """Both host paths: the network executor (one C call per pass, the default) and the per-module path (the surface
+    the reference's own models/mink_unet.py runs on)."""
+    from openscene_amd import executor
     from openscene_amd.mink_unet import mink_unet
     from openscene_amd.sparse import SparseTensor
+    monkeypatch.setattr(executor, "ENABLED", path == "executor")
     torch.manual_seed(7)
     model = mink_unet(3, out_dim, 3, arch)
     for m in model.modules():
@@ -138,6 +145,72 @@ def test_disnet_distill_step_and_row_order():
     grads = [p.grad for p in net.parameters()]
     assert all(g is not None and torch.isfinite(g).all().item() for g in grads)
     assert sum(float(g.abs().sum()) for g in grads) > 0
+
+
+def test_executor_equals_the_module_path(monkeypatch):
+    """The executor plays the same kernels in the same order as the per-module path: forward outputs, feature taps and
+    running statistics are BITWISE equal, in training and in evaluation mode; parameter gradients agree to fp32
+    round-off (sums of three gradient sources are associated in consumer order instead of autograd's order)."""
+    from openscene_amd import executor
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import SparseTensor
+    d = dev()
+    coords = torch.from_numpy(scene_coords(51, 30000, 0.03, batch=2)).to(d)
+    feats = torch.rand(coords.shape[0], 3, device=d)
+    target = torch.randn(coords.shape[0], 48, device=d)
+    results = {}
+    for path in ("modules", "executor"):
+        monkeypatch.setattr(executor, "ENABLED", path == "executor")
+        torch.manual_seed(9)
+        model = mink_unet(3, 48, 3, "MinkUNet18A").to(d).train()
+        used = []
+        real = executor.UNetExecutor._run_forward
+        monkeypatch.setattr(executor.UNetExecutor, "_run_forward", lambda self, *a, **k: (used.append(1), real(self, *a, **k))[1])
+        out = model(SparseTensor(feats, coords))
+        (out * target).sum().backward()
+        grads = {n: q.grad.clone() for n, q in model.named_parameters()}
+        bufs = {n: b.clone() for n, b in model.named_buffers()}
+        model.eval()
+        with torch.no_grad():
+            ev = model(SparseTensor(feats, coords))
+            ft = model.forward_features(SparseTensor(feats, coords)).clone()
+        monkeypatch.setattr(executor.UNetExecutor, "_run_forward", real)
+        assert bool(used) == (path == "executor")
+        results[path] = (out.detach().clone(), ev.clone(), ft, grads, bufs)
+    a, b = results["modules"], results["executor"]
+    assert torch.equal(a[0], b[0]), "training-mode forward differs"
+    assert torch.equal(a[1], b[1]), "evaluation-mode forward differs"
+    assert torch.equal(a[2], b[2]), "forward_features differs"
+    for n in a[4]:
+        assert torch.equal(a[4][n], b[4][n]), n
+    worst = max(rel_l2(b[3][n], a[3][n]) for n in a[3])
+    assert worst <= 2e-6, "worst parameter-gradient difference between the two host paths: %.3e" % worst
+
+
+def test_executor_with_frozen_and_eval_mode_gradients():
+    """A frozen parameter gets no gradient; evaluation-mode BN (running statistics) inside a graph that needs gradients
+    back-propagates through the executor like the module path does."""
+    from openscene_amd import executor
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import SparseTensor
+    d = dev()
+    coords = torch.from_numpy(scene_coords(52, 8000, 0.04)).to(d)
+    feats = torch.rand(coords.shape[0], 3, device=d)
+    got = {}
+    for on in (False, True):
+        executor.ENABLED = on
+        try:
+            torch.manual_seed(3)
+            model = mink_unet(3, 16, 3, "MinkUNet14A").to(d).eval()
+            model.block2[0].conv1.kernel.requires_grad_(False)
+            out = model(SparseTensor(feats, coords))
+            out.square().mean().backward()
+            assert model.block2[0].conv1.kernel.grad is None
+            got[on] = {n: q.grad.clone() for n, q in model.named_parameters() if q.grad is not None}
+        finally:
+            executor.ENABLED = True
+    assert got[False].keys() == got[True].keys() and len(got[True]) > 50
+    assert max(rel_l2(got[True][n], got[False][n]) for n in got[True]) <= 2e-6
 
 
 def test_unfused_module_chain_equals_fused():
@@ -229,7 +302,7 @@ def test_prefetched_maps_give_the_same_step():
             assert torch.equal(a, b)
 
 
-def test_wgrad_on_the_auxiliary_stream_and_cached_weight_images_change_nothing(monkeypatch):
+def test_wgrad_on_the_auxiliary_stream_and_cached_weight_images_change_nothing(monkeypatch, modules_only):
     """The backward of a convolution on a small map forks the weight gradient onto an auxiliary stream and joins before
     it returns; weight images of parameters come from a per-device cache refreshed once per optimizer step.  Both are
     pure scheduling: two optimizer steps with them on must be bitwise identical to two steps with them off."""
