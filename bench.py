@@ -579,6 +579,7 @@ def main():
     prof = ExecProfiler(ex) if (ex is not None and not args.no_kernel_events and not prefetch) else None
     legacy = LaunchProfiler() if (ex is None and not args.no_kernel_events) else None
     survey_groups, survey_shapes, dom_key, dom_tags = {}, {}, None, []
+    stages = None
     N_SURVEY = 3
     if prof is not None:
         # untimed survey: N_SURVEY fully bracketed steps (every convolution launch of both passes), each counted with the
@@ -606,6 +607,16 @@ def main():
             SparseTensor.__init__ = real_prebuild
         survey_groups = group_records(recs, by_shape=False)
         survey_shapes = group_records(recs, by_shape=True)
+        # per stage and pass: mean duration of its convolution launch over the survey steps (where the step's time goes)
+        per_tag = {}
+        for key, tag, ms, byts, flops, meta in recs:
+            e = per_tag.setdefault(tag, {"us": 0.0, "n": 0, "kernel": key[0], "K": meta["K"], "cin": meta["cin"], "cout": meta["cout"],
+                                         "rows": meta["n_out"], "GFLOP": flops / 1e9})
+            e["us"] += 1e3 * ms
+            e["n"] += 1
+        stages = [dict(op=t // 4, phase=ExecProfiler.PHASE[t % 4], us=round(e["us"] / e["n"], 1), kernel=e["kernel"], K=e["K"],
+                       cin=e["cin"], cout=e["cout"], rows=e["rows"], TFLOPs=round(e["GFLOP"] / (e["us"] / e["n"]) * 1e3, 1))
+                  for t, e in sorted(per_tag.items())]
         if survey_shapes:
             dom_key, d_g = max(survey_shapes.items(), key=lambda kv: kv[1]["ms"])
             dom_tags = sorted(d_g["tags"])
@@ -967,7 +978,7 @@ def main():
                    "level_sizes": sizes, "parallelism": "dp%d" % world,
                    "step_algorithmic_GB": step_bytes / 1e9, "step_GFLOP": step_flops / 1e9},
         "query": qres, "voxelizer": vox_res, "phases": extra, "roofline": roofline, "cpu_baseline": cpu, "comm": comm,
-        "kernels": kernels, "loss": float(loss.detach()),
+        "kernels": kernels, "stages": stages, "loss": float(loss.detach()),
         "host_path": "network executor (one C call per forward / backward pass)" if ex is not None else "per-module (Python autograd)",
     }
     print(json.dumps(line))

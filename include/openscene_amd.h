@@ -254,6 +254,22 @@ size_t osn_spconv_wgrad_tl_ws_bytes(int K, int cin, int cout);
 int osn_spconv_wgrad_tl(const float* in, const float* gout, const void* pl, int swap, float* gW, int64_t n_in,
                         int64_t n_out, int K, int cin, int cout, void* ws, size_t ws_bytes, osn_stream_t stream);
 
+/* The two halves of osn_spconv_wgrad_tl for callers that run many weight gradients back to back (the network executor):
+ * osn_spconv_wgrad_tl_partial launches the kernel only -- partial sums per work item into `partial`
+ * (osn_spconv_wgrad_tl_ws_bytes bytes, must stay untouched until the reduction ran) -- and fills `job` (HOST);
+ * osn_wgrad_tl_reduce_batch reduces any number of such jobs in ONE launch per 32 jobs (same summation order as
+ * osn_spconv_wgrad_tl: bitwise the same gradient).  A job whose gW is null (empty map: gW was zeroed) is skipped.  */
+typedef struct osn_wgrad_job {
+    const float* partial;        /* device */
+    const void* range;           /* device: items of each offset, or null (identity map: items [0, ident_items))     */
+    float* gW;                   /* device, [K, cin, cout]                                                         */
+    int32_t K, cin, cout, ident_items;
+} osn_wgrad_job;                 /* 40 bytes */
+int osn_spconv_wgrad_tl_partial(const float* in, const float* gout, const void* pl, int swap, float* gW, int64_t n_in,
+                                int64_t n_out, int K, int cin, int cout, void* partial, size_t partial_bytes,
+                                osn_wgrad_job* job_host, osn_stream_t stream);
+int osn_wgrad_tl_reduce_batch(const osn_wgrad_job* jobs_host, int n_jobs, osn_stream_t stream);
+
 /* The 3-channel stem convolution (conv0p1s1: 5^3 kernel, 3 -> 32, models/mink_unet.py:47-50): same contract as
  * osn_spconv_fwd on the plain (unordered) table, exact fp32 FMA chain in ascending offset order, for cin <= 4
  * and cout == 32 (no contraction worth a matrix unit; the op streams the 125 x n_out table once).            */
@@ -297,6 +313,12 @@ int osn_bn_backward(const float* x, const float* y, const float* gy, const float
 int osn_bn_apply2(const float* x, const float* mean, const float* var, const float* gamma,
                   const float* beta, float eps, const float* residual, int relu, float* y,
                   float* y2, int64_t ld2, int64_t n, int c, osn_stream_t stream);
+/* osn_bn_forward_train with the second destination of osn_bn_apply2.  Maps of at most 4096 rows (the deep U-Net levels)
+ * run as ONE launch (statistics and apply from registers); osn_bn_forward_train / osn_bn_backward[_multi] do the same. */
+int osn_bn_forward_train2(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
+                          const float* residual, int relu, float momentum, float* mean, float* var,
+                          float* running_mean, float* running_var, float* y, float* y2, int64_t ld2,
+                          void* ws, size_t ws_bytes, osn_stream_t stream);
 /* osn_bn_backward whose incoming gradient is the SUM of n_gy (1..3) row-aligned matrices, each with its own row
  * stride (HOST arrays of device pointers / strides in floats): a block input feeds conv1 and the residual, an encoder
  * output feeds the next stride-2 convolution and -- through ME.cat -- two convolutions of the decoder
@@ -426,7 +448,7 @@ typedef struct osn_net_buf { int32_t level, channels; } osn_net_buf;
 typedef struct osn_net_desc {
     int32_t n_ops, n_bufs, n_bns, n_weights, n_maps, n_levels;
     int32_t tl_min_rows;         /* tile-list forward / input gradient on tables of at least this many rows       */
-    int32_t bn_small_rows;       /* single-launch batch norm up to this many rows (0 = never)                     */
+    int32_t tl_small_rows;       /* ... and on tables of at most this many rows (0 = never): the deep U-Net levels       */
     const osn_net_op* ops;
     const osn_net_buf* bufs;
 } osn_net_desc;
@@ -465,6 +487,7 @@ typedef struct osn_net_bn {
     float eps, momentum;
 } osn_net_bn;
 typedef struct osn_prof osn_prof_t;           /* optional launch timer, see osn_prof_create                       */
+typedef struct osn_events osn_events_t;       /* pool of HIP events for the fork / join of the backward pass      */
 typedef struct osn_net_run {
     const int64_t* level_rows;   /* [n_levels] rows of every pyramid level                                        */
     const osn_net_map* maps;
@@ -481,10 +504,18 @@ typedef struct osn_net_run {
     int32_t first_op, end_op;    /* ops [first_op, end_op) are executed                                           */
     int32_t reserved;
     osn_prof_t* prof;            /* nullable                                                                      */
+    /* backward only, all nullable: the weight gradients (needed only at the end of the pass) run on `side_stream`
+     * beside the input-gradient / batch-norm chain of the main stream; the pass forks after each stage's batch-norm
+     * backward and joins before its batched reduction, so nothing outside sees the second stream.                  */
+    osn_stream_t side_stream;
+    void* ws_side; uint64_t ws_side_bytes;     /* scratch of the side stream's launches (same size rule as ws)       */
+    osn_events_t* events;        /* osn_events_create(n_ops + 1)                                                  */
 } osn_net_run;
 int osn_net_plan_query(const osn_net_desc* net, const int64_t* level_rows, int training, osn_net_plan* plan);
 int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, osn_stream_t stream);
 int osn_net_backward(const osn_net_desc* net, const osn_net_run* run, osn_stream_t stream);
+osn_events_t* osn_events_create(int n);       /* n timing-free HIP events on the current device; null on failure   */
+void osn_events_destroy(osn_events_t* e);
 
 /* Launch timer for the executor (bench.py's roofline entry): HIP events recorded on the launch stream around the
  * convolution launches of selected stages.  tag = op * 4 + phase (0 forward, 1 input gradient, 2 weight gradient).

@@ -54,6 +54,8 @@ PROTOTYPES = {
     "osn_pair_lists_build": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "osn_spconv_wgrad_tl_ws_bytes": (_sz, [_i32, _i32, _i32]),
     "osn_spconv_wgrad_tl": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "osn_spconv_wgrad_tl_partial": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _sz, _vp, _vp]),
+    "osn_wgrad_tl_reduce_batch": (_i32, [_vp, _i32, _vp]),
     "osn_stem_conv_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "osn_bn_ws_bytes": (_sz, [_i64, _i32]),
     "osn_bn_stats": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _sz, _vp]),
@@ -62,11 +64,14 @@ PROTOTYPES = {
     "osn_bn_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32,
                                _vp, _sz, _vp]),
     "osn_bn_apply2": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "osn_bn_forward_train2": (_i32, [_vp, _i64, _i32, _vp, _vp, _f32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "osn_bn_backward_multi": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32,
                                      _vp, _sz, _vp]),
     "osn_net_plan_query": (_i32, [_vp, _vp, _i32, _vp]),
     "osn_net_forward": (_i32, [_vp, _vp, _vp]),
     "osn_net_backward": (_i32, [_vp, _vp, _vp]),
+    "osn_events_create": (_vp, [_i32]),
+    "osn_events_destroy": (None, [_vp]),
     "osn_prof_create": (_vp, [_i32]),
     "osn_prof_destroy": (None, [_vp]),
     "osn_prof_filter": (_i32, [_vp, _vp, _i32]),

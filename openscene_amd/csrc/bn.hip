@@ -256,6 +256,174 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small maps (the deep U-Net levels: 700 - 3 000 rows): the three launches of a training-mode batch norm (column sums,
+// finalize, apply) and of its backward are each a few microseconds of launch latency around almost no work.  Up to
+// SB_MAX_ROWS rows one workgroup of 1024 threads owns 8 columns, keeps its rows IN REGISTERS between the statistics and
+// the apply pass (x is read once), and reduces with wave shuffles + one LDS round in a fixed order (deterministic).
+// Same formulas as the three-kernel path (fp64 sums, fp32 mean / var / apply).
+constexpr int SB_THREADS = 1024, SB_RL = 512, SB_PER = 8, SB_COLS = 8;
+constexpr int SB_MAX_ROWS = SB_RL * SB_PER;       // 4096
+
+__device__ inline double sb_wave_sum(double v) {
+    // lanes of one wave that share bit 0 (the column lane): xor-shuffle over the 32 row lanes
+#pragma unroll
+    for (int off = 2; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// sums[0..3] / sums[4..7] of this thread's 4 columns -> totals over the workgroup's rows, in every thread
+__device__ inline void sb_block_sums(double (&s)[8], int tid, int cl) {
+    __shared__ double red[SB_THREADS / 64][2][8];
+    __shared__ double tot[2][8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s[q] = sb_wave_sum(s[q]);
+    const int lane = tid & 63, wave = tid >> 6;
+    if ((lane >> 1) == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) red[wave][cl][q] = s[q];
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int c2 = tid >> 3, q = tid & 7;
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < SB_THREADS / 64; ++w) t += red[w][c2][q];
+        tot[c2][q] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s[q] = tot[cl][q];
+}
+
+__global__ __launch_bounds__(SB_THREADS) void bn_small_fwd_kernel(const float* __restrict__ x, int n, int c,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  float eps, const float* __restrict__ residual, int relu,
+                                                                  float momentum, float* __restrict__ mean_out,
+                                                                  float* __restrict__ var_out, float* __restrict__ running_mean,
+                                                                  float* __restrict__ running_var, float* __restrict__ y,
+                                                                  float* __restrict__ y2, int64_t ld2) {
+    const int tid = threadIdx.x, cl = tid & 1, rl = tid >> 1;
+    const int col = blockIdx.x * SB_COLS + cl * 4;
+    const bool con = col < c;
+    const int cc = con ? col : 0;
+    float4 v[SB_PER];
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < SB_PER; ++j) {
+        const int r = rl + SB_RL * j;
+        const bool ok = con && r < n;
+        v[j] = ld4(x + int64_t(ok ? r : 0) * c + cc);
+        if (ok) {
+            s[0] += v[j].x; s[1] += v[j].y; s[2] += v[j].z; s[3] += v[j].w;
+            s[4] += double(v[j].x) * v[j].x; s[5] += double(v[j].y) * v[j].y;
+            s[6] += double(v[j].z) * v[j].z; s[7] += double(v[j].w) * v[j].w;
+        }
+    }
+    sb_block_sums(s, tid, cl);
+    float mu[4], vr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double m = s[q] / double(n);
+        double var = s[4 + q] / double(n) - m * m;
+        if (var < 0) var = 0;
+        mu[q] = float(m);
+        vr[q] = float(var);
+        if (rl == 0 && con) {
+            mean_out[col + q] = mu[q];
+            var_out[col + q] = vr[q];
+            if (running_mean) running_mean[col + q] = (1.f - momentum) * running_mean[col + q] + momentum * mu[q];
+            if (running_var) {
+                const double unb = n > 1 ? var * double(n) / double(n - 1) : var;
+                running_var[col + q] = (1.f - momentum) * running_var[col + q] + momentum * float(unb);
+            }
+        }
+    }
+    if (!con) return;
+    const float4 ga = ld4(gamma + col), be = ld4(beta + col);
+    const float is0 = 1.f / sqrtf(vr[0] + eps), is1 = 1.f / sqrtf(vr[1] + eps), is2 = 1.f / sqrtf(vr[2] + eps),
+                is3 = 1.f / sqrtf(vr[3] + eps);
+#pragma unroll
+    for (int j = 0; j < SB_PER; ++j) {
+        const int r = rl + SB_RL * j;
+        if (r >= n) continue;
+        float4 o;
+        o.x = (v[j].x - mu[0]) * is0 * ga.x + be.x;
+        o.y = (v[j].y - mu[1]) * is1 * ga.y + be.y;
+        o.z = (v[j].z - mu[2]) * is2 * ga.z + be.z;
+        o.w = (v[j].w - mu[3]) * is3 * ga.w + be.w;
+        if (residual) {
+            const float4 rv = ld4(residual + int64_t(r) * c + col);
+            o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+        }
+        if (relu) {
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(y + int64_t(r) * c + col) = o;
+        if (y2) *reinterpret_cast<float4*>(y2 + int64_t(r) * ld2 + col) = o;
+    }
+}
+
+__global__ __launch_bounds__(SB_THREADS) void bn_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                  const GySrc gy, const float* __restrict__ mean,
+                                                                  const float* __restrict__ var, const float* __restrict__ gamma,
+                                                                  float eps, int relu, int training, float* __restrict__ gx,
+                                                                  float* __restrict__ gres, float* __restrict__ ggamma,
+                                                                  float* __restrict__ gbeta, int n, int c) {
+    const int tid = threadIdx.x, cl = tid & 1, rl = tid >> 1;
+    const int col = blockIdx.x * SB_COLS + cl * 4;
+    const bool con = col < c;
+    const int cc = con ? col : 0;
+    const float4 mu = ld4(mean + cc), vv = ld4(var + cc), ga = ld4(gamma + cc);
+    const float4 is = make_float4(1.f / sqrtf(vv.x + eps), 1.f / sqrtf(vv.y + eps), 1.f / sqrtf(vv.z + eps),
+                                  1.f / sqrtf(vv.w + eps));
+    float4 xv[SB_PER], g[SB_PER];
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < SB_PER; ++j) {
+        const int r = rl + SB_RL * j;
+        const bool ok = con && r < n;
+        const int64_t rr = ok ? r : 0;
+        xv[j] = ld4(x + rr * c + cc);
+        g[j] = gy_load(gy, rr, cc);
+        if (relu) {
+            const float4 yv = ld4(y + rr * c + cc);
+            g[j].x = yv.x > 0.f ? g[j].x : 0.f; g[j].y = yv.y > 0.f ? g[j].y : 0.f;
+            g[j].z = yv.z > 0.f ? g[j].z : 0.f; g[j].w = yv.w > 0.f ? g[j].w : 0.f;
+        }
+        if (ok) {
+            s[0] += g[j].x; s[1] += g[j].y; s[2] += g[j].z; s[3] += g[j].w;
+            s[4] += double(g[j].x) * ((xv[j].x - mu.x) * is.x); s[5] += double(g[j].y) * ((xv[j].y - mu.y) * is.y);
+            s[6] += double(g[j].z) * ((xv[j].z - mu.z) * is.z); s[7] += double(g[j].w) * ((xv[j].w - mu.w) * is.w);
+        }
+    }
+    sb_block_sums(s, tid, cl);
+    if (!con) return;
+    const float sg[4] = {float(s[0]), float(s[1]), float(s[2]), float(s[3])};
+    const float sx[4] = {float(s[4]), float(s[5]), float(s[6]), float(s[7])};
+    if (rl == 0) {
+        *reinterpret_cast<float4*>(gbeta + col) = make_float4(sg[0], sg[1], sg[2], sg[3]);
+        *reinterpret_cast<float4*>(ggamma + col) = make_float4(sx[0], sx[1], sx[2], sx[3]);
+    }
+    const float inv_n = 1.f / float(n);
+#pragma unroll
+    for (int j = 0; j < SB_PER; ++j) {
+        const int r = rl + SB_RL * j;
+        if (r >= n) continue;
+        if (gres) *reinterpret_cast<float4*>(gres + int64_t(r) * c + col) = g[j];
+        float4 o;
+        if (training) {
+            o.x = ga.x * is.x * (g[j].x - sg[0] * inv_n - (xv[j].x - mu.x) * is.x * sx[0] * inv_n);
+            o.y = ga.y * is.y * (g[j].y - sg[1] * inv_n - (xv[j].y - mu.y) * is.y * sx[1] * inv_n);
+            o.z = ga.z * is.z * (g[j].z - sg[2] * inv_n - (xv[j].z - mu.z) * is.z * sx[2] * inv_n);
+            o.w = ga.w * is.w * (g[j].w - sg[3] * inv_n - (xv[j].w - mu.w) * is.w * sx[3] * inv_n);
+        } else {
+            o.x = ga.x * is.x * g[j].x; o.y = ga.y * is.y * g[j].y; o.z = ga.z * is.z * g[j].z; o.w = ga.w * is.w * g[j].w;
+        }
+        *reinterpret_cast<float4*>(gx + int64_t(r) * c + col) = o;
+    }
+}
+
 static int ew_grid(int64_t total4) {
     int64_t g = cdiv(total4, 256);
     if (g > 2048) g = 2048;
@@ -315,16 +483,36 @@ extern "C" int osn_bn_apply(const float* x, const float* mean, const float* var,
     return osn_bn_apply2(x, mean, var, gamma, beta, eps, residual, relu, y, nullptr, 0, n, c, stream);
 }
 
-// Training-mode forward in ONE call: statistics (+ running buffers) and the fused normalise (+ residual) (+ ReLU) pass.
-// Same kernels as osn_bn_stats + osn_bn_apply; one trip through the host binding instead of two (the deep U-Net levels
-// are bound by the host's launch rate, and there are 48 of these per step).
+// Training-mode forward in ONE call: statistics (+ running buffers) and the fused normalise (+ residual) (+ ReLU) pass
+// (+ the second destination of osn_bn_apply2).  Up to SB_MAX_ROWS rows: ONE launch (bn_small_fwd_kernel); above: the
+// kernels of osn_bn_stats + osn_bn_apply2.
+extern "C" int osn_bn_forward_train2(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
+                                     const float* residual, int relu, float momentum, float* mean, float* var,
+                                     float* running_mean, float* running_var, float* y, float* y2, int64_t ld2, void* ws,
+                                     size_t ws_bytes, osn_stream_t stream) {
+    if (n >= 1 && n <= SB_MAX_ROWS && c >= 4 && (c & 3) == 0) {
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        OSN_REQUIRE(x && mean && var && gamma && beta && y, OSN_E_ARG, "osn_bn_forward_train: null pointer");
+        OSN_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && (!residual || aligned16(residual)),
+                    OSN_E_ARG, "osn_bn_forward_train: pointers must be 16-byte aligned");
+        OSN_REQUIRE(!y2 || (aligned16(y2) && ld2 >= c && (ld2 & 3) == 0), OSN_E_ARG,
+                    "osn_bn_forward_train2: the second destination needs a 16-byte aligned pointer and a row stride >= c, %% 4 == 0");
+        hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(unsigned(cdiv(c, SB_COLS))), dim3(SB_THREADS), 0, st, x, int(n), c, gamma,
+                           beta, eps, residual, relu, momentum, mean, var, running_mean, running_var, y, y2, ld2);
+        OSN_LAUNCH_CHECK();
+        return OSN_OK;
+    }
+    int rc = osn_bn_stats(x, n, c, mean, var, running_mean, running_var, momentum, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return osn_bn_apply2(x, mean, var, gamma, beta, eps, residual, relu, y, y2, ld2, n, c, stream);
+}
+
 extern "C" int osn_bn_forward_train(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
                                     const float* residual, int relu, float momentum, float* mean, float* var,
                                     float* running_mean, float* running_var, float* y, void* ws, size_t ws_bytes,
                                     osn_stream_t stream) {
-    int rc = osn_bn_stats(x, n, c, mean, var, running_mean, running_var, momentum, ws, ws_bytes, stream);
-    if (rc) return rc;
-    return osn_bn_apply(x, mean, var, gamma, beta, eps, residual, relu, y, n, c, stream);
+    return osn_bn_forward_train2(x, n, c, gamma, beta, eps, residual, relu, momentum, mean, var, running_mean, running_var, y,
+                                 nullptr, 0, ws, ws_bytes, stream);
 }
 
 extern "C" int osn_bn_backward_multi(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,
@@ -348,6 +536,12 @@ extern "C" int osn_bn_backward_multi(const float* x, const float* y, const float
                     "osn_bn_backward: gradient source %d needs a 16-byte aligned pointer and a row stride >= c, %% 4 == 0", j);
         src.p[i] = gy[j];
         src.ld[i] = gy_ld[j];
+    }
+    if (n <= SB_MAX_ROWS) {               // small map: one launch (sums, gamma / beta gradients and the apply pass)
+        hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(unsigned(cdiv(c, SB_COLS))), dim3(SB_THREADS), 0, st, x, y, src, mean, var,
+                           gamma, eps, relu, training, gx, gres, ggamma, gbeta, int(n), c);
+        OSN_LAUNCH_CHECK();
+        return OSN_OK;
     }
     ColReducePlan p = plan_colreduce(n, c);
     const size_t need = size_t(p.n_rb) * 2 * size_t(c) * 8;

@@ -15,6 +15,10 @@ namespace osn {
 
 constexpr uint64_t NO_OFF = ~uint64_t(0);
 
+struct Events {
+    std::vector<hipEvent_t> ev;
+};
+
 struct Prof {
     std::vector<hipEvent_t> ev;        // 2 per record
     std::vector<int32_t> tag;
@@ -39,7 +43,7 @@ static bool x6_eligible(int K, int cin, int cout, int64_t n_out) {
 
 // Everything the passes derive from (program, level sizes): kernel per stage, arena offsets, scratch size.
 struct Layout {
-    std::vector<uint64_t> x_off, stat_off, y_off, gx_off, gres_off, gin_off;
+    std::vector<uint64_t> x_off, stat_off, y_off, gx_off, gres_off, gin_off, gpart_off;
     std::vector<int32_t> fwd_k, dgrad_k, wgrad_k, images;
     std::vector<int32_t> producer;       // buffer -> op with dst == buffer
     uint64_t fwd_bytes = 0, bwd_bytes = 0, ws_bytes = 0;
@@ -85,7 +89,7 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
     if (rc) return rc;
     const int n = net->n_ops;
     L.x_off.assign(n, NO_OFF); L.stat_off.assign(n, NO_OFF); L.gx_off.assign(n, NO_OFF); L.gres_off.assign(n, NO_OFF);
-    L.gin_off.assign(n, NO_OFF);
+    L.gin_off.assign(n, NO_OFF); L.gpart_off.assign(n, NO_OFF);
     L.y_off.assign(net->n_bufs, NO_OFF);
     L.fwd_k.assign(n, 0); L.dgrad_k.assign(n, 0); L.wgrad_k.assign(n, 0); L.images.assign(n, 0);
     L.producer.assign(net->n_bufs, -1);
@@ -108,7 +112,7 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
         if (stem_eligible(o.K, o.cin, o.cout)) {
             OSN_REQUIRE(!o.transposed, OSN_E_ARG, "osn_net: op %d: transposed stem", i);
             L.fwd_k[i] = OSN_NET_K_STEM;
-        } else if (o.K > 1 && tl_eligible(o.K, o.cin, o.cout, n_in) && n_out >= net->tl_min_rows) {
+        } else if (o.K > 1 && tl_eligible(o.K, o.cin, o.cout, n_in) && (n_out >= net->tl_min_rows || n_out <= net->tl_small_rows)) {
             L.fwd_k[i] = OSN_NET_K_TL;
             L.images[i] |= OSN_NET_IMG_TL_FWD;
             need_ws(osn_spconv_fwd_tl_ws_bytes(n_out, o.K, o.cout, osn_tile_rows(n_out)));
@@ -122,7 +126,8 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
         if (!training) continue;
         // ---- input gradient: a convolution of the output gradient with the transposed weights, [n_in, cin]
         if (o.need_dgrad) {
-            if (o.K > 1 && tl_eligible(o.K, o.cout, o.cin, n_out) && tl_eligible(o.K, o.cin, o.cout, n_in) && n_in >= net->tl_min_rows) {
+            if (o.K > 1 && tl_eligible(o.K, o.cout, o.cin, n_out) && tl_eligible(o.K, o.cin, o.cout, n_in) &&
+                (n_in >= net->tl_min_rows || n_in <= net->tl_small_rows)) {
                 L.dgrad_k[i] = OSN_NET_K_TL;
                 L.images[i] |= OSN_NET_IMG_TL_DGRAD;
                 need_ws(osn_spconv_fwd_tl_ws_bytes(n_in, o.K, o.cin, osn_tile_rows(n_in)));
@@ -135,9 +140,15 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
             }
         }
         // ---- weight gradient
-        if (o.K > 1 && tl_eligible(o.K, o.cin, o.cout, n_in) && !stem_eligible(o.K, o.cin, o.cout)) {
+        // pair-array kernel on every 3^3 / 2^3 map, and -- identity map -- for the 1x1 shortcut convs up to 128 x 128
+        // channels (their 512 partial tiles are summed by the pass's ONE batched reduction; the 96 -> 768 head stays on the
+        // table kernel: 188 us against 215 us measured)
+        const bool wg_tl = (o.K > 1 || (o.cin <= 128 && o.cout <= 128)) && tl_eligible(o.K, o.cin, o.cout, n_in) &&
+                           !stem_eligible(o.K, o.cin, o.cout);
+        if (wg_tl) {
             L.wgrad_k[i] = OSN_NET_K_WGRAD_TL;
-            need_ws(osn_spconv_wgrad_tl_ws_bytes(o.K, o.cin, o.cout));
+            // partial sums per work item live in the backward arena until the ONE batched reduction at the end of the pass
+            L.gpart_off[i] = b; b += up256(osn_spconv_wgrad_tl_ws_bytes(o.K, o.cin, o.cout));
         } else {
             L.wgrad_k[i] = OSN_NET_K_WGRAD;
             need_ws(osn_spconv_wgrad_ws_bytes(n_out, o.K, o.cin, o.cout));
@@ -302,16 +313,14 @@ extern "C" int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, 
             ld2 = net->bufs[o.copy_buf].channels;
             y2 = reinterpret_cast<float*>(A + L.y_off[o.copy_buf]) + o.copy_col;
         }
-        const float *mean = bn.running_mean, *var = bn.running_var;
         if (run->training) {
             float* mv = reinterpret_cast<float*>(A + L.stat_off[i]);
-            rc = osn_bn_stats(x, n_out, o.cout, mv, mv + o.cout, bn.running_mean, bn.running_var, bn.momentum, run->ws,
-                              size_t(run->ws_bytes), stream);
-            if (rc) return rc;
-            mean = mv; var = mv + o.cout;
+            rc = osn_bn_forward_train2(x, n_out, o.cout, bn.gamma, bn.beta, bn.eps, res, o.relu, bn.momentum, mv, mv + o.cout,
+                                       bn.running_mean, bn.running_var, y, y2, ld2, run->ws, size_t(run->ws_bytes), stream);
+        } else {
+            OSN_REQUIRE(bn.running_mean && bn.running_var, OSN_E_ARG, "osn_net_forward: op %d: evaluation-mode batch norm without running statistics", i);
+            rc = osn_bn_apply2(x, bn.running_mean, bn.running_var, bn.gamma, bn.beta, bn.eps, res, o.relu, y, y2, ld2, n_out, o.cout, stream);
         }
-        OSN_REQUIRE(mean && var, OSN_E_ARG, "osn_net_forward: op %d: evaluation-mode batch norm without running statistics", i);
-        rc = osn_bn_apply2(x, mean, var, bn.gamma, bn.beta, bn.eps, res, o.relu, y, y2, ld2, n_out, o.cout, stream);
         if (rc) return rc;
     }
     (void)st;
@@ -329,6 +338,16 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
     char* A = static_cast<char*>(run->fwd_arena);
     char* B = static_cast<char*>(run->bwd_arena);
     const int64_t* rows = run->level_rows;
+    std::vector<osn_wgrad_job> jobs;
+    jobs.reserve(size_t(net->n_ops));
+    // optional second stream for the weight gradients
+    Events* evs = reinterpret_cast<Events*>(run->events);
+    hipStream_t side = static_cast<hipStream_t>(run->side_stream);
+    const bool forked = side && side != st && evs && int(evs->ev.size()) > net->n_ops && run->ws_side &&
+                        run->ws_side_bytes >= L.ws_bytes;
+    osn_stream_t wstream = forked ? run->side_stream : stream;
+    void* wws = forked ? run->ws_side : run->ws;
+    const size_t wws_bytes = size_t(forked ? run->ws_side_bytes : run->ws_bytes);
     for (int i = run->end_op - 1; i >= run->first_op; --i) {
         const osn_net_op& o = net->ops[i];
         const int64_t n_in = rows[o.lvl_in], n_out = rows[o.lvl_out];
@@ -377,18 +396,24 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
         MapView v{};
         const osn_net_map* m = o.map >= 0 ? &run->maps[o.map] : nullptr;
         if (m) v = view_of(*m, o.transposed != 0);
-        // ---- weight gradient
+        // ---- weight gradient (fork: the side stream sees everything the main stream has queued up to gx)
         OSN_REQUIRE(w.gW, OSN_E_ARG, "osn_net_backward: op %d: null weight-gradient pointer", i);
+        if (forked) {
+            OSN_HIP(hipEventRecord(evs->ev[i], st));
+            OSN_HIP(hipStreamWaitEvent(side, evs->ev[i], 0));
+        }
         {
-            Bracket br(run->prof, i, 2, st);
+            Bracket br(run->prof, i, 2, forked ? side : st);
             if (L.wgrad_k[i] == OSN_NET_K_WGRAD_TL) {
                 // pair arrays of the map's forward table; a transposed conv uses the strided conv's arrays, roles swapped
-                OSN_REQUIRE(m && m->pl_fwd, OSN_E_ARG, "osn_net_backward: op %d: pair lists missing", i);
-                rc = osn_spconv_wgrad_tl(in, gx, m->pl_fwd, o.transposed ? 1 : 0, w.gW, n_in, n_out, o.K, o.cin, o.cout, run->ws,
-                                         size_t(run->ws_bytes), stream);
+                OSN_REQUIRE(o.K == 1 || (m && m->pl_fwd), OSN_E_ARG, "osn_net_backward: op %d: pair lists missing", i);
+                osn_wgrad_job job;
+                rc = osn_spconv_wgrad_tl_partial(in, gx, m ? m->pl_fwd : nullptr, o.transposed ? 1 : 0, w.gW, n_in, n_out, o.K, o.cin, o.cout,
+                                                 B + L.gpart_off[i], osn_spconv_wgrad_tl_ws_bytes(o.K, o.cin, o.cout), &job, wstream);
+                if (!rc) jobs.push_back(job);
             } else {
                 rc = osn_spconv_wgrad(in, gx, o.K > 1 ? v.nbr_f : nullptr, o.K > 1 && m ? m->counts : nullptr, nullptr, w.gW, n_out, o.K,
-                                      o.cin, o.cout, run->ws, size_t(run->ws_bytes), stream);
+                                      o.cin, o.cout, wws, wws_bytes, wstream);
             }
         }
         if (rc) return rc;
@@ -401,7 +426,34 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
             if (rc) return rc;
         }
     }
-    return OSN_OK;
+    if (forked) {                                          // join: the reductions (and everything after the pass) see the side stream's work
+        OSN_HIP(hipEventRecord(evs->ev[net->n_ops], side));
+        OSN_HIP(hipStreamWaitEvent(st, evs->ev[net->n_ops], 0));
+    }
+    // every pair-array weight gradient of the pass: one reduction launch (per 32 convolutions) instead of one each
+    return osn_wgrad_tl_reduce_batch(jobs.data(), int(jobs.size()), stream);
+}
+
+extern "C" osn_events_t* osn_events_create(int n) {
+    if (n < 1) return nullptr;
+    Events* e = new (std::nothrow) Events();
+    if (!e) return nullptr;
+    e->ev.resize(size_t(n), nullptr);
+    for (int i = 0; i < n; ++i) {
+        if (hipEventCreateWithFlags(&e->ev[i], hipEventDisableTiming) != hipSuccess) {
+            for (int j = 0; j < i; ++j) (void)hipEventDestroy(e->ev[j]);
+            delete e;
+            return nullptr;
+        }
+    }
+    return reinterpret_cast<osn_events_t*>(e);
+}
+
+extern "C" void osn_events_destroy(osn_events_t* h) {
+    Events* e = reinterpret_cast<Events*>(h);
+    if (!e) return;
+    for (hipEvent_t x : e->ev) (void)hipEventDestroy(x);
+    delete e;
 }
 
 // ------------------------------------------------------------------------------------------- launch timer

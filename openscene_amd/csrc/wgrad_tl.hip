@@ -378,6 +378,29 @@ __global__ void wgrad_tl_reduce_kernel(const float* __restrict__ partial, const 
     }
 }
 
+// The same reduction for MANY weight gradients in one launch (the network executor defers every convolution's reduce to
+// the end of the backward pass: 49 launches of a few microseconds -> 1): blockIdx.y = job, identical summation order.
+constexpr int WG_BATCH = 32;
+struct WgJobs {
+    osn_wgrad_job j[WG_BATCH];
+};
+__global__ __launch_bounds__(256) void wgrad_tl_reduce_batch_kernel(const WgJobs jobs) {
+    const osn_wgrad_job& jb = jobs.j[blockIdx.y];
+    const float* __restrict__ partial = jb.partial;
+    const int2* __restrict__ range = static_cast<const int2*>(jb.range);
+    float* __restrict__ out = jb.gW;
+    const int64_t per_k = int64_t(jb.cin) * jb.cout;
+    const int64_t total = int64_t(jb.K) * per_k;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        const int k = int(e / per_k);
+        const int64_t r = e - int64_t(k) * per_k;
+        const int t0 = range ? range[k].x : 0, t1 = range ? range[k].y : jb.ident_items;
+        float s = 0.f;
+        for (int t = t0; t < t1; ++t) s += partial[int64_t(t) * per_k + r];
+        out[e] = s;
+    }
+}
+
 }  // namespace osn
 
 using namespace osn;
@@ -429,7 +452,7 @@ WgTlPlan plan_wg_tl(int ca, int cg) {
 int ident_quota(int64_t n) {
     int64_t q = cdiv(n, PL_ITEMS);
     q = (q + 31) / 32 * 32;
-    if (q < PL_MIN_QUOTA) q = PL_MIN_QUOTA;
+    if (q < 64) q = 64;        // identity maps (1x1 convs) of the deep levels have a few hundred rows: keep >= ~10 items in flight
     return int(q);
 }
 }  // namespace
@@ -455,15 +478,18 @@ static void launch_wg_tl_nb(int nb, dim3 grid, hipStream_t st, const float* ra, 
 #undef OSN_WGTL
 }
 
-extern "C" int osn_spconv_wgrad_tl(const float* in, const float* gout, const void* pl, int swap, float* gW, int64_t n_in,
-                                   int64_t n_out, int K, int cin, int cout, void* ws, size_t ws_bytes,
-                                   osn_stream_t stream) {
+// kernel launch only: partial[item][cin][cout] + the job describing its reduction (job->gW = gW); gW itself is written only
+// when the map is empty (zeros).  Returns through *launched whether a reduction is pending.
+static int wgrad_tl_partial(const float* in, const float* gout, const void* pl, int swap, float* gW, int64_t n_in,
+                            int64_t n_out, int K, int cin, int cout, void* ws, size_t ws_bytes, osn_wgrad_job* job,
+                            int* launched, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(K >= 1 && K <= PL_KMAX && cin >= 4 && (cin & 3) == 0 && cout >= 4 && (cout & 3) == 0 && gW, OSN_E_ARG,
                 "osn_spconv_wgrad_tl: needs cin %% 4 == 0 and cout %% 4 == 0 (K=%d cin=%d cout=%d)", K, cin, cout);
     OSN_REQUIRE(n_in >= 0 && n_out >= 0 && n_in < (int64_t(1) << 31) && n_out < (int64_t(1) << 31), OSN_E_ARG,
                 "osn_spconv_wgrad_tl: row counts out of range");
     const int64_t wtotal = int64_t(K) * cin * cout;
+    *launched = 0;
     if (n_out == 0 || n_in == 0) {
         OSN_HIP(hipMemsetAsync(gW, 0, size_t(wtotal) * 4, st));
         return OSN_OK;
@@ -506,9 +532,61 @@ extern "C" int osn_spconv_wgrad_tl(const float* in, const float* gout, const voi
         default: launch_wg_tl_nb<4>(p.nb, grid, st, ra, rg, ia, ig, poff, items, partial, ca, cg, p.n_gb, irows, iquota); break;
     }
     OSN_LAUNCH_CHECK();
+    job->partial = partial;
+    job->range = range;
+    job->gW = gW;
+    job->K = K; job->cin = cin; job->cout = cout; job->ident_items = n_items;
+    *launched = 1;
+    return OSN_OK;
+}
+
+extern "C" int osn_spconv_wgrad_tl(const float* in, const float* gout, const void* pl, int swap, float* gW, int64_t n_in,
+                                   int64_t n_out, int K, int cin, int cout, void* ws, size_t ws_bytes,
+                                   osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    osn_wgrad_job job;
+    int launched = 0;
+    int rc = wgrad_tl_partial(in, gout, pl, swap, gW, n_in, n_out, K, cin, cout, ws, ws_bytes, &job, &launched, stream);
+    if (rc || !launched) return rc;
+    const int64_t wtotal = int64_t(K) * cin * cout;
     int g = int(cdiv(wtotal, 256));
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(wgrad_tl_reduce_kernel, dim3(g), dim3(256), 0, st, partial, range, K, cin, cout, 0, n_items, gW);
+    hipLaunchKernelGGL(wgrad_tl_reduce_kernel, dim3(g), dim3(256), 0, st, job.partial, static_cast<const int2*>(job.range), K, cin,
+                       cout, 0, job.ident_items, gW);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
+}
+
+extern "C" int osn_spconv_wgrad_tl_partial(const float* in, const float* gout, const void* pl, int swap, float* gW, int64_t n_in,
+                                           int64_t n_out, int K, int cin, int cout, void* partial, size_t partial_bytes,
+                                           osn_wgrad_job* job, osn_stream_t stream) {
+    OSN_REQUIRE(job, OSN_E_ARG, "osn_spconv_wgrad_tl_partial: null job");
+    int launched = 0;
+    job->partial = nullptr; job->range = nullptr; job->gW = nullptr;
+    job->K = 0; job->cin = 0; job->cout = 0; job->ident_items = 0;
+    return wgrad_tl_partial(in, gout, pl, swap, gW, n_in, n_out, K, cin, cout, partial, partial_bytes, job, &launched, stream);
+}
+
+extern "C" int osn_wgrad_tl_reduce_batch(const osn_wgrad_job* jobs, int n_jobs, osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || jobs), OSN_E_ARG, "osn_wgrad_tl_reduce_batch: bad arguments");
+    WgJobs b;
+    int nb = 0;
+    auto flush = [&]() -> int {
+        if (nb == 0) return OSN_OK;
+        hipLaunchKernelGGL(wgrad_tl_reduce_batch_kernel, dim3(128, unsigned(nb)), dim3(256), 0, st, b);
+        OSN_LAUNCH_CHECK();
+        nb = 0;
+        return OSN_OK;
+    };
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!jobs[i].gW) continue;                        // nothing was launched for this job (empty map: gW already zero)
+        OSN_REQUIRE(jobs[i].partial && jobs[i].K >= 1, OSN_E_ARG, "osn_wgrad_tl_reduce_batch: job %d is incomplete", i);
+        b.j[nb++] = jobs[i];
+        if (nb == WG_BATCH) {
+            int rc = flush();
+            if (rc) return rc;
+        }
+    }
+    return flush();
 }

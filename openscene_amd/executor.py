@@ -21,6 +21,13 @@ from . import _lib, ops
 from ._lib import check
 
 ENABLED = os.environ.get("OSN_EXECUTOR", "1") != "0"
+# tile-list forward / input gradient ALSO on tables of at most this many rows (the deep U-Net levels, where the
+# output-stationary kernel's 32-channel stages are latency-bound); 0 = only from functional.TL_FWD_MIN_ROWS rows on
+TL_SMALL_MAX_ROWS = int(os.environ.get("OSN_TL_SMALL_MAX_ROWS", "0"))
+# weight gradients of the backward pass on a second stream beside the input-gradient / batch-norm chain (bitwise the same
+# gradients; the GPU is the bottleneck since the executor took the host out of the way, and the deep levels' launches
+# leave most compute units idle)
+WGRAD_SIDE_STREAM = os.environ.get("OSN_WGRAD_SIDE_STREAM", "1") != "0"
 _DRY_RUN = False        # tools/dryrun only: accept host tensors (a null HIP runtime logs the launches instead of running them)
 
 _OP = np.dtype([(n, "<i4") for n in ("K", "cin", "cout", "lvl_in", "lvl_out", "map", "transposed", "src", "dst", "bn", "relu",
@@ -42,7 +49,7 @@ K_NAMES = {0: "none", 1: "stem", 2: "tl", 3: "x6", 4: "wgrad_tl", 5: "wgrad"}
 class _Desc(ctypes.Structure):
     _fields_ = [("n_ops", ctypes.c_int32), ("n_bufs", ctypes.c_int32), ("n_bns", ctypes.c_int32), ("n_weights", ctypes.c_int32),
                 ("n_maps", ctypes.c_int32), ("n_levels", ctypes.c_int32), ("tl_min_rows", ctypes.c_int32),
-                ("bn_small_rows", ctypes.c_int32), ("ops", ctypes.c_void_p), ("bufs", ctypes.c_void_p)]
+                ("tl_small_rows", ctypes.c_int32), ("ops", ctypes.c_void_p), ("bufs", ctypes.c_void_p)]
 
 
 class _Plan(ctypes.Structure):
@@ -59,7 +66,9 @@ class _Run(ctypes.Structure):
                 ("bwd_arena", ctypes.c_void_p), ("bwd_arena_bytes", ctypes.c_uint64),
                 ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_uint64),
                 ("tl_counters", ctypes.c_void_p), ("training", ctypes.c_int32), ("first_op", ctypes.c_int32),
-                ("end_op", ctypes.c_int32), ("reserved", ctypes.c_int32), ("prof", ctypes.c_void_p)]
+                ("end_op", ctypes.c_int32), ("reserved", ctypes.c_int32), ("prof", ctypes.c_void_p),
+                ("side_stream", ctypes.c_void_p), ("ws_side", ctypes.c_void_p), ("ws_side_bytes", ctypes.c_uint64),
+                ("events", ctypes.c_void_p)]
 
 
 def _ptr(a):
@@ -179,6 +188,7 @@ class UNetExecutor:
                            _ptr(self._kw), _ptr(self._img))
         self._rows = np.zeros(8, np.int64)
         self.prof = None                  # osn_prof_t* (bench.py), or None
+        self._events = {}                 # device index -> osn_events_t* (fork / join of the backward pass)
         # gradient layout: one flat fp32 buffer, every parameter's slice starts on a 16-byte boundary
         self.grad_off, off = [], 0
         for prm in p.params:
@@ -207,6 +217,7 @@ class UNetExecutor:
     def _plan_query(self, lib, rows, training):
         from . import functional as F_
         self.desc.tl_min_rows = int(F_.TL_FWD_MIN_ROWS)
+        self.desc.tl_small_rows = TL_SMALL_MAX_ROWS
         self._rows[:len(rows)] = rows
         check(lib.osn_net_plan_query(ctypes.addressof(self.desc), _ptr(self._rows), int(training), ctypes.addressof(self._plan)),
               "osn_net_plan_query")
@@ -348,9 +359,19 @@ class UNetExecutor:
         barena = torch.empty(int(self._plan.bwd_arena_bytes), dtype=torch.uint8, device=dev)
         ws = ops._ws(int(self._plan.ws_bytes), dev)
         self._rows[:len(st.rows)] = st.rows
+        side = ws2 = events = None
+        if WGRAD_SIDE_STREAM and not _DRY_RUN:
+            side = ops.side_stream(dev).cuda_stream
+            ws2 = ops.ws_on(int(self._plan.ws_bytes), dev, side)
+            events = self._events.get(ops._idx(dev))
+            if events is None:
+                with ops._Dev(dev):
+                    events = self._events[ops._idx(dev)] = lib.osn_events_create(len(p.ops) + 1)
         run = _Run(_ptr(self._rows), _ptr(st.maps), _ptr(st.weights), _ptr(st.bns), st.feats.data_ptr(), None, gout.data_ptr(),
                    st.arena.data_ptr(), st.arena.numel(), barena.data_ptr(), barena.numel(), ws.data_ptr(), ws.numel(),
-                   ops.tl_counters(dev).data_ptr(), int(st.training), 0, len(p.ops), 0, self.prof)
+                   ops.tl_counters(dev).data_ptr(), int(st.training), 0, len(p.ops), 0, self.prof,
+                   side if events else None, ws2.data_ptr() if (events and ws2 is not None) else None,
+                   ws2.numel() if (events and ws2 is not None) else 0, events)
         with ops._Dev(dev):
             check(lib.osn_net_backward(ctypes.addressof(self.desc), ctypes.addressof(run), ops._stream(dev)), "osn_net_backward")
         return [grads[o:o + q.numel()].view_as(q) for o, q in zip(self.grad_off, p.params)]

@@ -101,6 +101,17 @@ def _ws(nbytes, dev):
     return buf
 
 
+def ws_on(nbytes, dev, raw_stream):
+    """The growing scratch buffer of (device, the given raw stream) -- for launches a C call places on another stream."""
+    nbytes = max(int(nbytes), 16)
+    key = (_idx(dev), raw_stream)
+    buf = _ws_pool.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
+        _ws_pool[key] = buf
+    return buf
+
+
 _size_cache = {}
 
 
@@ -826,6 +837,57 @@ def bn_backward(x, y, gy, mean, var, gamma, eps, relu, training, want_gres):
         check(lib.osn_bn_backward(_p(x), _p(y), _p(gy), _p(mean), _p(var), _p(gamma), float(eps), int(bool(relu)),
                                   int(bool(training)), _p(gx), _p(gres), _p(ggamma), _p(gbeta), n, c, _p(ws),
                                   ws.numel(), _stream(dev)), "osn_bn_backward")
+    return gx, gres, ggamma, gbeta
+
+
+def _row_view(t, c, name):
+    """(pointer, row stride in floats) of a float32 [n, c] matrix that may be a column window of a wider one."""
+    if t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != c or (t.shape[0] > 1 and t.stride(1) != 1):
+        raise TypeError("%s must be a float32 [n, %d] matrix with unit column stride" % (name, c))
+    ld = t.stride(0) if t.shape[0] > 1 else max(c, t.stride(0))
+    if ld % 4 or t.data_ptr() % 16:
+        raise ValueError("%s: row stride and first element must be 16-byte aligned" % name)
+    return t.data_ptr(), ld
+
+
+def bn_forward_train2(x, gamma, beta, eps, residual, relu, running_mean, running_var, momentum, y2):
+    """bn_forward_train that ALSO stores the result into `y2`, a [n, c] column window of a wider matrix (ME.cat written in
+    place by its producer).  -> (y, mean, var)."""
+    dev = x.device
+    lib = _prep(dev)
+    x = _f32c(x, "x")
+    n, c = x.shape
+    if residual is not None:
+        residual = _f32c(residual, "residual")
+    p2, ld2 = _row_view(y2, c, "y2")
+    mv = torch.empty((2, c), dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    ws = _ws(_cached("osn_bn_ws_bytes", n, c), dev)
+    with _Dev(dev):
+        check(lib.osn_bn_forward_train2(_p(x), n, c, _p(gamma), _p(beta), float(eps), _p(residual), int(bool(relu)),
+                                        float(momentum), _p(mv[0]), _p(mv[1]), _p(running_mean), _p(running_var), _p(y), p2, ld2,
+                                        _p(ws), ws.numel(), _stream(dev)), "osn_bn_forward_train2")
+    return y, mv[0], mv[1]
+
+
+def bn_backward_multi(x, y, gys, mean, var, gamma, eps, relu, training, want_gres):
+    """bn_backward whose incoming gradient is the SUM of the matrices in `gys` (1 .. 3, each possibly a column window of a
+    wider matrix): the sum is formed while reading."""
+    dev = x.device
+    lib = _prep(dev)
+    n, c = x.shape
+    views = [_row_view(g, c, "grad_output[%d]" % i) for i, g in enumerate(gys)]
+    ptrs = (ctypes.c_void_p * len(views))(*[v[0] for v in views])
+    lds = (ctypes.c_int64 * len(views))(*[v[1] for v in views])
+    gx = torch.empty_like(x)
+    gres = torch.empty_like(x) if want_gres else None
+    ggamma = torch.empty(c, dtype=torch.float32, device=dev)
+    gbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    ws = _ws(_cached("osn_bn_ws_bytes", n, c), dev)
+    with _Dev(dev):
+        check(lib.osn_bn_backward_multi(_p(x), _p(y), ptrs, lds, len(views), _p(mean), _p(var), _p(gamma), float(eps),
+                                        int(bool(relu)), int(bool(training)), _p(gx), _p(gres), _p(ggamma), _p(gbeta), n, c,
+                                        _p(ws), ws.numel(), _stream(dev)), "osn_bn_backward_multi")
     return gx, gres, ggamma, gbeta
 
 

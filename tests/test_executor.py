@@ -58,7 +58,8 @@ def test_program_covers_the_module_tree(arch):
 def test_planned_kernels_are_the_per_module_choice():
     """functional.SparseConvFunction's dispatch, restated: tile-list kernels from TL_FWD_MIN_ROWS table rows on, the
     split-bf16 output-stationary kernel below, the stem kernel for 3 -> 32, pair-array weight gradient on every
-    3^3 / 2^3 map, the table weight gradient for the stem and the 1x1 convs."""
+    3^3 / 2^3 map and (identity map) for the 1x1 shortcuts up to 128 channels, the table weight gradient for the stem
+    and the 96 -> 768 head."""
     from openscene_amd import executor as E
     from openscene_amd import functional as F_
     from openscene_amd.mink_unet import mink_unet
@@ -71,7 +72,7 @@ def test_planned_kernels_are_the_per_module_choice():
         want_f = "tl" if (o["K"] > 1 and n_out >= F_.TL_FWD_MIN_ROWS) else "x6"
         want_d = "tl" if (o["K"] > 1 and n_in >= F_.TL_FWD_MIN_ROWS) else "x6"
         assert (kf, kd) == (want_f, want_d), (i, o, kf, kd)
-        assert kw == ("wgrad_tl" if o["K"] > 1 else "wgrad")
+        assert kw == ("wgrad_tl" if (o["K"] > 1 or max(o["cin"], o["cout"]) <= 128) else "wgrad")
     assert sum(k[1] == "tl" for k in ks) == 5 and sum(k[2] == "tl" for k in ks) == 5      # the 10 tile-list launches of a step
 
 

@@ -23,6 +23,46 @@ def rel(got, ref):
     return (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
 
 
+# ------------------------------------------------------------------ the executor's batch-norm entry points
+@pytest.mark.parametrize("n,c,nsrc", [(700, 256, 3), (3052, 128, 2), (4096, 32, 1), (4097, 32, 3), (47618, 96, 3), (20000, 64, 2)])
+def test_batchnorm_summed_gradient_sources_and_second_destination(n, c, nsrc):
+    """osn_bn_forward_train2 (the result also lands in a column window of a wider matrix: ME.cat in place) and
+    osn_bn_backward_multi (incoming gradient = sum of up to three matrices, column windows included), on both sides of
+    the 4096-row switch between the single-launch and the three-launch kernels, vs float64 torch."""
+    from openscene_amd import ops
+    g = torch.Generator().manual_seed(n + c + nsrc)
+    x = torch.randn(n, c, generator=g) * 1.7 - 0.3
+    res = torch.randn(n, c, generator=g)
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.rand(c, generator=g) - 0.5
+    wide = torch.randn(n, c + 24, generator=g)                        # one source is columns [8, 8 + c) of this
+    srcs = [wide[:, 8:8 + c]] + [torch.randn(n, c, generator=g) for _ in range(nsrc - 1)]
+    d = dev()
+    bn = torch.nn.BatchNorm1d(c).double()
+    bn.weight.data.copy_(gamma); bn.bias.data.copy_(beta)
+    x64 = x.double().requires_grad_(True)
+    r64 = res.double().requires_grad_(True)
+    y_ref = torch.relu(bn(x64) + r64)
+    y_ref.backward(sum(t.double() for t in srcs))
+    rm = torch.zeros(c, device=d); rv = torch.ones(c, device=d)
+    cat = torch.full((n, c + 40), -7.0, device=d)
+    y, mean, var = ops.bn_forward_train2(x.to(d), gamma.to(d), beta.to(d), 1e-5, res.to(d), True, rm, rv, 0.1, cat[:, 16:16 + c])
+    assert rel(y, y_ref) < 2e-5
+    assert torch.equal(cat[:, 16:16 + c], y) and bool((cat[:, :16] == -7).all()) and bool((cat[:, 16 + c:] == -7).all())
+    assert rel(rm, bn.running_mean) < 1e-5 and rel(rv, bn.running_var) < 1e-5
+    wide_d = wide.to(d)
+    gsrc = [wide_d[:, 8:8 + c]] + [t.to(d) for t in srcs[1:]]
+    gx, gres, ggamma, gbeta = ops.bn_backward_multi(x.to(d), y, gsrc, mean, var, gamma.to(d), 1e-5, True, True, True)
+    assert rel(gx, x64.grad) < 5e-5 and rel(gres, r64.grad) < 2e-6
+    assert rel(ggamma, bn.weight.grad) < 5e-5 and rel(gbeta, bn.bias.grad) < 5e-5
+    # one source, contiguous: bitwise the plain entry point
+    one = sum(t for t in srcs).to(d).contiguous()
+    a = ops.bn_backward(x.to(d), y, one, mean, var, gamma.to(d), 1e-5, True, True, True)
+    b = ops.bn_backward_multi(x.to(d), y, [one], mean, var, gamma.to(d), 1e-5, True, True, True)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
 # ------------------------------------------------------------------ elementwise (a11)
 @pytest.mark.parametrize("n,ca,cb", [(1, 4, 4), (37, 32, 96), (3052, 128, 128), (100999, 96, 32), (700, 8, 256)])
 def test_relu_add_cat_kernels(n, ca, cb):

@@ -55,6 +55,8 @@ hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipSt
 }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(0x10); return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(0x10); return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { add("WAIT"); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { add("EVENT"); return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
