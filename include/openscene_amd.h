@@ -314,7 +314,7 @@ int osn_bn_apply2(const float* x, const float* mean, const float* var, const flo
                   const float* beta, float eps, const float* residual, int relu, float* y,
                   float* y2, int64_t ld2, int64_t n, int c, osn_stream_t stream);
 /* osn_bn_forward_train with the second destination of osn_bn_apply2.  Maps of at most 4096 rows (the deep U-Net levels)
- * run as ONE launch (statistics and apply from registers); osn_bn_forward_train / osn_bn_backward[_multi] do the same. */
+ * run as ONE launch (statistics and apply from registers); osn_bn_forward_train does the same.                         */
 int osn_bn_forward_train2(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
                           const float* residual, int relu, float momentum, float* mean, float* var,
                           float* running_mean, float* running_var, float* y, float* y2, int64_t ld2,
@@ -448,7 +448,7 @@ typedef struct osn_net_buf { int32_t level, channels; } osn_net_buf;
 typedef struct osn_net_desc {
     int32_t n_ops, n_bufs, n_bns, n_weights, n_maps, n_levels;
     int32_t tl_min_rows;         /* tile-list forward / input gradient on tables of at least this many rows       */
-    int32_t tl_small_rows;       /* ... and on tables of at most this many rows (0 = never): the deep U-Net levels       */
+    int32_t reserved;
     const osn_net_op* ops;
     const osn_net_buf* bufs;
 } osn_net_desc;

@@ -258,10 +258,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // ---------------------------------------------------------------------------------------------------------------
 // Small maps (the deep U-Net levels: 700 - 3 000 rows): the three launches of a training-mode batch norm (column sums,
-// finalize, apply) and of its backward are each a few microseconds of launch latency around almost no work.  Up to
-// SB_MAX_ROWS rows one workgroup of 1024 threads owns 8 columns, keeps its rows IN REGISTERS between the statistics and
-// the apply pass (x is read once), and reduces with wave shuffles + one LDS round in a fixed order (deterministic).
-// Same formulas as the three-kernel path (fp64 sums, fp32 mean / var / apply).
+// finalize, apply) are each a few microseconds of launch latency around almost no work.  Up to SB_MAX_ROWS rows one
+// workgroup of 1024 threads owns 8 columns, keeps its rows IN REGISTERS between the statistics and the apply pass (x is
+// read once), and reduces with wave shuffles + one LDS round in a fixed order (deterministic).  Same formulas as the
+// three-kernel path (fp64 sums, fp32 mean / var / apply).  Measured (profiles/r03_s3): 14.5 us per launch against
+// ~15 us for the three launches it replaces -- a tie in GPU time, two launches (and their gaps) fewer.  The same design
+// for the BACKWARD pass (x, y and up to three gradient sources per row in registers) was slower (24 us against 14 us)
+// and is not kept.
 constexpr int SB_THREADS = 1024, SB_RL = 512, SB_PER = 8, SB_COLS = 8;
 constexpr int SB_MAX_ROWS = SB_RL * SB_PER;       // 4096
 
@@ -361,66 +364,6 @@ __global__ __launch_bounds__(SB_THREADS) void bn_small_fwd_kernel(const float* _
         }
         *reinterpret_cast<float4*>(y + int64_t(r) * c + col) = o;
         if (y2) *reinterpret_cast<float4*>(y2 + int64_t(r) * ld2 + col) = o;
-    }
-}
-
-__global__ __launch_bounds__(SB_THREADS) void bn_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                                  const GySrc gy, const float* __restrict__ mean,
-                                                                  const float* __restrict__ var, const float* __restrict__ gamma,
-                                                                  float eps, int relu, int training, float* __restrict__ gx,
-                                                                  float* __restrict__ gres, float* __restrict__ ggamma,
-                                                                  float* __restrict__ gbeta, int n, int c) {
-    const int tid = threadIdx.x, cl = tid & 1, rl = tid >> 1;
-    const int col = blockIdx.x * SB_COLS + cl * 4;
-    const bool con = col < c;
-    const int cc = con ? col : 0;
-    const float4 mu = ld4(mean + cc), vv = ld4(var + cc), ga = ld4(gamma + cc);
-    const float4 is = make_float4(1.f / sqrtf(vv.x + eps), 1.f / sqrtf(vv.y + eps), 1.f / sqrtf(vv.z + eps),
-                                  1.f / sqrtf(vv.w + eps));
-    float4 xv[SB_PER], g[SB_PER];
-    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < SB_PER; ++j) {
-        const int r = rl + SB_RL * j;
-        const bool ok = con && r < n;
-        const int64_t rr = ok ? r : 0;
-        xv[j] = ld4(x + rr * c + cc);
-        g[j] = gy_load(gy, rr, cc);
-        if (relu) {
-            const float4 yv = ld4(y + rr * c + cc);
-            g[j].x = yv.x > 0.f ? g[j].x : 0.f; g[j].y = yv.y > 0.f ? g[j].y : 0.f;
-            g[j].z = yv.z > 0.f ? g[j].z : 0.f; g[j].w = yv.w > 0.f ? g[j].w : 0.f;
-        }
-        if (ok) {
-            s[0] += g[j].x; s[1] += g[j].y; s[2] += g[j].z; s[3] += g[j].w;
-            s[4] += double(g[j].x) * ((xv[j].x - mu.x) * is.x); s[5] += double(g[j].y) * ((xv[j].y - mu.y) * is.y);
-            s[6] += double(g[j].z) * ((xv[j].z - mu.z) * is.z); s[7] += double(g[j].w) * ((xv[j].w - mu.w) * is.w);
-        }
-    }
-    sb_block_sums(s, tid, cl);
-    if (!con) return;
-    const float sg[4] = {float(s[0]), float(s[1]), float(s[2]), float(s[3])};
-    const float sx[4] = {float(s[4]), float(s[5]), float(s[6]), float(s[7])};
-    if (rl == 0) {
-        *reinterpret_cast<float4*>(gbeta + col) = make_float4(sg[0], sg[1], sg[2], sg[3]);
-        *reinterpret_cast<float4*>(ggamma + col) = make_float4(sx[0], sx[1], sx[2], sx[3]);
-    }
-    const float inv_n = 1.f / float(n);
-#pragma unroll
-    for (int j = 0; j < SB_PER; ++j) {
-        const int r = rl + SB_RL * j;
-        if (r >= n) continue;
-        if (gres) *reinterpret_cast<float4*>(gres + int64_t(r) * c + col) = g[j];
-        float4 o;
-        if (training) {
-            o.x = ga.x * is.x * (g[j].x - sg[0] * inv_n - (xv[j].x - mu.x) * is.x * sx[0] * inv_n);
-            o.y = ga.y * is.y * (g[j].y - sg[1] * inv_n - (xv[j].y - mu.y) * is.y * sx[1] * inv_n);
-            o.z = ga.z * is.z * (g[j].z - sg[2] * inv_n - (xv[j].z - mu.z) * is.z * sx[2] * inv_n);
-            o.w = ga.w * is.w * (g[j].w - sg[3] * inv_n - (xv[j].w - mu.w) * is.w * sx[3] * inv_n);
-        } else {
-            o.x = ga.x * is.x * g[j].x; o.y = ga.y * is.y * g[j].y; o.z = ga.z * is.z * g[j].z; o.w = ga.w * is.w * g[j].w;
-        }
-        *reinterpret_cast<float4*>(gx + int64_t(r) * c + col) = o;
     }
 }
 
@@ -536,12 +479,6 @@ extern "C" int osn_bn_backward_multi(const float* x, const float* y, const float
                     "osn_bn_backward: gradient source %d needs a 16-byte aligned pointer and a row stride >= c, %% 4 == 0", j);
         src.p[i] = gy[j];
         src.ld[i] = gy_ld[j];
-    }
-    if (n <= SB_MAX_ROWS) {               // small map: one launch (sums, gamma / beta gradients and the apply pass)
-        hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(unsigned(cdiv(c, SB_COLS))), dim3(SB_THREADS), 0, st, x, y, src, mean, var,
-                           gamma, eps, relu, training, gx, gres, ggamma, gbeta, int(n), c);
-        OSN_LAUNCH_CHECK();
-        return OSN_OK;
     }
     ColReducePlan p = plan_colreduce(n, c);
     const size_t need = size_t(p.n_rb) * 2 * size_t(c) * 8;

@@ -112,7 +112,7 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
         if (stem_eligible(o.K, o.cin, o.cout)) {
             OSN_REQUIRE(!o.transposed, OSN_E_ARG, "osn_net: op %d: transposed stem", i);
             L.fwd_k[i] = OSN_NET_K_STEM;
-        } else if (o.K > 1 && tl_eligible(o.K, o.cin, o.cout, n_in) && (n_out >= net->tl_min_rows || n_out <= net->tl_small_rows)) {
+        } else if (o.K > 1 && tl_eligible(o.K, o.cin, o.cout, n_in) && n_out >= net->tl_min_rows) {
             L.fwd_k[i] = OSN_NET_K_TL;
             L.images[i] |= OSN_NET_IMG_TL_FWD;
             need_ws(osn_spconv_fwd_tl_ws_bytes(n_out, o.K, o.cout, osn_tile_rows(n_out)));
@@ -126,8 +126,7 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
         if (!training) continue;
         // ---- input gradient: a convolution of the output gradient with the transposed weights, [n_in, cin]
         if (o.need_dgrad) {
-            if (o.K > 1 && tl_eligible(o.K, o.cout, o.cin, n_out) && tl_eligible(o.K, o.cin, o.cout, n_in) &&
-                (n_in >= net->tl_min_rows || n_in <= net->tl_small_rows)) {
+            if (o.K > 1 && tl_eligible(o.K, o.cout, o.cin, n_out) && tl_eligible(o.K, o.cin, o.cout, n_in) && n_in >= net->tl_min_rows) {
                 L.dgrad_k[i] = OSN_NET_K_TL;
                 L.images[i] |= OSN_NET_IMG_TL_DGRAD;
                 need_ws(osn_spconv_fwd_tl_ws_bytes(n_in, o.K, o.cin, osn_tile_rows(n_in)));

@@ -386,17 +386,26 @@ struct WgJobs {
 };
 __global__ __launch_bounds__(256) void wgrad_tl_reduce_batch_kernel(const WgJobs jobs) {
     const osn_wgrad_job& jb = jobs.j[blockIdx.y];
-    const float* __restrict__ partial = jb.partial;
+    const float4* __restrict__ partial = reinterpret_cast<const float4*>(jb.partial);
     const int2* __restrict__ range = static_cast<const int2*>(jb.range);
-    float* __restrict__ out = jb.gW;
-    const int64_t per_k = int64_t(jb.cin) * jb.cout;
-    const int64_t total = int64_t(jb.K) * per_k;
-    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
-        const int k = int(e / per_k);
-        const int64_t r = e - int64_t(k) * per_k;
+    float4* __restrict__ out = reinterpret_cast<float4*>(jb.gW);
+    const int64_t per_k4 = int64_t(jb.cin) * jb.cout / 4;               // cin % 4 == 0 and cout % 4 == 0
+    const int64_t total4 = int64_t(jb.K) * per_k4;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total4; e += int64_t(gridDim.x) * blockDim.x) {
+        const int k = int(e / per_k4);
+        const int64_t r = e - int64_t(k) * per_k4;
         const int t0 = range ? range[k].x : 0, t1 = range ? range[k].y : jb.ident_items;
-        float s = 0.f;
-        for (int t = t0; t < t1; ++t) s += partial[int64_t(t) * per_k + r];
+        // item order, as osn_spconv_wgrad_tl sums: s = ((0 + p[t0]) + p[t0 + 1]) + ...; two loads in flight per round
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int t = t0;
+        for (; t + 1 < t1; t += 2) {
+            const float4 a = partial[int64_t(t) * per_k4 + r], b = partial[int64_t(t + 1) * per_k4 + r];
+            s.x = (s.x + a.x) + b.x; s.y = (s.y + a.y) + b.y; s.z = (s.z + a.z) + b.z; s.w = (s.w + a.w) + b.w;
+        }
+        if (t < t1) {
+            const float4 a = partial[int64_t(t) * per_k4 + r];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
         out[e] = s;
     }
 }
@@ -574,7 +583,7 @@ extern "C" int osn_wgrad_tl_reduce_batch(const osn_wgrad_job* jobs, int n_jobs, 
     int nb = 0;
     auto flush = [&]() -> int {
         if (nb == 0) return OSN_OK;
-        hipLaunchKernelGGL(wgrad_tl_reduce_batch_kernel, dim3(128, unsigned(nb)), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(wgrad_tl_reduce_batch_kernel, dim3(96, unsigned(nb)), dim3(256), 0, st, b);
         OSN_LAUNCH_CHECK();
         nb = 0;
         return OSN_OK;

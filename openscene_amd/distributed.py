@@ -75,12 +75,33 @@ class FlatGradAllReduce(object):
             self._broadcast(self.buffers)
             self._broadcast(self.int_buffers)
 
+    def _common_base(self):
+        """The one contiguous fp32 tensor all gradients are views of (same on every rank: the executor's layout is a function
+        of the module tree), or None."""
+        base = None
+        for p in self.params:
+            g = p.grad
+            b = None if g is None else g._base
+            if b is None or b.dim() != 1 or not b.is_contiguous() or b.dtype != self.flat.dtype or (base is not None and b is not base):
+                return None
+            base = b
+        return base
+
     def reduce_gradients(self):
         """After backward: p.grad <- mean over ranks, as views of the flat buffer (no copy back).
         A parameter without a gradient on this rank contributes zeros (DDP with find_unused_parameters) and, like
         there, ends up with the (possibly all-zero) mean as its gradient: an optimizer with momentum / weight decay
         then still advances its state for a parameter NO rank used -- a documented deviation from a single-process
         run, where such a parameter keeps grad None (no parameter of the MinkUNet family is unused)."""
+        # the network executor (openscene_amd/executor.py) hands every gradient out as a view of ONE flat buffer it wrote
+        # in place: exchange that buffer itself -- no gather copy, the optimizer keeps reading the same views
+        base = self._common_base()
+        if base is not None:
+            if self.collectives:
+                if self.world > 1:
+                    base.div_(self.world)
+                dist.all_reduce(base, group=self.group)
+            return
         grads = []
         for p, v in zip(self.params, self.views):
             if p.grad is None:

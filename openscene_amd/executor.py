@@ -21,9 +21,6 @@ from . import _lib, ops
 from ._lib import check
 
 ENABLED = os.environ.get("OSN_EXECUTOR", "1") != "0"
-# tile-list forward / input gradient ALSO on tables of at most this many rows (the deep U-Net levels, where the
-# output-stationary kernel's 32-channel stages are latency-bound); 0 = only from functional.TL_FWD_MIN_ROWS rows on
-TL_SMALL_MAX_ROWS = int(os.environ.get("OSN_TL_SMALL_MAX_ROWS", "0"))
 # weight gradients of the backward pass on a second stream beside the input-gradient / batch-norm chain (bitwise the same
 # gradients; the GPU is the bottleneck since the executor took the host out of the way, and the deep levels' launches
 # leave most compute units idle)
@@ -49,7 +46,7 @@ K_NAMES = {0: "none", 1: "stem", 2: "tl", 3: "x6", 4: "wgrad_tl", 5: "wgrad"}
 class _Desc(ctypes.Structure):
     _fields_ = [("n_ops", ctypes.c_int32), ("n_bufs", ctypes.c_int32), ("n_bns", ctypes.c_int32), ("n_weights", ctypes.c_int32),
                 ("n_maps", ctypes.c_int32), ("n_levels", ctypes.c_int32), ("tl_min_rows", ctypes.c_int32),
-                ("tl_small_rows", ctypes.c_int32), ("ops", ctypes.c_void_p), ("bufs", ctypes.c_void_p)]
+                ("reserved", ctypes.c_int32), ("ops", ctypes.c_void_p), ("bufs", ctypes.c_void_p)]
 
 
 class _Plan(ctypes.Structure):
@@ -217,7 +214,6 @@ class UNetExecutor:
     def _plan_query(self, lib, rows, training):
         from . import functional as F_
         self.desc.tl_min_rows = int(F_.TL_FWD_MIN_ROWS)
-        self.desc.tl_small_rows = TL_SMALL_MAX_ROWS
         self._rows[:len(rows)] = rows
         check(lib.osn_net_plan_query(ctypes.addressof(self.desc), _ptr(self._rows), int(training), ctypes.addressof(self._plan)),
               "osn_net_plan_query")

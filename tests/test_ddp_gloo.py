@@ -241,3 +241,41 @@ def test_flat_exchange_unused_parameter_and_buffer_sync(tmp_path):
     assert any(not torch.equal(a["buf_before"][n], b["buf_before"][n]) for n in a["buf"] if "running" in n)   # local statistics ...
     for n in a["buf"]:
         assert torch.equal(a["buf"][n], b["buf"][n]) and torch.equal(a["buf"][n], a["buf_before"][n])         # ... until sync_buffers
+
+
+def _worker_flat_views(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    from openscene_amd.distributed import FlatGradAllReduce
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    ex = FlatGradAllReduce(net)
+    # gradients handed out as views of ONE flat buffer with 4-float-aligned slices (what the network executor does)
+    params = list(net.parameters())
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + 3) // 4 * 4
+    flat = torch.full((off,), float("nan"))                 # padding holds garbage: it is exchanged but never read
+    for p, o in zip(params, offs):
+        v = flat[o:o + p.numel()].view_as(p)
+        v.copy_(torch.full_like(p, float(rank + 1)) * (o + 1))
+        p.grad = v
+    ptr = flat.data_ptr()
+    ex.reduce_gradients()
+    assert all(p.grad._base is flat and p.grad.data_ptr() == ptr + 4 * o for p, o in zip(params, offs)), "gradients were copied"
+    torch.save({"g": [p.grad.clone() for p in params], "offs": offs}, os.path.join(out_dir, "v%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_exchange_reduces_the_executors_gradient_buffer_in_place(tmp_path):
+    """Gradients that already are views of one flat buffer (the network executor's layout) are all-reduced in place:
+    no gather copy, p.grad keeps pointing into that buffer, value = mean over ranks."""
+    mp.spawn(_worker_flat_views, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(tmp_path, "v0.pt"))
+    b = torch.load(os.path.join(tmp_path, "v1.pt"))
+    for ga, gb, o in zip(a["g"], b["g"], a["offs"]):
+        assert torch.equal(ga, gb) and torch.equal(ga, torch.full_like(ga, 1.5 * (o + 1)))
