@@ -504,12 +504,13 @@ typedef struct osn_net_run {
     int32_t first_op, end_op;    /* ops [first_op, end_op) are executed                                           */
     int32_t reserved;
     osn_prof_t* prof;            /* nullable                                                                      */
-    /* backward only, all nullable: the weight gradients (needed only at the end of the pass) run on `side_stream`
-     * beside the input-gradient / batch-norm chain of the main stream; the pass forks after each stage's batch-norm
-     * backward and joins before its batched reduction, so nothing outside sees the second stream.                  */
+    /* all nullable: work that is off the main dependency chain runs on `side_stream` -- in both passes the BasicBlock
+     * shortcut stages (1x1 conv + batch norm, beside conv1 - BN - conv2), in the backward pass also every weight
+     * gradient (needed only at the end of the pass).  The passes fork and join with events of `events`, so nothing
+     * outside sees the second stream; results are bitwise those of a single stream.                               */
     osn_stream_t side_stream;
     void* ws_side; uint64_t ws_side_bytes;     /* scratch of the side stream's launches (same size rule as ws)       */
-    osn_events_t* events;        /* osn_events_create(n_ops + 1)                                                  */
+    osn_events_t* events;        /* osn_events_create(2 * n_ops + 2)                                              */
 } osn_net_run;
 int osn_net_plan_query(const osn_net_desc* net, const int64_t* level_rows, int training, osn_net_plan* plan);
 int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, osn_stream_t stream);

@@ -46,6 +46,7 @@ struct Layout {
     std::vector<uint64_t> x_off, stat_off, y_off, gx_off, gres_off, gin_off, gpart_off;
     std::vector<int32_t> fwd_k, dgrad_k, wgrad_k, images;
     std::vector<int32_t> producer;       // buffer -> op with dst == buffer
+    std::vector<uint8_t> side;           // stage may run beside the main chain: a block's 1x1 shortcut (conv + BN), see below
     uint64_t fwd_bytes = 0, bwd_bytes = 0, ws_bytes = 0;
 };
 
@@ -152,6 +153,19 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
             L.wgrad_k[i] = OSN_NET_K_WGRAD;
             need_ws(osn_spconv_wgrad_ws_bytes(n_out, o.K, o.cin, o.cout));
         }
+    }
+    // A BasicBlock's shortcut (1x1 conv + batch norm without ReLU, models/resnet_base.py:101-107) only meets the main chain
+    // again as the residual of the block's last batch norm: it can run on a second stream beside conv1 - BN - conv2.
+    L.side.assign(n, 0);
+    for (int i = 0; i < n; ++i) {
+        const osn_net_op& o = net->ops[i];
+        if (o.K != 1 || o.bn < 0 || o.relu || o.src < 0 || o.dst < 0 || o.copy_buf >= 0 || o.res >= 0) continue;
+        int as_res = 0, other = 0;
+        for (int j = 0; j < n; ++j) {
+            if (net->ops[j].res == o.dst) ++as_res;
+            if (net->ops[j].src == o.dst || net->ops[j].copy_buf == o.dst) ++other;
+        }
+        L.side[i] = (as_res == 1 && other == 0) ? 1 : 0;
     }
     for (int bf = 0; bf < net->n_bufs; ++bf) {
         L.y_off[bf] = f;
@@ -284,10 +298,26 @@ extern "C" int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* A = static_cast<char*>(run->fwd_arena);
     const int64_t* rows = run->level_rows;
+    // optional second stream: the blocks' shortcut stages run beside conv1 - BN - conv2 (events: [i] fork, [n_ops + 1 + i] done)
+    Events* evs = reinterpret_cast<Events*>(run->events);
+    hipStream_t side = static_cast<hipStream_t>(run->side_stream);
+    const bool forked = side && side != st && evs && int(evs->ev.size()) >= 2 * net->n_ops + 2 && run->ws_side &&
+                        run->ws_side_bytes >= L.ws_bytes;
+    std::vector<uint8_t> pending(size_t(net->n_ops), 0);       // side stages the main stream has not joined yet
     for (int i = run->first_op; i < run->end_op; ++i) {
         const osn_net_op& o = net->ops[i];
         const int64_t n_in = rows[o.lvl_in], n_out = rows[o.lvl_out];
         const osn_net_weight& w = run->weights[o.weight];
+        const bool on_side = forked && L.side[i];
+        if (on_side) {                                         // fork: everything queued so far (the producer of src) is visible
+            OSN_HIP(hipEventRecord(evs->ev[i], st));
+            OSN_HIP(hipStreamWaitEvent(side, evs->ev[i], 0));
+        }
+        osn_net_run side_run = *run;                           // scratch of the stream the stage runs on
+        if (on_side) { side_run.ws = run->ws_side; side_run.ws_bytes = run->ws_side_bytes; }
+        const osn_net_run* r = on_side ? &side_run : run;
+        const osn_stream_t sstream = on_side ? run->side_stream : stream;
+
         const float* in = o.src < 0 ? run->input : reinterpret_cast<const float*>(A + L.y_off[o.src]);
         float* x = o.dst < 0 ? run->output : reinterpret_cast<float*>(A + L.x_off[i]);
         OSN_REQUIRE(x, OSN_E_ARG, "osn_net_forward: op %d writes the network output but run->output is null", i);
@@ -297,12 +327,19 @@ extern "C" int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, 
             v = view_of(run->maps[o.map], o.transposed != 0);
         }
         {
-            Bracket br(run->prof, i, 0, st);
+            Bracket br(run->prof, i, 0, on_side ? side : st);
             rc = run_conv(L.fwd_k[i], in, n_in, x, n_out, o.K, o.cin, o.cout, w.W, w.x6_fwd, w.tl_fwd, v.nbr_f, v.tf_rows, v.tf_tbl,
-                          v.tf_g, v.tl_f, v.tl_f_rows, v.tl_f_bm, run, stream, i);
+                          v.tf_g, v.tl_f, v.tl_f_rows, v.tl_f_bm, r, sstream, i);
         }
         if (rc) return rc;
         if (o.bn < 0) continue;
+        if (o.res >= 0 && forked) {                            // join: the residual may come from a side stage
+            const int p = L.producer[o.res];
+            if (p >= 0 && pending[p]) {
+                OSN_HIP(hipStreamWaitEvent(st, evs->ev[net->n_ops + 1 + p], 0));
+                pending[p] = 0;
+            }
+        }
         const osn_net_bn& bn = run->bns[o.bn];
         float* y = reinterpret_cast<float*>(A + L.y_off[o.dst]);
         const float* res = o.res >= 0 ? reinterpret_cast<const float*>(A + L.y_off[o.res]) : nullptr;
@@ -315,14 +352,19 @@ extern "C" int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, 
         if (run->training) {
             float* mv = reinterpret_cast<float*>(A + L.stat_off[i]);
             rc = osn_bn_forward_train2(x, n_out, o.cout, bn.gamma, bn.beta, bn.eps, res, o.relu, bn.momentum, mv, mv + o.cout,
-                                       bn.running_mean, bn.running_var, y, y2, ld2, run->ws, size_t(run->ws_bytes), stream);
+                                       bn.running_mean, bn.running_var, y, y2, ld2, r->ws, size_t(r->ws_bytes), sstream);
         } else {
             OSN_REQUIRE(bn.running_mean && bn.running_var, OSN_E_ARG, "osn_net_forward: op %d: evaluation-mode batch norm without running statistics", i);
-            rc = osn_bn_apply2(x, bn.running_mean, bn.running_var, bn.gamma, bn.beta, bn.eps, res, o.relu, y, y2, ld2, n_out, o.cout, stream);
+            rc = osn_bn_apply2(x, bn.running_mean, bn.running_var, bn.gamma, bn.beta, bn.eps, res, o.relu, y, y2, ld2, n_out, o.cout, sstream);
         }
         if (rc) return rc;
+        if (on_side) {
+            OSN_HIP(hipEventRecord(evs->ev[net->n_ops + 1 + i], side));
+            pending[i] = 1;
+        }
     }
-    (void)st;
+    for (int i = run->first_op; i < run->end_op; ++i)          // a side stage nobody consumed inside the executed range
+        if (pending[i]) OSN_HIP(hipStreamWaitEvent(st, evs->ev[net->n_ops + 1 + i], 0));
     return OSN_OK;
 }
 
@@ -342,8 +384,12 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
     // optional second stream for the weight gradients
     Events* evs = reinterpret_cast<Events*>(run->events);
     hipStream_t side = static_cast<hipStream_t>(run->side_stream);
-    const bool forked = side && side != st && evs && int(evs->ev.size()) > net->n_ops && run->ws_side &&
+    const bool forked = side && side != st && evs && int(evs->ev.size()) >= 2 * net->n_ops + 2 && run->ws_side &&
                         run->ws_side_bytes >= L.ws_bytes;
+    std::vector<uint8_t> pending(size_t(net->n_ops), 0);       // side stages whose input gradient the main stream has not joined
+    osn_net_run side_run = *run;
+    side_run.ws = run->ws_side;
+    side_run.ws_bytes = run->ws_side_bytes;
     osn_stream_t wstream = forked ? run->side_stream : stream;
     void* wws = forked ? run->ws_side : run->ws;
     const size_t wws_bytes = size_t(forked ? run->ws_side_bytes : run->ws_bytes);
@@ -361,15 +407,31 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
         } else {
             for (int j = i + 1; j < run->end_op && ng < 4; ++j) {
                 const osn_net_op& c = net->ops[j];
-                if (c.src == o.dst && c.need_dgrad) { gsrc[ng] = reinterpret_cast<const float*>(B + L.gin_off[j]); gld[ng] = c.cin; ++ng; }
+                bool from_j = false;
+                if (c.src == o.dst && c.need_dgrad) { gsrc[ng] = reinterpret_cast<const float*>(B + L.gin_off[j]); gld[ng] = c.cin; ++ng; from_j = true; }
                 if (ng < 4 && c.res == o.dst) { gsrc[ng] = reinterpret_cast<const float*>(B + L.gres_off[j]); gld[ng] = c.cout; ++ng; }
                 if (ng < 4 && o.copy_buf >= 0 && c.src == o.copy_buf && c.need_dgrad) {
-                    gsrc[ng] = reinterpret_cast<const float*>(B + L.gin_off[j]) + o.copy_col; gld[ng] = c.cin; ++ng;
+                    gsrc[ng] = reinterpret_cast<const float*>(B + L.gin_off[j]) + o.copy_col; gld[ng] = c.cin; ++ng; from_j = true;
+                }
+                // an input gradient computed on the side stream (a shortcut stage): join before it is read.  (A stage that
+                // itself runs on the side stream never reads one: its only source is a residual gradient of the main stream.)
+                if (from_j && forked && L.side[j] && pending[j] != 2) {
+                    OSN_HIP(hipStreamWaitEvent(st, evs->ev[net->n_ops + 1 + j], 0));
+                    pending[j] = 2;
                 }
             }
             OSN_REQUIRE(ng >= 1 && ng <= 3, OSN_E_ARG, "osn_net_backward: the output of op %d has %s consumers inside the executed range (1 .. 3 supported)",
                         i, ng == 0 ? "no" : "more than three");
         }
+        // a shortcut stage runs entirely on the side stream (batch-norm backward, weight gradient, input gradient), behind the
+        // weight gradients queued there; fork: its one gradient source (a residual gradient) is in the main stream's past
+        const bool on_side = forked && L.side[i];
+        if (on_side) {
+            OSN_HIP(hipEventRecord(evs->ev[i], st));
+            OSN_HIP(hipStreamWaitEvent(side, evs->ev[i], 0));
+        }
+        const osn_net_run* r = on_side ? &side_run : run;
+        const osn_stream_t sstream = on_side ? run->side_stream : stream;
         const float* gx;
         if (o.bn >= 0) {
             const osn_net_bn& bn = run->bns[o.bn];
@@ -384,7 +446,7 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
             float* gres = o.res >= 0 ? reinterpret_cast<float*>(B + L.gres_off[i]) : nullptr;
             OSN_REQUIRE(bn.ggamma && bn.gbeta, OSN_E_ARG, "osn_net_backward: op %d: null batch-norm gradient pointers", i);
             rc = osn_bn_backward_multi(x, y, gsrc, gld, ng, mean, var, bn.gamma, bn.eps, o.relu, run->training, gxw, gres,
-                                       bn.ggamma, bn.gbeta, n_out, o.cout, run->ws, size_t(run->ws_bytes), stream);
+                                       bn.ggamma, bn.gbeta, n_out, o.cout, r->ws, size_t(r->ws_bytes), sstream);
             if (rc) return rc;
             gx = gxw;
         } else {
@@ -397,7 +459,7 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
         if (m) v = view_of(*m, o.transposed != 0);
         // ---- weight gradient (fork: the side stream sees everything the main stream has queued up to gx)
         OSN_REQUIRE(w.gW, OSN_E_ARG, "osn_net_backward: op %d: null weight-gradient pointer", i);
-        if (forked) {
+        if (forked && !on_side) {
             OSN_HIP(hipEventRecord(evs->ev[i], st));
             OSN_HIP(hipStreamWaitEvent(side, evs->ev[i], 0));
         }
@@ -419,10 +481,16 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
         // ---- input gradient
         if (o.need_dgrad) {
             float* gin = reinterpret_cast<float*>(B + L.gin_off[i]);
-            Bracket br(run->prof, i, 1, st);
-            rc = run_conv(L.dgrad_k[i], gx, n_out, gin, n_in, o.K, o.cout, o.cin, nullptr, w.x6_dgrad, w.tl_dgrad, v.nbr_b, v.tb_rows,
-                          v.tb_tbl, v.tb_g, v.tl_b, v.tl_b_rows, v.tl_b_bm, run, stream, i);
+            {
+                Bracket br(run->prof, i, 1, on_side ? side : st);
+                rc = run_conv(L.dgrad_k[i], gx, n_out, gin, n_in, o.K, o.cout, o.cin, nullptr, w.x6_dgrad, w.tl_dgrad, v.nbr_b, v.tb_rows,
+                              v.tb_tbl, v.tb_g, v.tl_b, v.tl_b_rows, v.tl_b_bm, r, sstream, i);
+            }
             if (rc) return rc;
+            if (on_side) {
+                OSN_HIP(hipEventRecord(evs->ev[net->n_ops + 1 + i], side));
+                pending[i] = 1;
+            }
         }
     }
     if (forked) {                                          // join: the reductions (and everything after the pass) see the side stream's work

@@ -24,10 +24,40 @@ def dispatches(db, pattern, n):
         print("%-60s %9.2f" % (k[:60], us))
 
 
+def per_stream(db, steps):
+    """Kernel time and launches per stream / queue (ms per step), and the union (busy time of the device)."""
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(rocpd_kernel_dispatch)").fetchall()]
+    key = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
+    print("# columns:", ",".join(cols))
+    rows = cur.execute("select %s, start, end from rocpd_kernel_dispatch order by start" % (key or "0")).fetchall()
+    tot = {}
+    for k, a, b in rows:
+        t = tot.setdefault(k, [0, 0.0])
+        t[0] += 1
+        t[1] += (b - a)
+    for k, (n, t) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+        print("%s %s: %.1f launches/step, %.3f ms/step" % (key, k, n / steps, t / steps / 1e6))
+    busy, cur_end = 0.0, None
+    cur_start = None
+    for _, a, b in rows:                      # union of the intervals
+        if cur_end is None or a > cur_end:
+            if cur_end is not None:
+                busy += cur_end - cur_start
+            cur_start, cur_end = a, b
+        else:
+            cur_end = max(cur_end, b)
+    if cur_end is not None:
+        busy += cur_end - cur_start
+    print("device busy (union of all kernels): %.3f ms/step; sum of kernels %.3f ms/step" % (busy / steps / 1e6, sum(t for _, t in tot.values()) / steps / 1e6))
+
+
 def main():
     db = sqlite3.connect(sys.argv[1])
     if len(sys.argv) > 3 and sys.argv[2] == "--dispatches":
         return dispatches(db, sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 64)
+    if len(sys.argv) > 2 and sys.argv[2] == "--streams":
+        return per_stream(db, float(sys.argv[3]) if len(sys.argv) > 3 else 1.0)
     steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
     cur = db.cursor()
     rows = cur.execute("select s.kernel_name, count(*), sum(d.end - d.start), min(d.end - d.start), max(d.end - d.start) "
