@@ -518,6 +518,34 @@ int osn_net_backward(const osn_net_desc* net, const osn_net_run* run, osn_stream
 osn_events_t* osn_events_create(int n);       /* n timing-free HIP events on the current device; null on failure   */
 void osn_events_destroy(osn_events_t* e);
 
+/* ---- every kernel map of a scene from one call ------------------------------------------------------- *
+ * Replaces the per-map calls behind [ME] CoordinateManager.kernel_map for the convolutions of one forward pass
+ * (models/mink_unet.py:47-113: a 5^3 map, five 3^3 maps, four 2^3 stride-2 maps + their transposes).  A job = one map
+ * with everything derived from it; null output pointers skip a product.  Jobs name the stream they run on (index into
+ * `streams`, [0] = the caller's stream): the maps of different levels are independent chains of latency-bound launches,
+ * so they run side by side; the call forks after what is queued on streams[0] (the coordinate pyramid) and joins before
+ * it returns.  ws[s] = scratch of stream s (osn_kmap_sort_ws_bytes of the largest table sorted there).  Tables are bit
+ * for bit those of osn_kmap_build[_self] / osn_kmap_transpose / osn_kmap_sort / osn_tile_lists_build / osn_pair_lists_build. */
+#define OSN_MAPS_MAX_STREAMS 4
+typedef struct osn_map_level {               /* one pyramid level (osn_coords_unique[_async])                     */
+    const int32_t* coords4; const uint64_t* keys; const int32_t* vals;
+    int64_t cap, rows;
+} osn_map_level;
+typedef struct osn_map_job {
+    int32_t lvl_in, lvl_out;     /* table of lvl_in probed at the coordinates of lvl_out                          */
+    int32_t ksize, scale;        /* kernel size, offset scale (dilation x tensor stride of the input map)         */
+    int32_t self_map;            /* 1: odd kernel over the table's own rows (osn_kmap_build_self; no nbr_bwd)     */
+    int32_t stream;              /* index into `streams`                                                          */
+    int32_t bm_fwd, bm_bwd;      /* tile rows of the lists (osn_tile_rows)                                        */
+    int32_t* nbr_fwd; int32_t* nbr_bwd; int64_t* counts;
+    int32_t* order_fwd; int32_t* sorted_fwd; uint32_t* gmask_fwd;
+    int32_t* order_bwd; int32_t* sorted_bwd; uint32_t* gmask_bwd;
+    void* tl_fwd; void* tl_bwd; void* pl_fwd;
+} osn_map_job;                               /* 128 bytes */
+int osn_maps_build(const osn_map_level* levels, int n_levels, const osn_map_job* jobs, int n_jobs,
+                   const osn_stream_t* streams, void* const* ws, const uint64_t* ws_bytes, int n_streams,
+                   osn_events_t* events);
+
 /* Launch timer for the executor (bench.py's roofline entry): HIP events recorded on the launch stream around the
  * convolution launches of selected stages.  tag = op * 4 + phase (0 forward, 1 input gradient, 2 weight gradient).
  * osn_prof_filter: bracket only the listed tags (HOST array; n_tags = 0: every launch).  osn_prof_read synchronises

@@ -9,6 +9,7 @@
 // so results are those of the per-module path (same kernels, same order; only the gradient SUMS are associated
 // differently: (a + b) inside the consumer instead of a separate add).
 #include "common.h"
+#include "events.h"
 #include <vector>
 
 namespace osn {
@@ -18,6 +19,9 @@ constexpr uint64_t NO_OFF = ~uint64_t(0);
 struct Events {
     std::vector<hipEvent_t> ev;
 };
+
+int events_count(const osn_events_t* e) { return e ? int(reinterpret_cast<const Events*>(e)->ev.size()) : 0; }
+hipEvent_t events_get(const osn_events_t* e, int i) { return reinterpret_cast<const Events*>(e)->ev[size_t(i)]; }
 
 struct Prof {
     std::vector<hipEvent_t> ev;        // 2 per record

@@ -298,7 +298,7 @@ class UNetExecutor:
         dev = feats.device
         lib = ops._prep(dev)
         training = bool(model.training)
-        cm.prebuild()
+        cm.prebuild(pairs=grad)
         rows = [cm.size(s) for s in p.STRIDES]
         if feats.shape[0] != rows[0]:
             raise ValueError("%d feature rows for %d voxels" % (feats.shape[0], rows[0]))

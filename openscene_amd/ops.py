@@ -304,6 +304,66 @@ def kmap_count(nbr):
     return counts
 
 
+# ------------------------------------------------- every kernel map of a scene from one call, on several streams
+_MAP_LEVEL = None
+_MAP_JOB = None
+_map_streams = {}
+_map_events = {}
+MAPS_STREAMS = int(os.environ.get("OSN_MAPS_STREAMS", "3"))        # 1 = everything on the caller's stream
+
+
+def _map_dtypes():
+    global _MAP_LEVEL, _MAP_JOB
+    if _MAP_LEVEL is None:
+        import numpy as np
+        _MAP_LEVEL = np.dtype([("coords4", "<u8"), ("keys", "<u8"), ("vals", "<u8"), ("cap", "<i8"), ("rows", "<i8")])
+        _MAP_JOB = np.dtype([(n, "<i4") for n in ("lvl_in", "lvl_out", "ksize", "scale", "self_map", "stream", "bm_fwd", "bm_bwd")] +
+                            [(n, "<u8") for n in ("nbr_fwd", "nbr_bwd", "counts", "order_fwd", "sorted_fwd", "gmask_fwd", "order_bwd",
+                                                  "sorted_bwd", "gmask_bwd", "tl_fwd", "tl_bwd", "pl_fwd")])
+        assert _MAP_LEVEL.itemsize == 40 and _MAP_JOB.itemsize == 128
+    return _MAP_LEVEL, _MAP_JOB
+
+
+def maps_build(levels, jobs, dev, sort_rows):
+    """levels: [(coords4, HashTable, rows)]; jobs: list of dicts with the fields of osn_map_job (tensors or None for the
+    pointers, `stream` = 0 .. MAPS_STREAMS - 1); sort_rows: rows of the largest table that gets tile-ordered (scratch
+    size).  One C call; the maps of different levels run side by side on MAPS_STREAMS streams (fork / join inside)."""
+    import numpy as np
+    lib = _prep(dev)
+    ldt, jdt = _map_dtypes()
+    la = np.zeros(len(levels), dtype=ldt)
+    for i, (c, t, rows) in enumerate(levels):
+        la[i] = (c.data_ptr(), t.keys.data_ptr(), t.vals.data_ptr(), t.cap, rows)
+    ja = np.zeros(max(len(jobs), 1), dtype=jdt)
+    for i, q in enumerate(jobs):
+        ja[i] = tuple((q.get(n).data_ptr() if q.get(n) is not None else 0) if jdt[n].kind == "u" else int(q.get(n, 0)) for n in jdt.names)
+    ns = max(1, min(MAPS_STREAMS, 4))
+    idx = _idx(dev)
+    main = _stream(dev)
+    raws = [main]
+    if ns > 1:
+        pool = _map_streams.get(idx)
+        if pool is None:
+            pool = _map_streams[idx] = [torch.cuda.Stream(device=idx) for _ in range(3)]
+        raws += [s.cuda_stream for s in pool[:ns - 1]]
+        ev = _map_events.get(idx)
+        if ev is None:
+            with _Dev(dev):
+                ev = _map_events[idx] = lib.osn_events_create(8)
+        if not ev:
+            ns, raws, ev = 1, [main], None
+    else:
+        ev = None
+    wsb = int(_cached("osn_kmap_sort_ws_bytes", int(sort_rows))) if sort_rows else 256
+    wss = [_ws(wsb, dev)] + [ws_on(wsb, dev, r) for r in raws[1:]]
+    st_arr = (ctypes.c_void_p * ns)(*raws)
+    ws_arr = (ctypes.c_void_p * ns)(*[w.data_ptr() for w in wss])
+    wb_arr = (ctypes.c_uint64 * ns)(*[w.numel() for w in wss])
+    with _Dev(dev):
+        check(lib.osn_maps_build(la.ctypes.data, len(levels), ja.ctypes.data, len(jobs), st_arr, ws_arr, wb_arr, ns, ev),
+              "osn_maps_build")
+
+
 # ----------------------------------------------------------------- convolution
 def _w3(weight):
     return weight.unsqueeze(0) if weight.dim() == 2 else weight

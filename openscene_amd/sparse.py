@@ -113,14 +113,18 @@ class CoordinateManager:
                 self._kmaps[key] = ops.kmap_count(fwd) if fwd is not None else None
         return self._kmaps[key]
 
-    def prebuild(self, strides=(2, 4, 8, 16), kernel_sizes=(3,), stem_kernel=5):
+    def prebuild(self, strides=(2, 4, 8, 16), kernel_sizes=(3,), stem_kernel=5, pairs=False):
         """Build every kernel map (and any level of the pyramid the constructor did not create) up front, before any
         heavy kernel is queued: the host then runs ahead of the GPU for the rest of the forward/backward pass instead of
         stopping at every first use of a map.  (The pyramid's levels 1 ... 16 were built by the constructor with one
-        host synchronisation; a level beyond them costs one read-back of its unique count here.)"""
+        host synchronisation; a level beyond them costs one read-back of its unique count here.)
+        On the device all maps come from ONE C call that deals the levels' independent chains of launches to several
+        streams (ops.maps_build); pairs: also build the pair lists the weight gradients need (training)."""
         for s in strides:
             self.coords(s)
         levels = (1,) + tuple(strides)
+        if self.device.type == "cuda" and all(self.size(s) > 0 for s in levels):
+            self._prebuild_fast(levels, kernel_sizes, stem_kernel, pairs)
         if stem_kernel:
             self.kmap(1, 1, stem_kernel)
             self.kmap_tiles(1, 1, stem_kernel)
@@ -136,6 +140,66 @@ class CoordinateManager:
             self.kmap(2 * s, s, 2)
             self.kmap_tiles(2 * s, s, 2)
             self.kmap_lists(2 * s, s, 2)
+
+    def _want_sort(self, K, rows):
+        """kmap_tiles' rule: which tables get a tile-ordered copy."""
+        return K <= 32 and rows >= self.SORT_MIN_ROWS and not (K <= 8 and rows < self.SORT_MIN_ROWS_K8)
+
+    def _prebuild_fast(self, levels, kernel_sizes, stem_kernel, pairs):
+        """The maps prebuild() asks for, not cached yet, as jobs of one ops.maps_build call; results land in the caches
+        kmap() / kmap_counts() / kmap_tiles() / kmap_lists() read -- the same tensors the per-map path would create."""
+        dev = self.device
+        index = {s: i for i, s in enumerate(levels)}
+        specs = ([(1, 1, stem_kernel)] if stem_kernel else []) + [(s, s, k) for s in levels for k in kernel_sizes] + \
+                [(s, 2 * s, 2) for s in levels[:-1]]
+        i32 = dict(dtype=torch.int32, device=dev)
+        jobs, done, sort_rows = [], [], 0
+        # streams: the two longest chains (the 5^3 map; the level-0 3^3 map with its tile order and lists) get one each
+        lane = {(1, 1, stem_kernel): 1, (1, 1, 3): 2, (4, 4, 3): 2, (1, 2, 2): 2}
+        for si, so, k in specs:
+            key = (si, so, k, 1)
+            if key in self._kmaps or (si == so and k % 2 == 0):
+                continue
+            K, n_in, n_out = k ** 3, self.size(si), self.size(so)
+            own = si == so
+            nbr = torch.empty((K, n_out), **i32)
+            counts = torch.empty(K, dtype=torch.int64, device=dev)
+            bwd = None if own else torch.empty((K, n_in), **i32)
+            q = dict(lvl_in=index[si], lvl_out=index[so], ksize=k, scale=si, self_map=int(own), stream=lane.get((si, so, k), 0),
+                     nbr_fwd=nbr, nbr_bwd=bwd, counts=counts)
+
+            def ordered(rows, side):
+                if not self._want_sort(K, rows):
+                    return None
+                t = (torch.empty(rows, **i32), torch.empty((K, rows), **i32), torch.empty((rows + 31) // 32, **i32))
+                q["order_" + side], q["sorted_" + side], q["gmask_" + side] = t
+                return t
+            tf = ordered(n_out, "fwd")
+            tb = tf if own else ordered(n_in, "bwd")
+            sort_rows = max(sort_rows, n_out if tf is not None else 0, n_in if (tb is not None and not own) else 0)
+            lf = lb = None
+            if K <= 32:                                  # tile lists: every 3^3 / 2^3 map (not the 3-channel stem's 5^3 map)
+                def lists(rows, tiles, side):
+                    bm = ops.tile_rows(rows)
+                    buf = torch.empty(int(ops._cached("osn_tile_lists_bytes", rows, K, bm)), dtype=torch.uint8, device=dev)
+                    q["tl_" + side], q["bm_" + side] = buf, bm
+                    return ops.TileLists(buf, bm, rows, K, tiles[0] if tiles is not None else None)
+                lf = lists(n_out, tf, "fwd")
+                lb = lf if own else lists(n_in, tb, "bwd")
+                if pairs:
+                    lf.pairs = q["pl_fwd"] = torch.empty(int(ops._cached("osn_pair_lists_bytes", n_out, K, lf.bm)),
+                                                          dtype=torch.uint8, device=dev)
+            jobs.append(q)
+            done.append((key, nbr, bwd, counts, tf, tb, lf, lb, own))
+        if not jobs:
+            return
+        ops.maps_build([(self._coords[s], self._tables[s], self.size(s)) for s in levels], jobs, dev, sort_rows)
+        for key, nbr, bwd, counts, tf, tb, lf, lb, own in done:
+            self._kmaps[key] = (nbr, nbr, True) if own else (nbr, bwd, False)
+            self._kmaps[("counts",) + key] = counts
+            self._kmaps[("tiles",) + key] = (tf, tb)
+            if lf is not None:
+                self._kmaps[("lists",) + key] = (lf, lb)
 
     def tensors(self):
         """Every device tensor this manager owns (coordinates, hash tables, parent maps, kernel maps, tile

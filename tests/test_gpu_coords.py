@@ -197,3 +197,52 @@ def test_one_sync_pyramid_equals_the_level_by_level_build():
         ops.coords_pyramid(torch.from_numpy(bad).to(dev()), strides)
     one = ops.coords_pyramid(x[:1], strides)                # a single voxel: every level has one row
     assert [t[0].shape[0] for t in one] == [1] * 5
+
+
+@pytest.mark.parametrize("streams", [1, 3])
+def test_all_maps_from_one_call_equal_the_per_map_builds(streams, monkeypatch):
+    """CoordinateManager.prebuild on the device = ONE osn_maps_build call that deals the levels' maps to several streams:
+    every product (neighbour tables, transposed tables, pair counts, tile orders + group masks, tile lists, pair arrays)
+    bit-identical to the per-map entry points, on one stream and on three; twice in a row (fork / join reuse)."""
+    from openscene_amd import ops
+    from openscene_amd.sparse import CoordinateManager
+    monkeypatch.setattr(ops, "MAPS_STREAMS", streams)
+    v = syn.shuffled(syn.grid_voxels(syn.room_points(12, n_pts=60000), 0.025), 12)
+    coords = torch.from_numpy(syn.batch_coords([v, v[: len(v) // 2] + 3])).to(dev())
+    ref = CoordinateManager(coords)
+    monkeypatch.setattr(CoordinateManager, "_prebuild_fast", lambda self, *a, **k: None)
+    ref.prebuild()
+    monkeypatch.undo()
+    monkeypatch.setattr(ops, "MAPS_STREAMS", streams)
+    for _ in range(2):
+        calls = []
+        real = ops.maps_build
+        monkeypatch.setattr(ops, "maps_build", lambda *a, **k: (calls.append(len(a[1])), real(*a, **k))[1])
+        cm = CoordinateManager(coords)
+        cm.prebuild(pairs=True)
+        monkeypatch.setattr(ops, "maps_build", real)
+        assert calls == [10]                                    # 5^3 + five 3^3 + four 2^3 maps, one call
+        assert ref.kmap_tiles(1, 1, 3)[0] is not None and ref.kmap_tiles(16, 16, 3)[0] is None      # ordered and plain tables
+        keys = [(1, 1, 5)] + [(s, s, 3) for s in (1, 2, 4, 8, 16)] + [(s, 2 * s, 2) for s in (1, 2, 4, 8)] + \
+               [(2 * s, s, 2) for s in (1, 2, 4, 8)]
+        for key in keys:
+            a, b = cm.kmap(*key), ref.kmap(*key)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2], key
+            assert torch.equal(cm.kmap_counts(*key), ref.kmap_counts(*key)), key
+            for ta, tb in zip(cm.kmap_tiles(*key), ref.kmap_tiles(*key)):
+                assert (ta is None) == (tb is None), key
+                if ta is not None:
+                    assert all(torch.equal(x, y) for x, y in zip(ta, tb)), key
+            if key[2] == 5:
+                continue
+            for la, lb in zip(cm.kmap_lists(*key), ref.kmap_lists(*key)):
+                assert la.bm == lb.bm and la.n_out == lb.n_out and (la.out_rows is None) == (lb.out_rows is None), key
+                ca, cb = la.counts(), lb.counts()
+                assert torch.equal(ca, cb), key
+                # list entries are defined up to the count of their (tile, offset)
+                valid = (torch.arange(la.bm, device=ca.device)[None, None, :] < ca[:, :, None])[..., None].expand(-1, -1, -1, 2)
+                assert torch.equal(la.lists()[valid], lb.lists()[valid]), key
+            if key[0] <= key[1]:                                # pair arrays of the forward lists (weight gradient)
+                assert cm.kmap_lists(*key)[0].pairs is not None
+                for x, y in zip(ops.pair_arrays(cm.kmap_lists(*key)[0]), ops.pair_arrays(ref.kmap_lists(*key)[0])):
+                    assert torch.equal(x, y), key
