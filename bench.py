@@ -623,7 +623,13 @@ def main():
             # deterministic), unless another shape's summed time exceeds it by more than 15 % -- two shapes of this network
             # (3^3, 96 -> 96 at levels 0 and 1) are within 5 % of each other in time, and a pure time ranking would flip
             # between them from run to run
-            by_flops = max(survey_shapes.items(), key=lambda kv: kv[1]["flops"])
+            def flops0(kv):
+                # FLOPs of the shape on the UNSHIFTED scene (the per-step lattice shift moves the coarse levels' pair counts
+                # by +-15 %: ranking by a step's own counts would depend on which shifts the survey steps happened to draw)
+                (nm, K_, ci_, co_, lvl_), g_ = kv
+                pr = pair_counts.get((K_, sizes[lvl_]), sizes[lvl_]) if K_ > 1 else sizes[lvl_]
+                return 2.0 * pr * ci_ * co_ * g_["launches"]
+            by_flops = max(survey_shapes.items(), key=flops0)
             by_time = max(survey_shapes.items(), key=lambda kv: kv[1]["ms"])
             dom_key, d_g = by_time if by_time[1]["ms"] > 1.15 * by_flops[1]["ms"] else by_flops
             # bracket its FORWARD launches in the timed region: in the backward pass the same kernel shares the device with the

@@ -476,6 +476,12 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
                 rc = osn_spconv_wgrad_tl_partial(in, gx, m ? m->pl_fwd : nullptr, o.transposed ? 1 : 0, w.gW, n_in, n_out, o.K, o.cin, o.cout,
                                                  B + L.gpart_off[i], osn_spconv_wgrad_tl_ws_bytes(o.K, o.cin, o.cout), &job, wstream);
                 if (!rc) jobs.push_back(job);
+                // reduce in batches ON the stream the partial sums were computed on (stream order is all the ordering it needs):
+                // only the last, small batch is left for the tail of the pass
+                if (!rc && forked && jobs.size() >= 12) {
+                    rc = osn_wgrad_tl_reduce_batch(jobs.data(), int(jobs.size()), wstream);
+                    jobs.clear();
+                }
             } else {
                 rc = osn_spconv_wgrad(in, gx, o.K > 1 ? v.nbr_f : nullptr, o.K > 1 && m ? m->counts : nullptr, nullptr, w.gW, n_out, o.K,
                                       o.cin, o.cout, wws, wws_bytes, wstream);
@@ -497,12 +503,14 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
             }
         }
     }
-    if (forked) {                                          // join: the reductions (and everything after the pass) see the side stream's work
+    // the pair-array weight gradients still waiting for their reduction: one launch (instead of one per convolution)
+    rc = osn_wgrad_tl_reduce_batch(jobs.data(), int(jobs.size()), wstream);
+    if (rc) return rc;
+    if (forked) {                                          // join: everything after the pass sees the side stream's work
         OSN_HIP(hipEventRecord(evs->ev[net->n_ops], side));
         OSN_HIP(hipStreamWaitEvent(st, evs->ev[net->n_ops], 0));
     }
-    // every pair-array weight gradient of the pass: one reduction launch (per 32 convolutions) instead of one each
-    return osn_wgrad_tl_reduce_batch(jobs.data(), int(jobs.size()), stream);
+    return OSN_OK;
 }
 
 extern "C" osn_events_t* osn_events_create(int n) {

@@ -324,9 +324,13 @@ def _map_dtypes():
     return _MAP_LEVEL, _MAP_JOB
 
 
+def _addr(v):
+    return 0 if v is None else (int(v) if isinstance(v, int) else v.data_ptr())
+
+
 def maps_build(levels, jobs, dev, sort_rows):
-    """levels: [(coords4, HashTable, rows)]; jobs: list of dicts with the fields of osn_map_job (tensors or None for the
-    pointers, `stream` = 0 .. MAPS_STREAMS - 1); sort_rows: rows of the largest table that gets tile-ordered (scratch
+    """levels: [(coords4, HashTable, rows)]; jobs: list of dicts with the fields of osn_map_job (tensors, device addresses
+    or None for the pointers, `stream` = 0 .. MAPS_STREAMS - 1); sort_rows: rows of the largest table that gets tile-ordered (scratch
     size).  One C call; the maps of different levels run side by side on MAPS_STREAMS streams (fork / join inside)."""
     import numpy as np
     lib = _prep(dev)
@@ -336,7 +340,7 @@ def maps_build(levels, jobs, dev, sort_rows):
         la[i] = (c.data_ptr(), t.keys.data_ptr(), t.vals.data_ptr(), t.cap, rows)
     ja = np.zeros(max(len(jobs), 1), dtype=jdt)
     for i, q in enumerate(jobs):
-        ja[i] = tuple((q.get(n).data_ptr() if q.get(n) is not None else 0) if jdt[n].kind == "u" else int(q.get(n, 0)) for n in jdt.names)
+        ja[i] = tuple((_addr(q.get(n)) if jdt[n].kind == "u" else int(q.get(n, 0))) for n in jdt.names)
     ns = max(1, min(MAPS_STREAMS, 4))
     idx = _idx(dev)
     main = _stream(dev)

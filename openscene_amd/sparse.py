@@ -147,58 +147,87 @@ class CoordinateManager:
 
     def _prebuild_fast(self, levels, kernel_sizes, stem_kernel, pairs):
         """The maps prebuild() asks for, not cached yet, as jobs of one ops.maps_build call; results land in the caches
-        kmap() / kmap_counts() / kmap_tiles() / kmap_lists() read -- the same tensors the per-map path would create."""
+        kmap() / kmap_counts() / kmap_tiles() / kmap_lists() read -- the same tensors the per-map path would create.
+        The GPU is idle when this runs (the pyramid's size read-back has just returned), so the launches go out first:
+        ONE allocation, addresses by arithmetic, the C call -- and only then the tensor views over the allocation."""
         dev = self.device
         index = {s: i for i, s in enumerate(levels)}
         specs = ([(1, 1, stem_kernel)] if stem_kernel else []) + [(s, s, k) for s in levels for k in kernel_sizes] + \
                 [(s, 2 * s, 2) for s in levels[:-1]]
-        i32 = dict(dtype=torch.int32, device=dev)
-        jobs, done, sort_rows = [], [], 0
         # streams: the two longest chains (the 5^3 map; the level-0 3^3 map with its tile order and lists) get one each
         lane = {(1, 1, stem_kernel): 1, (1, 1, 3): 2, (4, 4, 3): 2, (1, 2, 2): 2}
+        plan, total, sort_rows = [], 0, 0
+
+        def take(nbytes):
+            nonlocal total
+            off = total
+            total += (int(nbytes) + 255) // 256 * 256
+            return off, int(nbytes)
         for si, so, k in specs:
             key = (si, so, k, 1)
             if key in self._kmaps or (si == so and k % 2 == 0):
                 continue
             K, n_in, n_out = k ** 3, self.size(si), self.size(so)
             own = si == so
-            nbr = torch.empty((K, n_out), **i32)
-            counts = torch.empty(K, dtype=torch.int64, device=dev)
-            bwd = None if own else torch.empty((K, n_in), **i32)
-            q = dict(lvl_in=index[si], lvl_out=index[so], ksize=k, scale=si, self_map=int(own), stream=lane.get((si, so, k), 0),
-                     nbr_fwd=nbr, nbr_bwd=bwd, counts=counts)
-
-            def ordered(rows, side):
-                if not self._want_sort(K, rows):
-                    return None
-                t = (torch.empty(rows, **i32), torch.empty((K, rows), **i32), torch.empty((rows + 31) // 32, **i32))
-                q["order_" + side], q["sorted_" + side], q["gmask_" + side] = t
-                return t
-            tf = ordered(n_out, "fwd")
-            tb = tf if own else ordered(n_in, "bwd")
-            sort_rows = max(sort_rows, n_out if tf is not None else 0, n_in if (tb is not None and not own) else 0)
-            lf = lb = None
-            if K <= 32:                                  # tile lists: every 3^3 / 2^3 map (not the 3-channel stem's 5^3 map)
-                def lists(rows, tiles, side):
+            e = dict(key=key, K=K, n_in=n_in, n_out=n_out, own=own, lane=lane.get((si, so, k), 0), lvl_in=index[si], lvl_out=index[so],
+                     ksize=k, scale=si)
+            e["nbr_fwd"] = take(4 * K * n_out)
+            e["counts"] = take(8 * K)
+            if not own:
+                e["nbr_bwd"] = take(4 * K * n_in)
+            for side, rows, on in (("fwd", n_out, True), ("bwd", n_in, not own)):
+                if on and self._want_sort(K, rows):
+                    e["order_" + side], e["sorted_" + side] = take(4 * rows), take(4 * K * rows)
+                    e["gmask_" + side] = take(4 * ((rows + 31) // 32))
+                    sort_rows = max(sort_rows, rows)
+                if on and K <= 32:                       # tile lists: every 3^3 / 2^3 map (not the 3-channel stem's 5^3 map)
                     bm = ops.tile_rows(rows)
-                    buf = torch.empty(int(ops._cached("osn_tile_lists_bytes", rows, K, bm)), dtype=torch.uint8, device=dev)
-                    q["tl_" + side], q["bm_" + side] = buf, bm
-                    return ops.TileLists(buf, bm, rows, K, tiles[0] if tiles is not None else None)
-                lf = lists(n_out, tf, "fwd")
-                lb = lf if own else lists(n_in, tb, "bwd")
-                if pairs:
-                    lf.pairs = q["pl_fwd"] = torch.empty(int(ops._cached("osn_pair_lists_bytes", n_out, K, lf.bm)),
-                                                          dtype=torch.uint8, device=dev)
-            jobs.append(q)
-            done.append((key, nbr, bwd, counts, tf, tb, lf, lb, own))
-        if not jobs:
+                    e["bm_" + side] = bm
+                    e["tl_" + side] = take(ops._cached("osn_tile_lists_bytes", rows, K, bm))
+            if pairs and "tl_fwd" in e:
+                e["pl_fwd"] = take(ops._cached("osn_pair_lists_bytes", n_out, K, e["bm_fwd"]))
+            plan.append(e)
+        if not plan:
             return
+        arena = torch.empty(total, dtype=torch.uint8, device=dev)
+        base = arena.data_ptr()
+        ptr_fields = ("nbr_fwd", "nbr_bwd", "counts", "order_fwd", "sorted_fwd", "gmask_fwd", "order_bwd", "sorted_bwd", "gmask_bwd",
+                      "tl_fwd", "tl_bwd", "pl_fwd")
+        jobs = []
+        for e in plan:
+            q = dict(lvl_in=e["lvl_in"], lvl_out=e["lvl_out"], ksize=e["ksize"], scale=e["scale"], self_map=int(e["own"]), stream=e["lane"],
+                     bm_fwd=e.get("bm_fwd", 0), bm_bwd=e.get("bm_bwd", 0))
+            for f in ptr_fields:
+                if f in e:
+                    q[f] = base + e[f][0]
+            jobs.append(q)
         ops.maps_build([(self._coords[s], self._tables[s], self.size(s)) for s in levels], jobs, dev, sort_rows)
-        for key, nbr, bwd, counts, tf, tb, lf, lb, own in done:
-            self._kmaps[key] = (nbr, nbr, True) if own else (nbr, bwd, False)
+
+        # ---- the launches are queued; now the views the rest of the library works with
+        def view(e, f, dtype, shape):
+            off, nb = e[f]
+            return arena[off:off + nb].view(dtype).view(shape)
+        for e in plan:
+            K, n_in, n_out, key = e["K"], e["n_in"], e["n_out"], e["key"]
+            nbr = view(e, "nbr_fwd", torch.int32, (K, n_out))
+            counts = view(e, "counts", torch.int64, (K,))
+            bwd = nbr if e["own"] else view(e, "nbr_bwd", torch.int32, (K, n_in))
+            tiles = {}
+            for side, rows in (("fwd", n_out), ("bwd", n_in)):
+                tiles[side] = (view(e, "order_" + side, torch.int32, (rows,)), view(e, "sorted_" + side, torch.int32, (K, rows)),
+                               view(e, "gmask_" + side, torch.int32, ((rows + 31) // 32,))) if ("order_" + side) in e else None
+            if e["own"]:
+                tiles["bwd"] = tiles["fwd"]
+            self._kmaps[key] = (nbr, bwd, bool(e["own"]))
             self._kmaps[("counts",) + key] = counts
-            self._kmaps[("tiles",) + key] = (tf, tb)
-            if lf is not None:
+            self._kmaps[("tiles",) + key] = (tiles["fwd"], tiles["bwd"])
+            if "tl_fwd" in e:
+                lf = ops.TileLists(view(e, "tl_fwd", torch.uint8, (e["tl_fwd"][1],)), e["bm_fwd"], n_out, K,
+                                   tiles["fwd"][0] if tiles["fwd"] is not None else None)
+                lb = lf if e["own"] else ops.TileLists(view(e, "tl_bwd", torch.uint8, (e["tl_bwd"][1],)), e["bm_bwd"], n_in, K,
+                                                       tiles["bwd"][0] if tiles["bwd"] is not None else None)
+                if "pl_fwd" in e:
+                    lf.pairs = view(e, "pl_fwd", torch.uint8, (e["pl_fwd"][1],))
                 self._kmaps[("lists",) + key] = (lf, lb)
 
     def tensors(self):

@@ -50,6 +50,35 @@ def per_stream(db, steps):
     if cur_end is not None:
         busy += cur_end - cur_start
     print("device busy (union of all kernels): %.3f ms/step; sum of kernels %.3f ms/step" % (busy / steps / 1e6, sum(t for _, t in tot.values()) / steps / 1e6))
+    # which kernels of the other streams run while the busiest stream is idle (exposed side-stream work)
+    main_key = max(tot.items(), key=lambda kv: kv[1][1])[0]
+    named = cur.execute("select d.%s, d.start, d.end, s.kernel_name from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+                        "on d.kernel_id = s.id order by d.start" % key).fetchall() if key else []
+    main_iv = [(a, b) for k, a, b, _ in named if k == main_key]
+    exposed = {}
+    j = 0
+    for k, a, b, name in named:
+        if k == main_key:
+            continue
+        # part of [a, b) not covered by any main-stream kernel
+        while j < len(main_iv) and main_iv[j][1] <= a:
+            j += 1
+        t, i, un = a, j, 0
+        while t < b:
+            if i >= len(main_iv) or main_iv[i][0] >= b:
+                un += b - t
+                break
+            if main_iv[i][0] > t:
+                un += main_iv[i][0] - t
+            t = max(t, main_iv[i][1])
+            i += 1
+        if un > 0:
+            e = exposed.setdefault(short(name)[:70], [0, 0.0])
+            e[0] += 1
+            e[1] += un
+    print("side-stream time while stream %s is idle: %.3f ms/step" % (main_key, sum(v[1] for v in exposed.values()) / steps / 1e6))
+    for name, (n, t) in sorted(exposed.items(), key=lambda kv: -kv[1][1])[:14]:
+        print("   %-70s %6.1f launches/step %8.3f ms/step" % (name, n / steps, t / steps / 1e6))
 
 
 def main():
