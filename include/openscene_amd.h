@@ -515,8 +515,6 @@ typedef struct osn_net_run {
 int osn_net_plan_query(const osn_net_desc* net, const int64_t* level_rows, int training, osn_net_plan* plan);
 int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, osn_stream_t stream);
 int osn_net_backward(const osn_net_desc* net, const osn_net_run* run, osn_stream_t stream);
-osn_stream_t osn_stream_create(int priority_class);   /* -1 highest, 0 default, 1 lowest priority of the device; null on failure */
-void osn_stream_destroy(osn_stream_t s);
 osn_events_t* osn_events_create(int n);       /* n timing-free HIP events on the current device; null on failure   */
 void osn_events_destroy(osn_events_t* e);
 

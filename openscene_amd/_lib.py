@@ -71,8 +71,6 @@ PROTOTYPES = {
     "osn_net_forward": (_i32, [_vp, _vp, _vp]),
     "osn_net_backward": (_i32, [_vp, _vp, _vp]),
     "osn_maps_build": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
-    "osn_stream_create": (_vp, [_i32]),
-    "osn_stream_destroy": (None, [_vp]),
     "osn_events_create": (_vp, [_i32]),
     "osn_events_destroy": (None, [_vp]),
     "osn_prof_create": (_vp, [_i32]),

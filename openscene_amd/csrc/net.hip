@@ -513,22 +513,6 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
     return OSN_OK;
 }
 
-// A stream of the given priority class on the current device: -1 = the device's highest, 0 = default, 1 = its lowest
-// (hipDeviceGetStreamPriorityRange).  The executor's side stream is a LOW-priority one: its launches fill what the main
-// dependency chain leaves idle instead of competing with it for compute units.
-extern "C" osn_stream_t osn_stream_create(int priority_class) {
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return nullptr;
-    const int prio = priority_class > 0 ? least : (priority_class < 0 ? greatest : (least + greatest) / 2);
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
-    return static_cast<osn_stream_t>(s);
-}
-
-extern "C" void osn_stream_destroy(osn_stream_t s) {
-    if (s) (void)hipStreamDestroy(static_cast<hipStream_t>(s));
-}
-
 extern "C" osn_events_t* osn_events_create(int n) {
     if (n < 1) return nullptr;
     Events* e = new (std::nothrow) Events();

@@ -25,10 +25,6 @@ ENABLED = os.environ.get("OSN_EXECUTOR", "1") != "0"
 # only at its end) and the BasicBlock shortcut stages of both passes.  Bitwise the same results; the GPU is the bottleneck
 # since the executor took the host out of the way, and most launches leave compute units idle (measured: -0.86 ms / step)
 SIDE_STREAM = os.environ.get("OSN_SIDE_STREAM", "1") != "0"
-# priority class of that stream: "low" = the device's lowest priority (its launches fill what the main chain leaves idle
-# instead of competing with it), "normal" = a default-priority stream
-SIDE_PRIORITY = os.environ.get("OSN_SIDE_PRIORITY", "low")
-_side_raw = {}          # device index -> raw handle of the library-created side stream
 _DRY_RUN = False        # tools/dryrun only: accept host tensors (a null HIP runtime logs the launches instead of running them)
 
 _OP = np.dtype([(n, "<i4") for n in ("K", "cin", "cout", "lvl_in", "lvl_out", "map", "transposed", "src", "dst", "bn", "relu",
@@ -341,15 +337,7 @@ class UNetExecutor:
         """(raw side stream, its scratch buffer, event pool) or (None, None, None)."""
         if not SIDE_STREAM:
             return None, None, None
-        if _DRY_RUN:
-            side = 0x51DE                                                     # any handle but the main stream's
-        elif SIDE_PRIORITY == "low":
-            side = _side_raw.get(ops._idx(dev))
-            if side is None:
-                with ops._Dev(dev):
-                    side = _side_raw[ops._idx(dev)] = lib.osn_stream_create(1) or ops.side_stream(dev).cuda_stream
-        else:
-            side = ops.side_stream(dev).cuda_stream
+        side = 0x51DE if _DRY_RUN else ops.side_stream(dev).cuda_stream       # (dry run: any handle but the main stream's)
         ws2 = ops.ws_on(int(self._plan.ws_bytes), dev, side)
         events = self._events.get(ops._idx(dev))
         if events is None:

@@ -62,9 +62,6 @@ hipError_t hipEventRecord(hipEvent_t, hipStream_t) { add("EVENT"); return hipSuc
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 1; *greatest = -1; return hipSuccess; }
-hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = reinterpret_cast<hipStream_t>(0x51DE); return hipSuccess; }
-hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 
 // ---- tool interface
 const char* osn_dry_log(void) { std::lock_guard<std::mutex> lk(g_mu); static std::string copy; copy = g_log; return copy.c_str(); }
