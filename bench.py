@@ -459,6 +459,9 @@ def main():
     ap.add_argument("--prefetch-maps", action="store_true", help="build the maps of the NEXT batch on a side stream "
                     "while a step runs (openscene_amd.sparse.MapPrefetcher) instead of inside the step as "
                     "MinkowskiEngine does; measured 4 %% SLOWER on S100k (DESIGN.md section 4), off by default")
+    ap.add_argument("--no-prefetch-pyramid", action="store_true", help="build the coordinate pyramid of a batch inside its own step "
+                    "(after the previous step has drained) instead of queueing it on a side stream while the previous step runs; "
+                    "every step still builds exactly one pyramid and one set of kernel maps inside the timed region")
     ap.add_argument("--prefetch-maps-threaded", action="store_true", help="as --prefetch-maps, but the maps are built by a "
                     "worker thread (the main thread never waits on the pyramid's size read-backs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -537,21 +540,36 @@ def main():
         coords[:, 1:4] += shift                                    # run/distill.py:315
         return coords
 
-    prefetch = args.prefetch_maps or args.prefetch_maps_threaded
-    pf = MapPrefetcher(device, threaded=args.prefetch_maps_threaded) if prefetch else None
-    pending = [pf.submit(next_coords())] if prefetch else None
+    # the loader knows a batch's coordinates one step ahead (DataLoader prefetch, dataset/feature_loader.py): by default its
+    # coordinate PYRAMID (hash insert, unique, four coarse levels, the one size read-back -- work during which the GPU can do
+    # nothing else) is queued on a side stream while the previous step's backward pass runs; the kernel maps are built
+    # inside the step.  --prefetch-maps moves the maps there as well (measured slower), --no-prefetch-pyramid nothing.
+    full_prefetch = args.prefetch_maps or args.prefetch_maps_threaded
+    prefetch = full_prefetch or not args.no_prefetch_pyramid
+    pf = MapPrefetcher(device, threaded=args.prefetch_maps_threaded, pyramid_only=not full_prefetch) if prefetch else None
+    def prepare_next():
+        """Inputs of the NEXT step, queued on the prefetcher's stream: shifted coordinates, the rows the mask selects (a
+        size read-back of its own) and the coordinate pyramid (full prefetch: every map)."""
+        with torch.cuda.stream(pf.stream):
+            coords = next_coords()
+            sel_n = mask.nonzero(as_tuple=False).squeeze(1)
+            return pf.submit(coords), sel_n
+
+    pending = [prepare_next()] if prefetch else None
 
     def step():
         # `out[mask]` with a bool mask makes torch read the selected-row count back in the MIDDLE of the step
         # (host stalls until the forward has drained, then refills an empty queue).  The row indices of the mask
         # are batch data (openscene_amd.loader hands them out): resolve them here, next to the size read-backs
         # of the coordinate pyramid, and the rest of the step runs without a host sync.
-        sel = mask.nonzero(as_tuple=False).squeeze(1)
         if prefetch:
-            # maps of this batch were built on the side stream while the previous step ran (every step still
-            # builds exactly one set of maps: the one for the batch after it)
-            sinput = SparseTensor(feats, coordinate_manager=pf.take(pending[0]))
+            # the pyramid (full prefetch: and the maps) of this batch was queued on the side stream while the previous
+            # step ran; every step still builds exactly one pyramid and one set of maps
+            handle, sel = pending[0]
+            sinput = SparseTensor(feats, coordinate_manager=pf.take(handle))
+            sel.record_stream(torch.cuda.current_stream(device))
         else:
+            sel = mask.nonzero(as_tuple=False).squeeze(1)
             sinput = SparseTensor(feats, next_coords())            # builds every map (ME does per forward)
         out = net(sinput)
         loss = (1 - cos(out.index_select(0, sel), feat_3d)).mean()  # = out[mask], run/distill.py:322-326
@@ -561,7 +579,7 @@ def main():
             exchange.reduce_gradients()                            # ONE all-reduce (RCCL over xGMI), mean over ranks
         optim.step()
         if prefetch:
-            pending[0] = pf.submit(next_coords())
+            pending[0] = prepare_next()
         return loss
 
     def sync():
@@ -576,7 +594,7 @@ def main():
         step()
     from openscene_amd import executor as _ex
     ex = _ex.for_model(model.net3d) if _ex.ENABLED else None
-    prof = ExecProfiler(ex) if (ex is not None and not args.no_kernel_events and not prefetch) else None
+    prof = ExecProfiler(ex) if (ex is not None and not args.no_kernel_events and not full_prefetch) else None
     legacy = LaunchProfiler() if (ex is None and not args.no_kernel_events) else None
     survey_groups, survey_shapes, dom_key, dom_tags = {}, {}, None, []
     dom_fwd_only = False
@@ -1001,6 +1019,9 @@ def main():
         "query": qres, "voxelizer": vox_res, "phases": extra, "roofline": roofline, "cpu_baseline": cpu, "comm": comm,
         "kernels": kernels, "stages": stages, "loss": float(loss.detach()),
         "host_path": "network executor (one C call per forward / backward pass)" if ex is not None else "per-module (Python autograd)",
+        "input_pipeline": ("every map of step i+1 built on a side stream during step i" if full_prefetch else
+                           "coordinate pyramid (+ mask rows) of step i+1 queued on a side stream during step i; kernel maps inside the step"
+                           if prefetch else "pyramid and maps inside the step"),
     }
     print(json.dumps(line))
     if dist_on:

@@ -335,13 +335,17 @@ class MapPrefetcher:
     read-backs for longer than the maps take alone, and the step turns host-bound.  It is kept for
     loaders that run two batches ahead (submit from a worker thread); `bench.py --prefetch-maps`."""
 
-    def __init__(self, device, threaded=False, **prebuild_args):
+    def __init__(self, device, threaded=False, pyramid_only=False, **prebuild_args):
         """threaded: build on a worker thread, so that the caller never blocks on the pyramid's size read-backs (the
-        C calls release the GIL while they wait): submit() returns at once, take() joins the build."""
+        C calls release the GIL while they wait): submit() returns at once, take() joins the build.
+        pyramid_only: queue only the coordinate pyramid ahead (five short launch chains and the one size read-back -- the
+        part of a step during which nothing else can run); the kernel maps are then built inside the step, from one C call
+        (ops.maps_build), when the forward pass asks for them."""
         self.device = torch.device(device)
         _lo, hi = torch.cuda.Stream.priority_range()
         self.stream = torch.cuda.Stream(self.device, priority=hi)
         self.prebuild_args = prebuild_args
+        self.pyramid_only = bool(pyramid_only)
         self.threaded = bool(threaded)
         self._pool = None
         if self.threaded:
@@ -354,7 +358,8 @@ class MapPrefetcher:
         coordinates.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
             cm = CoordinateManager(coordinates)
-            cm.prebuild(**self.prebuild_args)
+            if not self.pyramid_only:
+                cm.prebuild(**self.prebuild_args)
             done = torch.cuda.Event()
             done.record(self.stream)
         return cm, done
