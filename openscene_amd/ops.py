@@ -309,7 +309,11 @@ _MAP_LEVEL = None
 _MAP_JOB = None
 _map_streams = {}
 _map_events = {}
-MAPS_STREAMS = int(os.environ.get("OSN_MAPS_STREAMS", "3"))        # 1 = everything on the caller's stream
+# streams the jobs of one maps_build call are dealt to.  Measured on MI355X (profiles/r03_s5..s7): 2 - 4 streams do not
+# shorten the step (12.5 - 12.7 ms either way: the 5^3 stem map is the long pole and the first thing the forward pass
+# needs), and every extra stream counts against the runtime's four hardware queues -- with the executor's side stream
+# and the input prefetcher's stream in flight as well, streams start to share queues and the step DOUBLES (26 ms).
+MAPS_STREAMS = int(os.environ.get("OSN_MAPS_STREAMS", "1"))        # 1 = everything on the caller's stream
 
 
 def _map_dtypes():
