@@ -52,8 +52,16 @@ def query_distill_fused(features, final_kernel, text_features, inds_reverse=None
     fp16 rounding of the 768-d vector (<= 2e-3 absolute on O(1) scores, the same bound as the unfused path), and labels
     agree wherever the reference's top-2 margin exceeds twice that.  Returns int64 labels [N_pts] (and float32 scores
     [N_vox, n_labels] per VOXEL if return_scores)."""
+    scores = _rows_times(features, head_times_text(final_kernel, text_features))
+    labels = scores.argmax(1)
+    if inds_reverse is not None:
+        labels = labels[inds_reverse]
+    return (labels, scores) if return_scores else labels
+
+
+def _rows_times(features, M):
+    """features [N, c_in] (float32, device) @ M [c_in, c] at fp32 accuracy on the split-bf16 convolution kernel (K = 1)."""
     import torch
-    M = head_times_text(final_kernel, text_features)                  # [96, C]
     c = M.shape[1]
     cp = (c + 3) // 4 * 4
     if cp != c:
@@ -61,11 +69,36 @@ def query_distill_fused(features, final_kernel, text_features, inds_reverse=None
     n = features.shape[0]
     if ops.tl_eligible(1, M.shape[0], cp, n):
         wf, _ = ops.weight_prep_tl(M.contiguous(), want_dgrad=False)
-        scores = ops.spconv_fwd_tl(features, wf, None, n, 1, cp)
+        out = ops.spconv_fwd_tl(features, wf, None, n, 1, cp)
     else:
-        scores = ops.spconv_fwd(features, M.contiguous(), None, n)
-    scores = scores[:, :c]
-    labels = scores.argmax(1)
+        out = ops.spconv_fwd(features, M.contiguous(), None, n)
+    return out[:, :c]
+
+
+def query_ensemble_fused(features, final_kernel, feat_3d, text_features, inds_reverse=None, return_scores=False):
+    """SURVEY.md 8(f) row 2, ensemble variant (run/evaluate.py:302-324 with the head folded in): the distilled source is
+    never expanded to 768-d.  With W = the final 1x1 kernel [96, D], M = W text^T [96, C] and the Gram matrix
+    G = W W^T [96, 96]:
+        scores_d = F M,   |F W| = sqrt(rowsum((F G) * F))      (the 768-d norm from 96-d quantities)
+        best_d   = max_c scores_d / (|F W| + 1e-5),   best_f = max_c (x_f.half() text^T) / (|x_f| + 1e-5)
+    a point takes the fused 2-D feature iff best_d < best_f (the reference's rule), then is scored with the selected
+    UN-normalised feature.  `features`: float32 [N_vox, 96] (``forward_features``), `feat_3d`: the fused features per
+    POINT [N_pts, D], `inds_reverse`: point -> voxel.  Differences to the reference expression: it rounds the normalised
+    768-d vectors and their scores to fp16 before comparing, here the distilled side stays fp32 -- the selection agrees
+    wherever |best_d - best_f| exceeds that rounding (4e-3), scores of distill-selected points differ by the fp16 rounding
+    of the 768-d vector (as in query_distill_fused).  Returns (labels [N_pts], used_fusion bool [N_pts][, float32 scores])."""
+    import torch
+    W = final_kernel.detach().float()
+    M = head_times_text(final_kernel, text_features)
+    sd = _rows_times(features, M)                                            # [N_vox, C]
+    nd = (_rows_times(features, (W @ W.t()).contiguous()) * features).sum(1).clamp_min(0).sqrt()
+    best_d = sd.max(1)[0] / (nd + 1e-5)
+    sf, _ = ops.cosine_query(feat_3d, text_features, None, want_scores=True)  # [N_pts, C] fp16, un-normalised fused features
+    sf = sf.float()
+    best_f = sf.max(1)[0] / (feat_3d.float().norm(dim=1) + 1e-5)
     if inds_reverse is not None:
-        labels = labels[inds_reverse]
-    return (labels, scores) if return_scores else labels
+        sd, best_d = sd[inds_reverse], best_d[inds_reverse]
+    use_f = best_d < best_f
+    scores = torch.where(use_f[:, None], sf, sd)
+    labels = scores.argmax(1)
+    return (labels, use_f, scores) if return_scores else (labels, use_f)

@@ -113,6 +113,22 @@ def loader_cases():
                 out["%s_%s" % (split, nm)] = t.numpy()
             out["%s_seed" % split] = seed
         np.savez_compressed(os.path.join(HERE, "loader_fused.npz"), **out)
+        # ---- the TRAINING configuration: aug=True (config/scannet/ours_openseg.yaml `aug: True`): elastic distortion is
+        # drawn (and, for merged-mask files, not used: feature_loader.py:122 vs :126), then after the voxeliser the
+        # horizontal flip and -- with colour input -- the chromatic transforms (dataset/point_loader.py:101-113).
+        import random
+        aug = {k: v for k, v in out.items() if k.startswith("s")}
+        for tag, input_color, seed in (("ones", False, 7), ("color", True, 8), ("color2", True, 9)):
+            ds = fl.FusedFeatureLoader(datapath_prefix=data, datapath_prefix_feat=featdir, voxel_size=0.05,
+                                       split="train", aug=True, memcache_init=False, eval_all=False, input_color=input_color)
+            np.random.seed(seed)
+            random.seed(seed)
+            items = [ds[i] for i in range(len(ds))]
+            batch = fl.collation_fn(items)
+            for nm, t in zip(("coords", "feats", "labels", "feat_3d", "mask"), batch):
+                aug["%s_%s" % (tag, nm)] = t.numpy()
+            aug["%s_seed" % tag] = seed
+        np.savez_compressed(os.path.join(HERE, "loader_fused_aug.npz"), **aug)
     finally:
         torch.load = real_load
         shutil.rmtree(root, ignore_errors=True)

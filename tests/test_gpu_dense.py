@@ -251,6 +251,43 @@ def test_fused_head_query_matches_the_unfused_path():
         assert torch.equal(labels.cpu()[clear], ref_labels[clear])
 
 
+def test_fused_head_ensemble_query_matches_the_reference_expression():
+    """SURVEY.md 8(f) row 2, ensemble mode: selection and labels from 96-d quantities (W text^T and the Gram matrix W W^T)
+    against run/evaluate.py:302-324 evaluated on the expanded 768-d features (oracle/query.py)."""
+    from openscene_amd.query import query_ensemble_fused
+    g = torch.Generator().manual_seed(11)
+    n_vox, n_pts, d = 7000, 11000, 768
+    f96 = torch.randn(n_vox, 96, generator=g) * (0.5 + torch.rand(n_vox, 1, generator=g))
+    W = torch.randn(96, d, generator=g) / 96 ** 0.5
+    inds = torch.randint(0, n_vox, (n_pts,), generator=g)
+    for n_labels in (20, 160):
+        text = torch.nn.functional.normalize(torch.randn(n_labels, d, generator=g), dim=1).half()
+        # fused features correlated with the distilled ones so that both sources win for a share of the points
+        fd = (f96 @ W)[inds]
+        ff = (fd * (0.6 + 0.8 * torch.rand(n_pts, 1, generator=g)) + 0.9 * fd.std() * torch.randn(n_pts, d, generator=g)).half().float()
+        ref_scores, ref_labels, _ = oq.query_ensemble(f96 @ W, ff, text, inds)        # gathers the distilled source only ...
+        ref_scores = ref_scores.float()
+        fdn = fd / (fd.norm(dim=-1, keepdim=True) + 1e-5)
+        ffn = ff / (ff.norm(dim=-1, keepdim=True) + 1e-5)
+        pd, pf = oq.half_matmul(fdn.half(), text).float().max(1)[0], oq.half_matmul(ffn.half(), text).float().max(1)[0]
+        ref_scores2, ref_labels2, _ = oq.query_ensemble(fd, ff, text)                    # ... so evaluate per point directly
+        ref_scores2 = ref_scores2.float()
+        labels, used, scores = query_ensemble_fused(f96.to(dev()), W.to(dev()), ff.to(dev()), text.to(dev()), inds.to(dev()),
+                                                    return_scores=True)
+        labels, used, scores = labels.cpu(), used.cpu(), scores.cpu()
+        sel_ref = pd < pf
+        decided = (pd - pf).abs() > 4e-3
+        assert 0.15 < sel_ref.float().mean().item() < 0.85 and decided.float().mean().item() > 0.7
+        assert torch.equal(used[decided], sel_ref[decided])
+        tol = 1e-3 * max(1.0, ref_scores2.abs().max().item()) + 2e-3
+        assert (scores[decided] - ref_scores2[decided]).abs().max().item() <= tol
+        top2 = ref_scores2.topk(2, dim=1)[0]
+        clear = decided & ((top2[:, 0] - top2[:, 1]) > 2 * tol)
+        assert clear.float().mean().item() > 0.4
+        assert torch.equal(labels[clear], ref_labels2[clear])
+        del ref_scores, ref_labels
+
+
 def test_query_ensemble():
     from openscene_amd import ops
     xd, t, gather = _query_inputs(3000, 5000, 768, 20, 1)

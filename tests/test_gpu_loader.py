@@ -22,6 +22,13 @@ def test_loader_matches_the_reference_loader(golden_dir, split, eval_all, input_
     loader_cases.check(d, loader_cases.run(d, dev(), split, eval_all, input_color), split, eval_all)
 
 
+@pytest.mark.parametrize("tag,input_color", [("ones", False), ("color", True), ("color2", True)])
+def test_loader_training_augmentation_matches_the_reference_loader(golden_dir, tag, input_color):
+    """dataset/feature_loader.py with aug=True (point_loader.py:101-113), outputs of the reference's own loader."""
+    d = loader_cases.load_aug(golden_dir)
+    loader_cases.check_aug(d, loader_cases.run_aug(d, dev(), tag, input_color), tag)
+
+
 def test_remap_full_size_and_edges():
     from openscene_amd import ops, _lib
     rng = np.random.default_rng(9)

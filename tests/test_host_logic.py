@@ -230,6 +230,16 @@ def test_gpu_resident_loader_matches_the_reference_loader(monkeypatch, golden_di
     loader_cases.check(d, loader_cases.run(d, torch.device("cpu"), split, eval_all, input_color), split, eval_all)
 
 
+@pytest.mark.parametrize("tag,input_color", [("ones", False), ("color", True), ("color2", True)])
+def test_loader_training_augmentation_matches_the_reference_loader(monkeypatch, golden_dir, tag, input_color):
+    """aug=True (the training configuration): elastic-distortion draws, horizontal flip, chromatic transforms -- same
+    random stream, bit-identical batch as the reference's FusedFeatureLoader (tests/golden/loader_fused_aug.npz)."""
+    import loader_cases
+    cpu_backend.install(monkeypatch)
+    d = loader_cases.load_aug(golden_dir)
+    loader_cases.check_aug(d, loader_cases.run_aug(d, torch.device("cpu"), tag, input_color), tag)
+
+
 def test_forward_features_is_the_input_of_the_final_conv(cpu_ops):
     """MinkUNetBase.forward == final(forward_features): the fused-head query folds exactly
     the last 1x1 convolution (models/mink_unet.py:108-113,174) and nothing else."""
