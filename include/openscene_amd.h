@@ -448,7 +448,7 @@ typedef struct osn_net_buf { int32_t level, channels; } osn_net_buf;
 typedef struct osn_net_desc {
     int32_t n_ops, n_bufs, n_bns, n_weights, n_maps, n_levels;
     int32_t tl_min_rows;         /* tile-list forward / input gradient on tables of at least this many rows       */
-    int32_t reserved;
+    int32_t tl_mid_rows;         /* ... and from this many rows on when both channel counts are >= 96 (0 = never)  */
     const osn_net_op* ops;
     const osn_net_buf* bufs;
 } osn_net_desc;

@@ -36,6 +36,11 @@ static bool stem_eligible(int K, int cin, int cout) { return cin <= 4 && cout ==
 static bool tl_eligible(int K, int cin, int cout, int64_t n_in) {
     return (cin & 3) == 0 && cin >= 8 && (cout & 3) == 0 && K <= 128 && n_in <= (int64_t(1) << 24);
 }
+// functional.tl_rows_ok: a table big enough for the tile-list kernel (always from tl_min_rows rows on; from tl_mid_rows on
+// when both channel counts are at least 96)
+static bool tl_rows_ok(const osn_net_desc* net, int64_t rows, int ca, int cb) {
+    return rows >= net->tl_min_rows || (net->tl_mid_rows > 0 && rows >= net->tl_mid_rows && ca >= 96 && cb >= 96);
+}
 static bool x6_eligible(int K, int cin, int cout, int64_t n_out) {
     if ((cin & 3) || cin < 8) return false;
     if (int64_t(3) * K * cout * ((cin + 31) / 32 * 32) >= (int64_t(1) << 30)) return false;
@@ -117,7 +122,7 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
         if (stem_eligible(o.K, o.cin, o.cout)) {
             OSN_REQUIRE(!o.transposed, OSN_E_ARG, "osn_net: op %d: transposed stem", i);
             L.fwd_k[i] = OSN_NET_K_STEM;
-        } else if (o.K > 1 && tl_eligible(o.K, o.cin, o.cout, n_in) && n_out >= net->tl_min_rows) {
+        } else if (o.K > 1 && tl_eligible(o.K, o.cin, o.cout, n_in) && tl_rows_ok(net, n_out, o.cin, o.cout)) {
             L.fwd_k[i] = OSN_NET_K_TL;
             L.images[i] |= OSN_NET_IMG_TL_FWD;
             need_ws(osn_spconv_fwd_tl_ws_bytes(n_out, o.K, o.cout, osn_tile_rows(n_out)));
@@ -131,7 +136,7 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
         if (!training) continue;
         // ---- input gradient: a convolution of the output gradient with the transposed weights, [n_in, cin]
         if (o.need_dgrad) {
-            if (o.K > 1 && tl_eligible(o.K, o.cout, o.cin, n_out) && tl_eligible(o.K, o.cin, o.cout, n_in) && n_in >= net->tl_min_rows) {
+            if (o.K > 1 && tl_eligible(o.K, o.cout, o.cin, n_out) && tl_eligible(o.K, o.cin, o.cout, n_in) && tl_rows_ok(net, n_in, o.cin, o.cout)) {
                 L.dgrad_k[i] = OSN_NET_K_TL;
                 L.images[i] |= OSN_NET_IMG_TL_DGRAD;
                 need_ws(osn_spconv_fwd_tl_ws_bytes(n_in, o.K, o.cin, osn_tile_rows(n_in)));

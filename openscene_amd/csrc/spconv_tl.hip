@@ -119,9 +119,11 @@ struct TlIter {
     }
 
 // 4 waves; wave w < NW owns output columns [32 w, 32 w + 32) of the workgroup's column group and BOTH 16-pair
-// halves of a step (waves >= NW only help with the gathers and the staging); channel chunks of up to 128
-// (B fragments of a chunk: 4 k-steps x 2 column blocks x 3 planes = 96 VGPRs).
-template <int NW, bool PROF = false>
+// halves of a step (waves >= NW only help with the gathers and the staging); channel chunks of KS x 32 <= 128
+// (B fragments of a chunk: KS k-steps x 2 column blocks x 3 planes = 24 KS VGPRs).  KS is the k-step count that
+// tiles the input channels without a remainder where one exists (96 channels: KS = 3 -- with the fixed 128-channel
+// chunk of round 2 a quarter of the weight-fragment loads and of the gather lanes of every 96-channel conv was padding).
+template <int NW, int KS, bool PROF = false>
 __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restrict__ in, const bf16x8* __restrict__ Wp,
                                                                const int32_t* __restrict__ cnt, const int2* __restrict__ lst,
                                                                const int32_t* __restrict__ out_rows, float* __restrict__ out,
@@ -132,10 +134,10 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
     constexpr int NT = 256;
     constexpr int CW = 32 * NW;               // output columns of the workgroup
     constexpr int S = CW + 4;                 // fp32 row stride of the output tile
-    constexpr int KS = 4;                     // 32-deep k-steps per channel chunk
     constexpr int CK = 32 * KS;               // input channels per chunk
     constexpr int LDA = CK + 8;               // bf16 row stride of a staged plane (16-byte aligned rows)
-    constexpr int NQ = (32 * (CK / 4) + NT - 1) / NT;     // 4-channel quads per thread per step
+    constexpr int QPR = CK / 4;                           // 4-channel quads per staged row
+    constexpr int NQ = (32 * QPR + NT - 1) / NT;          // quads per thread per step
     constexpr int NL = (TL_LCAP + NT - 1) / NT;           // list entries per thread per batch
     __shared__ __attribute__((aligned(16))) float otile[(TL_BMAX + 1) * S];     // + one dump row for padded pairs
     __shared__ __attribute__((aligned(16))) __bf16 stage[3][32][LDA];
@@ -159,8 +161,8 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const int idx = tid + NT * j;
-        q_row[j] = (idx >> 5) & 31;
-        q_col[j] = (idx & 31) * 4;
+        q_row[j] = (idx / QPR) & 31;
+        q_col[j] = (idx % QPR) * 4;
     }
 
     bf16x8 B[KS][2][3];
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                 TL_TICK(3)                                 // 3: barrier A
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) {
-                    if (NT * NQ == 1024 || tid + NT * j < 1024) {
+                    if (NT * NQ == 32 * QPR || tid + NT * j < 32 * QPR) {
                         *reinterpret_cast<bf16x4*>(&stage[0][q_row[j]][q_col[j]]) = p1[j];
                         *reinterpret_cast<bf16x4*>(&stage[1][q_row[j]][q_col[j]]) = p2[j];
                         *reinterpret_cast<bf16x4*>(&stage[2][q_row[j]][q_col[j]]) = p3[j];
@@ -629,14 +631,26 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
     const unsigned gx = unsigned(units < TL_SLOTS ? units : TL_SLOTS);
     const dim3 grid(gx, unsigned(gy));
     const bf16x8* wp = static_cast<const bf16x8*>(Wp);
-#define OSN_TL(NW_)                                                                                                        \
+    // k-steps per channel chunk: the whole contraction when it fits (<= 4 k-steps), else the divisor of the k-step count
+    // that leaves no padded chunk (192 channels: 2 x 3), else 4
+    const int ks = ns <= 4 ? ns : (ns % 4 == 0 ? 4 : (ns % 3 == 0 ? 3 : 4));
+#define OSN_TL2(NW_, KS_)                                                                                                  \
     do {                                                                                                                   \
         if (prof)                                                                                                          \
-            hipLaunchKernelGGL((spconv_tl_kernel<NW_, true>), grid, dim3(256), 0, st, in, wp, cnt, lst, out_rows, out,   \
+            hipLaunchKernelGGL((spconv_tl_kernel<NW_, KS_, true>), grid, dim3(256), 0, st, in, wp, cnt, lst, out_rows, out, \
                                bn_partial, counter, partial, nz, int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof); \
         else                                                                                                               \
-            hipLaunchKernelGGL((spconv_tl_kernel<NW_, false>), grid, dim3(256), 0, st, in, wp, cnt, lst, out_rows, out,  \
+            hipLaunchKernelGGL((spconv_tl_kernel<NW_, KS_, false>), grid, dim3(256), 0, st, in, wp, cnt, lst, out_rows, out, \
                                bn_partial, counter, partial, nz, int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof); \
+    } while (0)
+#define OSN_TL(NW_)                                                                                                        \
+    do {                                                                                                                   \
+        switch (ks) {                                                                                                      \
+            case 1: OSN_TL2(NW_, 1); break;                                                                                \
+            case 2: OSN_TL2(NW_, 2); break;                                                                                \
+            case 3: OSN_TL2(NW_, 3); break;                                                                                \
+            default: OSN_TL2(NW_, 4); break;                                                                               \
+        }                                                                                                                  \
     } while (0)
     switch (nw) {
         case 4: OSN_TL(4); break;
@@ -645,6 +659,7 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
         default: OSN_TL(1); break;
     }
 #undef OSN_TL
+#undef OSN_TL2
     OSN_LAUNCH_CHECK();
     if (nz > 1) {
         const int64_t total4 = n_out * (cout / 4);

@@ -46,7 +46,7 @@ K_NAMES = {0: "none", 1: "stem", 2: "tl", 3: "x6", 4: "wgrad_tl", 5: "wgrad"}
 class _Desc(ctypes.Structure):
     _fields_ = [("n_ops", ctypes.c_int32), ("n_bufs", ctypes.c_int32), ("n_bns", ctypes.c_int32), ("n_weights", ctypes.c_int32),
                 ("n_maps", ctypes.c_int32), ("n_levels", ctypes.c_int32), ("tl_min_rows", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("ops", ctypes.c_void_p), ("bufs", ctypes.c_void_p)]
+                ("tl_mid_rows", ctypes.c_int32), ("ops", ctypes.c_void_p), ("bufs", ctypes.c_void_p)]
 
 
 class _Plan(ctypes.Structure):
@@ -214,6 +214,7 @@ class UNetExecutor:
     def _plan_query(self, lib, rows, training):
         from . import functional as F_
         self.desc.tl_min_rows = int(F_.TL_FWD_MIN_ROWS)
+        self.desc.tl_mid_rows = int(F_.TL_MID_MIN_ROWS)
         self._rows[:len(rows)] = rows
         check(lib.osn_net_plan_query(ctypes.addressof(self.desc), _ptr(self._rows), int(training), ctypes.addressof(self._plan)),
               "osn_net_plan_query")

@@ -19,6 +19,15 @@ from . import ops
 #   "fp32"   the same kernel on v_mfma_f32_32x32x2_f32 (exact fp32 products, 157 TF peak)
 CONV_MODE = os.environ.get("OSN_CONV_MODE", "tl")
 TL_FWD_MIN_ROWS = int(os.environ.get("OSN_TL_FWD_MIN_ROWS", "65536"))
+# ... and from this many rows on when both channel counts are at least 96 (measured with the per-width channel chunks of
+# round 3, profiles/r03_s8: 48 k rows 96 -> 96 121 us against 134 us, 128 -> 96 143 / 164; 12.9 k rows 128 -> 128 63 / 78,
+# 192 -> 128 88 / 104; narrower layers -- 64 -> 64: 39 / 34, 32 -> 32: 67 / 34 -- stay on the output-stationary kernel)
+TL_MID_MIN_ROWS = int(os.environ.get("OSN_TL_MID_MIN_ROWS", "8192"))
+
+
+def tl_rows_ok(n_rows, c_a, c_b):
+    """Is a table of n_rows rows big enough for the tile-list kernel on a conv between c_a and c_b channels?"""
+    return n_rows >= TL_FWD_MIN_ROWS or (n_rows >= TL_MID_MIN_ROWS and min(c_a, c_b) >= 96)
 # Backward of a convolution on a map of at most this many rows: the weight gradient (plan + kernel + reduce) runs on an
 # auxiliary stream beside the input gradient (+ its reduce); the node forks after `gout` is ready and joins before it
 # returns, so nothing outside sees the second stream.  OFF by default (0): measured on S100k (tools/ab_wall.sh, 2 rounds)
@@ -56,9 +65,9 @@ class SparseConvFunction(Function):
         if CONV_MODE == "tl" and K > 1 and ops.tl_eligible(K, cin, cout, ctx.n_in):
             # forward / input gradient: only on maps of at least TL_FWD_MIN_ROWS rows (measured: 20-30 % faster on the
             # 100 k-row maps, a tie at 48 k rows, slower below); 1x1 convs stay on the first-generation kernel
-            fwd_ok = lists_fwd is not None and n_out >= TL_FWD_MIN_ROWS
+            fwd_ok = lists_fwd is not None and tl_rows_ok(n_out, cin, cout)
             bwd_ok = (ctx.needs_input_grad[0] and ops.tl_eligible(K, cout, cin, n_out) and lists_bwd is not None
-                      and ctx.n_in >= TL_FWD_MIN_ROWS)
+                      and tl_rows_ok(ctx.n_in, cin, cout))
             # weight images: parameters are served from ops' per-device cache (one launch per optimizer step for the
             # whole model); the input-gradient image is requested here too so that it is part of that launch
             wf = ops.weight_image(kernel, False, False, ops.PREP_TL) if fwd_ok else None

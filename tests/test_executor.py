@@ -69,11 +69,12 @@ def test_planned_kernels_are_the_per_module_choice():
         n_in, n_out = S100K[o["lvl_in"]], S100K[o["lvl_out"]]
         if o["K"] == 125:
             continue
-        want_f = "tl" if (o["K"] > 1 and n_out >= F_.TL_FWD_MIN_ROWS) else "x6"
-        want_d = "tl" if (o["K"] > 1 and n_in >= F_.TL_FWD_MIN_ROWS) else "x6"
+        want_f = "tl" if (o["K"] > 1 and F_.tl_rows_ok(n_out, o["cin"], o["cout"])) else "x6"
+        want_d = "tl" if (o["K"] > 1 and F_.tl_rows_ok(n_in, o["cin"], o["cout"])) else "x6"
         assert (kf, kd) == (want_f, want_d), (i, o, kf, kd)
         assert kw == ("wgrad_tl" if (o["K"] > 1 or max(o["cin"], o["cout"]) <= 128) else "wgrad")
-    assert sum(k[1] == "tl" for k in ks) == 5 and sum(k[2] == "tl" for k in ks) == 5      # the 10 tile-list launches of a step
+    # level 0 (101 k rows): every 3^3 / 2^3 conv; levels 1 and 2 (48 k / 13 k rows): the decoder's >= 96-channel convs
+    assert sum(k[1] == "tl" for k in ks) == 15 and sum(k[2] == "tl" for k in ks) >= 13
 
 
 def test_executor_is_not_used_outside_its_configuration(monkeypatch):
