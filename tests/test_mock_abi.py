@@ -39,6 +39,8 @@ def mock_ops(monkeypatch):
     monkeypatch.setattr(_lib, "require_device", lambda dev: None)
     monkeypatch.setattr(ops, "_prep", lambda dev: lib)
     monkeypatch.setattr(ops, "_stream", lambda dev: None)
+    monkeypatch.setattr(ops, "_idx", lambda dev: 0)
+    monkeypatch.setattr(ops, "_tl_counters", {})
     monkeypatch.setattr(ops, "_ws", lambda nbytes, dev: torch.empty(max(int(nbytes), 16), dtype=torch.uint8))
     monkeypatch.setattr(ops, "_size_cache", {})
     monkeypatch.setattr(ops, "_plan_cache", {})

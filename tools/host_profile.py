@@ -77,6 +77,7 @@ def main():
     _lib.require_device = lambda dev: None
     ops._prep = lambda dev: mock
     ops._stream = lambda dev: None
+    ops._idx = lambda dev: 0
     ops._raw_stream = lambda dev: 0
 
     class NoDev:
