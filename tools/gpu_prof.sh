@@ -1,0 +1,14 @@
+#!/bin/bash
+# kernel trace of the training step: per-kernel and per-group launches / ms per step, per-stream busy time.  usage: gpu_prof.sh <tag> [bench args]
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$1
+shift
+mkdir -p $O
+cd /tmp
+export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o trace -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events --train-only "$@" > $O/prof.json 2> $O/prof.err
+python $R/tools/rocpd_stats.py $O/prof/trace_results.db 13 > $O/stats.csv
+python $R/tools/rocpd_stats.py $O/prof/trace_results.db --streams 13 > $O/streams.txt
+python $R/tools/group_stats.py $O/stats.csv > $O/groups.txt
+rm -rf $O/prof
+cat $O/groups.txt; tail -n 6 $O/streams.txt | cut -c1-150
