@@ -270,6 +270,29 @@ int osn_spconv_wgrad_tl_partial(const float* in, const float* gout, const void* 
                                 osn_wgrad_job* job_host, osn_stream_t stream);
 int osn_wgrad_tl_reduce_batch(const osn_wgrad_job* jobs_host, int n_jobs, osn_stream_t stream);
 
+/* Convolution of a SMALL map (<= 16 k rows) from its per-offset pair arrays, weight-stationary ([ME]
+ * MinkowskiConvolution[Transpose] forward, models/mink_unet.py:51-113 on the 1/4 .. 1/16 levels; with the input-gradient
+ * weight image also their backward):  a workgroup keeps W[k] of ONE offset in registers and multiplies a chunk of that
+ * offset's pairs, writes the result rows to partial[k][dst row]; a second launch sums out[r] over the offsets k the
+ * destination table has at r, ascending (fixed order, bitwise reproducible).  Same arithmetic and weight images as
+ * osn_spconv_fwd_tl (osn_weight_prep_tl: forward image, or the input-gradient image for a backward launch).
+ *   pl / pl_rows  pair arrays (osn_pair_lists_build) of a map with pl_rows output rows;
+ *   swap = 0      gathers pin -> writes pout: the map's own direction (pl_rows == n_dst);
+ *   swap = 1      gathers pout -> writes pin: the transposed direction (pl_rows == n_in) -- input gradient of a strided
+ *                 convolution, forward of the transposed convolution that mirrors it;
+ *   nbr_dst       int32 [K, n_dst] neighbour table of the DESTINATION side in plain row order (>= 0 <=> partial[k][r] was
+ *                 written): nbr_fwd for swap = 0, the transposed table (osn_kmap_transpose) for swap = 1.
+ *   direct = 1    the caller guarantees that every destination row has EXACTLY ONE pair in the whole map -- the fine side
+ *                 of a 2^3 stride-2 map (a voxel has one parent cell): forward of [ME] MinkowskiConvolutionTranspose
+ *                 (kernel 2, stride 2) and input gradient of the strided convolution.  The result rows then go straight to
+ *                 `out`: no partial rows, no second launch, any map size; nbr_dst may be null.
+ * ws: osn_spconv_fwd_ws_ws_bytes(n_dst, K, cout, direct) bytes (the partial rows).  Needs 2 <= K <= 128,
+ * cin % 4 == cout % 4 == 0. */
+size_t osn_spconv_fwd_ws_ws_bytes(int64_t n_dst, int K, int cout, int direct);
+int osn_spconv_fwd_ws(const float* in, int64_t n_in, const void* Wp, const void* pl, int64_t pl_rows, int swap, int direct,
+                      const int32_t* nbr_dst, float* out, int64_t n_dst, int K, int cin, int cout, void* ws,
+                      size_t ws_bytes, osn_stream_t stream);
+
 /* The 3-channel stem convolution (conv0p1s1: 5^3 kernel, 3 -> 32, models/mink_unet.py:47-50): same contract as
  * osn_spconv_fwd on the plain (unordered) table, exact fp32 FMA chain in ascending offset order, for cin <= 4
  * and cout == 32 (no contraction worth a matrix unit; the op streams the 125 x n_out table once).            */
@@ -443,16 +466,23 @@ typedef struct osn_net_op {
     int32_t copy_buf, copy_col;  /* second store of dst: columns [copy_col, copy_col + cout) of buffer copy_buf   */
     int32_t weight;              /* index into osn_net_run.weights                                                */
     int32_t need_dgrad;          /* 0: the input needs no gradient (stem)                                         */
-} osn_net_op;                    /* 64 bytes */
+    int32_t fine_unique;         /* 1: `map` is a 2^3 stride-2 map -- every row of its fine side has exactly one pair
+                                  *    (osn_spconv_fwd_ws direct mode for the launches that write the fine side)   */
+    int32_t reserved;
+} osn_net_op;                    /* 72 bytes */
 typedef struct osn_net_buf { int32_t level, channels; } osn_net_buf;
 typedef struct osn_net_desc {
     int32_t n_ops, n_bufs, n_bns, n_weights, n_maps, n_levels;
     int32_t tl_min_rows;         /* tile-list forward / input gradient on tables of at least this many rows       */
     int32_t tl_mid_rows;         /* ... and from this many rows on when both channel counts are >= 96 (0 = never)  */
+    int32_t ws_max_rows;         /* weight-stationary kernel (osn_spconv_fwd_ws) for launches writing at most this
+                                  *    many rows (0 = never; the direct mode of fine_unique maps is not limited)   */
+    int32_t reserved;
     const osn_net_op* ops;
     const osn_net_buf* bufs;
 } osn_net_desc;
-enum { OSN_NET_K_NONE = 0, OSN_NET_K_STEM = 1, OSN_NET_K_TL = 2, OSN_NET_K_X6 = 3, OSN_NET_K_WGRAD_TL = 4, OSN_NET_K_WGRAD = 5 };
+enum { OSN_NET_K_NONE = 0, OSN_NET_K_STEM = 1, OSN_NET_K_TL = 2, OSN_NET_K_X6 = 3, OSN_NET_K_WGRAD_TL = 4, OSN_NET_K_WGRAD = 5,
+       OSN_NET_K_WS = 6, OSN_NET_K_WS_DIRECT = 7 };
 enum { OSN_NET_IMG_X6_FWD = 1, OSN_NET_IMG_X6_DGRAD = 2, OSN_NET_IMG_TL_FWD = 4, OSN_NET_IMG_TL_DGRAD = 8 };
 typedef struct osn_net_plan {                 /* every array is caller-provided HOST memory                       */
     uint64_t fwd_arena_bytes, bwd_arena_bytes, ws_bytes;
@@ -472,7 +502,7 @@ typedef struct osn_net_map {                  /* one kernel map of the coordinat
     const int64_t* counts;       /* [K] pairs per offset                                                          */
     const void* tl_fwd; const int32_t* tl_fwd_rows;     /* osn_tile_lists_build of the forward table (+ permutation) */
     const void* tl_bwd; const int32_t* tl_bwd_rows;
-    const void* pl_fwd;          /* osn_pair_lists_build of tl_fwd (weight gradient), null in inference            */
+    const void* pl_fwd;          /* osn_pair_lists_build of tl_fwd: weight gradient, weight-stationary convolutions  */
     int32_t K, flip, tl_fwd_bm, tl_bwd_bm;
 } osn_net_map;
 typedef struct osn_net_weight {

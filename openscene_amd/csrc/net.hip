@@ -41,6 +41,15 @@ static bool tl_eligible(int K, int cin, int cout, int64_t n_in) {
 static bool tl_rows_ok(const osn_net_desc* net, int64_t rows, int ca, int cb) {
     return rows >= net->tl_min_rows || (net->tl_mid_rows > 0 && rows >= net->tl_mid_rows && ca >= 96 && cb >= 96);
 }
+// functional.ws_kernel: the weight-stationary kernel for a launch that gathers n_src rows of ca channels and writes n_dst
+// rows of cb channels -- direct (no partial rows) when the destination is the fine side of a 2^3 stride-2 map, else on the
+// maps of at most ws_max_rows destination rows.  0 = neither.
+static int ws_kernel(const osn_net_desc* net, const osn_net_op& o, int ca, int cb, int64_t n_src, int64_t n_dst, bool dst_fine) {
+    if (o.K <= 1 || !tl_eligible(o.K, ca, cb, n_src)) return 0;
+    if (o.fine_unique && dst_fine) return OSN_NET_K_WS_DIRECT;
+    if (net->ws_max_rows > 0 && n_dst <= net->ws_max_rows) return OSN_NET_K_WS;
+    return 0;
+}
 static bool x6_eligible(int K, int cin, int cout, int64_t n_out) {
     if ((cin & 3) || cin < 8) return false;
     if (int64_t(3) * K * cout * ((cin + 31) / 32 * 32) >= (int64_t(1) << 30)) return false;
@@ -122,10 +131,18 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
         if (stem_eligible(o.K, o.cin, o.cout)) {
             OSN_REQUIRE(!o.transposed, OSN_E_ARG, "osn_net: op %d: transposed stem", i);
             L.fwd_k[i] = OSN_NET_K_STEM;
+        } else if (ws_kernel(net, o, o.cin, o.cout, n_in, n_out, o.transposed != 0) == OSN_NET_K_WS_DIRECT) {
+            L.fwd_k[i] = OSN_NET_K_WS_DIRECT;
+            L.images[i] |= OSN_NET_IMG_TL_FWD;
+            need_ws(osn_spconv_fwd_ws_ws_bytes(n_out, o.K, o.cout, 1));
         } else if (o.K > 1 && tl_eligible(o.K, o.cin, o.cout, n_in) && tl_rows_ok(net, n_out, o.cin, o.cout)) {
             L.fwd_k[i] = OSN_NET_K_TL;
             L.images[i] |= OSN_NET_IMG_TL_FWD;
             need_ws(osn_spconv_fwd_tl_ws_bytes(n_out, o.K, o.cout, osn_tile_rows(n_out)));
+        } else if (ws_kernel(net, o, o.cin, o.cout, n_in, n_out, o.transposed != 0) == OSN_NET_K_WS) {
+            L.fwd_k[i] = OSN_NET_K_WS;
+            L.images[i] |= OSN_NET_IMG_TL_FWD;
+            need_ws(osn_spconv_fwd_ws_ws_bytes(n_out, o.K, o.cout, 0));
         } else if (x6_eligible(o.K, o.cin, o.cout, n_out)) {
             L.fwd_k[i] = OSN_NET_K_X6;
             L.images[i] |= OSN_NET_IMG_X6_FWD;
@@ -136,10 +153,19 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
         if (!training) continue;
         // ---- input gradient: a convolution of the output gradient with the transposed weights, [n_in, cin]
         if (o.need_dgrad) {
-            if (o.K > 1 && tl_eligible(o.K, o.cout, o.cin, n_out) && tl_eligible(o.K, o.cin, o.cout, n_in) && tl_rows_ok(net, n_in, o.cin, o.cout)) {
+            const int wsk = tl_eligible(o.K, o.cin, o.cout, n_in) ? ws_kernel(net, o, o.cout, o.cin, n_out, n_in, o.transposed == 0) : 0;
+            if (wsk == OSN_NET_K_WS_DIRECT) {
+                L.dgrad_k[i] = OSN_NET_K_WS_DIRECT;
+                L.images[i] |= OSN_NET_IMG_TL_DGRAD;
+                need_ws(osn_spconv_fwd_ws_ws_bytes(n_in, o.K, o.cin, 1));
+            } else if (o.K > 1 && tl_eligible(o.K, o.cout, o.cin, n_out) && tl_eligible(o.K, o.cin, o.cout, n_in) && tl_rows_ok(net, n_in, o.cin, o.cout)) {
                 L.dgrad_k[i] = OSN_NET_K_TL;
                 L.images[i] |= OSN_NET_IMG_TL_DGRAD;
                 need_ws(osn_spconv_fwd_tl_ws_bytes(n_in, o.K, o.cin, osn_tile_rows(n_in)));
+            } else if (wsk == OSN_NET_K_WS) {
+                L.dgrad_k[i] = OSN_NET_K_WS;
+                L.images[i] |= OSN_NET_IMG_TL_DGRAD;
+                need_ws(osn_spconv_fwd_ws_ws_bytes(n_in, o.K, o.cin, 0));
             } else if (x6_eligible(o.K, o.cout, o.cin, n_in)) {
                 L.dgrad_k[i] = OSN_NET_K_X6;
                 L.images[i] |= OSN_NET_IMG_X6_DGRAD;
@@ -236,8 +262,13 @@ static MapView view_of(const osn_net_map& m, bool transposed) {
 static int run_conv(int kernel, const float* in, int64_t n_in, float* out, int64_t n_out, int K, int cin, int cout,
                     const float* W, const void* img_x6, const void* img_tl, const int32_t* nbr, const int32_t* t_rows,
                     const int32_t* t_tbl, const uint32_t* t_g, const void* tl, const int32_t* tl_rows, int tl_bm,
-                    const osn_net_run* run, osn_stream_t stream, int op) {
+                    const void* pl, int64_t pl_rows, int pl_swap, const osn_net_run* run, osn_stream_t stream, int op) {
     switch (kernel) {
+        case OSN_NET_K_WS:
+        case OSN_NET_K_WS_DIRECT:
+            OSN_REQUIRE(pl && img_tl && nbr, OSN_E_ARG, "osn_net: op %d: pair arrays / tile-list weight image / destination table missing", op);
+            return osn_spconv_fwd_ws(in, n_in, img_tl, pl, pl_rows, pl_swap, kernel == OSN_NET_K_WS_DIRECT ? 1 : 0, nbr, out, n_out, K,
+                                     cin, cout, run->ws, size_t(run->ws_bytes), stream);
         case OSN_NET_K_STEM:
             OSN_REQUIRE(nbr && W, OSN_E_ARG, "osn_net: op %d: the stem kernel needs the plain table and the fp32 weight", op);
             return osn_stem_conv_fwd(in, W, nbr, out, n_out, K, cin, cout, stream);
@@ -337,8 +368,10 @@ extern "C" int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, 
         }
         {
             Bracket br(run->prof, i, 0, on_side ? side : st);
+            // pair arrays: those of the map's own (strided / self) direction; a transposed conv walks them the other way
             rc = run_conv(L.fwd_k[i], in, n_in, x, n_out, o.K, o.cin, o.cout, w.W, w.x6_fwd, w.tl_fwd, v.nbr_f, v.tf_rows, v.tf_tbl,
-                          v.tf_g, v.tl_f, v.tl_f_rows, v.tl_f_bm, r, sstream, i);
+                          v.tf_g, v.tl_f, v.tl_f_rows, v.tl_f_bm, o.map >= 0 ? run->maps[o.map].pl_fwd : nullptr,
+                          o.transposed ? n_in : n_out, o.transposed ? 1 : 0, r, sstream, i);
         }
         if (rc) return rc;
         if (o.bn < 0) continue;
@@ -498,8 +531,12 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
             float* gin = reinterpret_cast<float*>(B + L.gin_off[i]);
             {
                 Bracket br(run->prof, i, 1, on_side ? side : st);
+                // a self map (flip) is its own mirror: same direction of the pair arrays with the mirrored weight image;
+                // otherwise the input gradient walks them the other way round
+                const int swap_f = o.transposed ? 1 : 0;
                 rc = run_conv(L.dgrad_k[i], gx, n_out, gin, n_in, o.K, o.cout, o.cin, nullptr, w.x6_dgrad, w.tl_dgrad, v.nbr_b, v.tb_rows,
-                              v.tb_tbl, v.tb_g, v.tl_b, v.tl_b_rows, v.tl_b_bm, r, sstream, i);
+                              v.tb_tbl, v.tb_g, v.tl_b, v.tl_b_rows, v.tl_b_bm, m ? m->pl_fwd : nullptr, o.transposed ? n_in : n_out,
+                              (m && m->flip) ? swap_f : 1 - swap_f, r, sstream, i);
             }
             if (rc) return rc;
             if (on_side) {

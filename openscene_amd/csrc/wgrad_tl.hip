@@ -19,6 +19,7 @@
 //   * 4 waves as 2 x 2 over the (input channel, output channel) block, MB x NB accumulator blocks of 16 x 16
 //     per wave, six MFMAs per block and step (a3g1 + a2g2 + a1g3 + a2g1 + a1g2 + a1g1, fp32 accumulate).
 #include "common.h"
+#include "pairlist.h"
 
 namespace osn {
 
@@ -26,41 +27,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-constexpr int PL_KMAX = 128;          // offsets per map (5^3 = 125)
-constexpr int PL_ITEMS = 512;         // work items per map: one round of 2 workgroups per CU
-constexpr int PL_MIN_QUOTA = 256;     // pairs per item at least (bounds the partial-sum traffic of small maps)
-
-// ---- layout of a pair-list buffer ("pl")
-constexpr size_t PL_OFF_POFF = 0;                                   // int32 [PL_KMAX + 1] first pair of each offset
-constexpr size_t PL_OFF_TOTAL = 1024;                               // int32 [PL_KMAX]     pairs of each offset
-constexpr size_t PL_OFF_ITEMS = 2048;                               // int4  [PL_ITEMS]    (k, p0, p1, 0), k = -1 unused
-constexpr size_t PL_OFF_RANGE = PL_OFF_ITEMS + size_t(PL_ITEMS) * 16;   // int2 [PL_KMAX]  items of each offset [first, last)
-constexpr size_t PL_OFF_PAIRS = 16384;                              // int32 pin[cap], pout[cap], then the tile-prefix scratch
-
-struct PlView {
-    int32_t *poff, *total;
-    int4* items;
-    int2* range;
-    int32_t *pin, *pout, *pref;
-    size_t bytes;
-};
-
-static PlView pl_view(void* base, int64_t n_out, int K, int bm) {
-    PlView v;
-    char* p = static_cast<char*>(base);
-    const size_t cap = size_t(K) * size_t(n_out > 0 ? n_out : 1);
-    const size_t nt = size_t(cdiv(n_out > 0 ? n_out : 1, bm > 0 ? bm : 1));
-    v.poff = reinterpret_cast<int32_t*>(p + PL_OFF_POFF);
-    v.total = reinterpret_cast<int32_t*>(p + PL_OFF_TOTAL);
-    v.items = reinterpret_cast<int4*>(p + PL_OFF_ITEMS);
-    v.range = reinterpret_cast<int2*>(p + PL_OFF_RANGE);
-    v.pin = reinterpret_cast<int32_t*>(p + PL_OFF_PAIRS);
-    v.pout = v.pin + cap;
-    v.pref = v.pout + cap;
-    v.bytes = PL_OFF_PAIRS + (2 * cap + size_t(K) * nt) * 4;
-    return v;
-}
 
 __device__ inline int wave_incl_scan_i32(int v, int lane) {
 #pragma unroll

@@ -28,7 +28,7 @@ SIDE_STREAM = os.environ.get("OSN_SIDE_STREAM", "1") != "0"
 _DRY_RUN = False        # tools/dryrun only: accept host tensors (a null HIP runtime logs the launches instead of running them)
 
 _OP = np.dtype([(n, "<i4") for n in ("K", "cin", "cout", "lvl_in", "lvl_out", "map", "transposed", "src", "dst", "bn", "relu",
-                                     "res", "copy_buf", "copy_col", "weight", "need_dgrad")])
+                                     "res", "copy_buf", "copy_col", "weight", "need_dgrad", "fine_unique", "reserved")])
 _BUF = np.dtype([("level", "<i4"), ("channels", "<i4")])
 _MAP = np.dtype([(n, "<u8") for n in ("nbr_fwd", "nbr_bwd", "tiles_fwd_rows", "tiles_fwd_tbl", "tiles_fwd_gmask",
                                       "tiles_bwd_rows", "tiles_bwd_tbl", "tiles_bwd_gmask", "counts", "tl_fwd", "tl_fwd_rows",
@@ -37,16 +37,18 @@ _MAP = np.dtype([(n, "<u8") for n in ("nbr_fwd", "nbr_bwd", "tiles_fwd_rows", "t
 _WEIGHT = np.dtype([(n, "<u8") for n in ("W", "x6_fwd", "x6_dgrad", "tl_fwd", "tl_dgrad", "gW")])
 _BN = np.dtype([(n, "<u8") for n in ("gamma", "beta", "running_mean", "running_var", "ggamma", "gbeta")] +
                [("eps", "<f4"), ("momentum", "<f4")])
-assert _OP.itemsize == 64 and _MAP.itemsize == 128 and _WEIGHT.itemsize == 48 and _BN.itemsize == 56
+assert _OP.itemsize == 72 and _MAP.itemsize == 128 and _WEIGHT.itemsize == 48 and _BN.itemsize == 56
 
 IMG_X6_FWD, IMG_X6_DGRAD, IMG_TL_FWD, IMG_TL_DGRAD = 1, 2, 4, 8
-K_NAMES = {0: "none", 1: "stem", 2: "tl", 3: "x6", 4: "wgrad_tl", 5: "wgrad"}
+K_NAMES = {0: "none", 1: "stem", 2: "tl", 3: "x6", 4: "wgrad_tl", 5: "wgrad", 6: "ws", 7: "ws_direct"}
+K_WS = (6, 7)
 
 
 class _Desc(ctypes.Structure):
     _fields_ = [("n_ops", ctypes.c_int32), ("n_bufs", ctypes.c_int32), ("n_bns", ctypes.c_int32), ("n_weights", ctypes.c_int32),
                 ("n_maps", ctypes.c_int32), ("n_levels", ctypes.c_int32), ("tl_min_rows", ctypes.c_int32),
-                ("tl_mid_rows", ctypes.c_int32), ("ops", ctypes.c_void_p), ("bufs", ctypes.c_void_p)]
+                ("tl_mid_rows", ctypes.c_int32), ("ws_max_rows", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("ops", ctypes.c_void_p), ("bufs", ctypes.c_void_p)]
 
 
 class _Plan(ctypes.Structure):
@@ -141,7 +143,8 @@ class Program:
         self.ops.append(dict(K=conv.kernel_volume, cin=conv.in_channels, cout=conv.out_channels, lvl_in=lvl_in, lvl_out=lvl_out,
                              map=self._map(conv, lvl_in, lvl_out, transposed), transposed=int(transposed), src=src, dst=dst, bn=bn,
                              relu=int(relu), res=res, copy_buf=copy[0] if copy else -1, copy_col=copy[1] if copy else 0,
-                             weight=len(self.convs) - 1, need_dgrad=int(need_dgrad)))
+                             weight=len(self.convs) - 1, need_dgrad=int(need_dgrad),
+                             fine_unique=int(conv.kernel_size == 2 and conv.stride == 2 and conv.dilation == 1), reserved=0))
         if relu and dst >= 0:
             self.relu_bufs.append(dst)
         return dst
@@ -171,7 +174,7 @@ class UNetExecutor:
     def __init__(self, model):
         self.program = Program(model)
         p = self.program
-        self.desc = _Desc(len(p.ops), len(p.bufs), len(p.bns), len(p.convs), len(p.map_keys), p.n_levels, 0, 0,
+        self.desc = _Desc(len(p.ops), len(p.bufs), len(p.bns), len(p.convs), len(p.map_keys), p.n_levels, 0, 0, 0, 0,
                           _ptr(p.op_arr), _ptr(p.buf_arr))
         n = len(p.ops)
         self._x_off = np.zeros(n, np.uint64)
@@ -215,6 +218,7 @@ class UNetExecutor:
         from . import functional as F_
         self.desc.tl_min_rows = int(F_.TL_FWD_MIN_ROWS)
         self.desc.tl_mid_rows = int(F_.TL_MID_MIN_ROWS)
+        self.desc.ws_max_rows = int(F_.WS_MAX_ROWS)
         self._rows[:len(rows)] = rows
         check(lib.osn_net_plan_query(ctypes.addressof(self.desc), _ptr(self._rows), int(training), ctypes.addressof(self._plan)),
               "osn_net_plan_query")
@@ -224,6 +228,9 @@ class UNetExecutor:
         arr = np.zeros(max(len(p.map_keys), 1), dtype=_MAP)
         keep = []
         dp = lambda t: t.data_ptr() if t is not None else 0
+        # pair arrays: every map with lists in training (weight gradients); in inference those a weight-stationary
+        # forward launch reads (the plan of this pass is in self._kf)
+        ws_maps = {int(p.op_arr[j]["map"]) for j in range(len(p.ops)) if int(self._kf[j]) in K_WS}
         for i, (s_in, s_out, k, dil) in enumerate(p.map_keys):
             fwd, bwd, flip = cm.kmap(s_in, s_out, k, dil)
             tf, tb = cm.kmap_tiles(s_in, s_out, k, dil)
@@ -238,7 +245,7 @@ class UNetExecutor:
             a["counts"] = dp(counts)
             if lf is not None:
                 a["tl_fwd"], a["tl_fwd_rows"], a["tl_fwd_bm"] = dp(lf.buf), dp(lf.out_rows), lf.bm
-                if training:
+                if training or i in ws_maps:
                     a["pl_fwd"] = dp(ops.pair_lists(lf))
             if lb is not None:
                 a["tl_bwd"], a["tl_bwd_rows"], a["tl_bwd_bm"] = dp(lb.buf), dp(lb.out_rows), lb.bm
@@ -299,7 +306,7 @@ class UNetExecutor:
         dev = feats.device
         lib = ops._prep(dev)
         training = bool(model.training)
-        cm.prebuild(pairs=grad)
+        cm.prebuild(pairs=True if grad else "ws")
         rows = [cm.size(s) for s in p.STRIDES]
         if feats.shape[0] != rows[0]:
             raise ValueError("%d feature rows for %d voxels" % (feats.shape[0], rows[0]))

@@ -25,6 +25,25 @@ TL_FWD_MIN_ROWS = int(os.environ.get("OSN_TL_FWD_MIN_ROWS", "65536"))
 TL_MID_MIN_ROWS = int(os.environ.get("OSN_TL_MID_MIN_ROWS", "8192"))
 
 
+# Weight-stationary kernel (spconv_ws.hip) for the launches that write at most this many rows (measured, profiles/r03_s9:
+# 3 k rows 128 -> 128 34 us against 45, 256 -> 256 69 / 106-122; 700 rows 256 -> 256 30 / 43; a tie at 12.9 k rows), and --
+# without a row limit -- for the launches that write the fine side of a 2^3 stride-2 map, where every row has exactly one
+# pair and the result rows go straight to the output (100 k rows 96 -> 96: 32 us against 70; 48 k rows 128 -> 96: 20 / 62)
+WS_MAX_ROWS = int(os.environ.get("OSN_WS_MAX_ROWS", "4096"))
+
+
+def ws_kernel(K, c_src, c_dst, n_src, n_dst, fine_unique, dst_fine):
+    """"ws_direct" / "ws" / None: the weight-stationary kernel for a launch that gathers n_src rows of c_src channels and
+    writes n_dst rows of c_dst channels (same rule as csrc/net.hip:ws_kernel)."""
+    if K <= 1 or not ops.tl_eligible(K, c_src, c_dst, n_src):
+        return None
+    if fine_unique and dst_fine:
+        return "ws_direct"
+    if 0 < n_dst <= WS_MAX_ROWS:
+        return "ws"
+    return None
+
+
 def tl_rows_ok(n_rows, c_a, c_b):
     """Is a table of n_rows rows big enough for the tile-list kernel on a conv between c_a and c_b channels?"""
     return n_rows >= TL_FWD_MIN_ROWS or (n_rows >= TL_MID_MIN_ROWS and min(c_a, c_b) >= 96)
@@ -42,7 +61,7 @@ class SparseConvFunction(Function):
 
     @staticmethod
     def forward(ctx, feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tiles_fwd=None, tiles_bwd=None, counts=None,
-                lists_fwd=None, lists_bwd=None, transposed=False):
+                lists_fwd=None, lists_bwd=None, transposed=False, fine_unique=False):
         ctx.save_for_backward(feats, kernel)
         # weight gradient: the pair arrays of the map (a transposed conv runs on the arrays of the strided conv it
         # mirrors = its own input-gradient lists, with the operand roles swapped)
@@ -54,6 +73,7 @@ class SparseConvFunction(Function):
         tbl, rows, gm = (tiles_fwd[1], tiles_fwd[0], tiles_fwd[2]) if tiles_fwd is not None else (nbr_fwd, None, None)
         ctx.wp_dgrad = None
         ctx.tl_bwd = None
+        ctx.ws_bwd = None
         # the cached weight images are shared and refreshed in place: remember which version of the kernel the image kept
         # for the backward pass belongs to (a weight changed through .data between forward and backward bypasses autograd's
         # own saved-tensor check)
@@ -63,11 +83,26 @@ class SparseConvFunction(Function):
         if ctx.stem:
             return ops.stem_conv_fwd(feats, kernel, nbr_fwd, n_out)
         if CONV_MODE == "tl" and K > 1 and ops.tl_eligible(K, cin, cout, ctx.n_in):
+            # weight-stationary kernel from the map's pair arrays (those of the strided / self direction: a transposed conv
+            # walks them the other way): forward, and -- decided here, launched in backward -- the input gradient, which on
+            # a self map (flip) keeps the direction and takes the mirrored weight image
+            pl, swap_f = ctx.wg_lists
+            ws_f = ws_kernel(K, cin, cout, ctx.n_in, n_out, fine_unique, transposed) if pl is not None else None
+            ws_b = (ws_kernel(K, cout, cin, n_out, ctx.n_in, fine_unique, not transposed)
+                    if pl is not None and ctx.needs_input_grad[0] and ops.tl_eligible(K, cout, cin, n_out) else None)
             # forward / input gradient: only on maps of at least TL_FWD_MIN_ROWS rows (measured: 20-30 % faster on the
             # 100 k-row maps, a tie at 48 k rows, slower below); 1x1 convs stay on the first-generation kernel
-            fwd_ok = lists_fwd is not None and tl_rows_ok(n_out, cin, cout)
+            fwd_ok = lists_fwd is not None and tl_rows_ok(n_out, cin, cout) and ws_f != "ws_direct"
             bwd_ok = (ctx.needs_input_grad[0] and ops.tl_eligible(K, cout, cin, n_out) and lists_bwd is not None
-                      and tl_rows_ok(ctx.n_in, cin, cout))
+                      and tl_rows_ok(ctx.n_in, cin, cout) and ws_b != "ws_direct")
+            if ws_b is not None and not bwd_ok:
+                ctx.ws_bwd = (ops.weight_image(kernel, flip, True, ops.PREP_TL), pl, swap_f if flip else not swap_f,
+                              ws_b == "ws_direct")
+            if ws_f is not None and not fwd_ok:
+                wf = ops.weight_image(kernel, False, False, ops.PREP_TL)
+                if bwd_ok:
+                    ctx.wp_dgrad, ctx.tl_bwd = ops.weight_image(kernel, flip, True, ops.PREP_TL), lists_bwd
+                return ops.spconv_fwd_ws(feats, wf, pl, nbr_fwd, n_out, K, cout, swap=swap_f, direct=ws_f == "ws_direct")
             # weight images: parameters are served from ops' per-device cache (one launch per optimizer step for the
             # whole model); the input-gradient image is requested here too so that it is part of that launch
             wf = ops.weight_image(kernel, False, False, ops.PREP_TL) if fwd_ok else None
@@ -77,7 +112,7 @@ class SparseConvFunction(Function):
                 return ops.spconv_fwd_tl(feats, wf, lists_fwd, n_out, K, cout)
         if mode == "bf16x6" and ops.x6_eligible(K, cin, cout, n_out):
             wp = ops.weight_image(kernel, False, False, ops.PREP_X6)
-            if ctx.needs_input_grad[0] and ctx.tl_bwd is None and ops.x6_eligible(K, cout, cin, ctx.n_in):
+            if ctx.needs_input_grad[0] and ctx.tl_bwd is None and ctx.ws_bwd is None and ops.x6_eligible(K, cout, cin, ctx.n_in):
                 ctx.wp_dgrad = ops.weight_image(kernel, flip, True, ops.PREP_X6)
             return ops.spconv_fwd_x6(feats, wp, tbl, n_out, out_rows=rows, gmask=gm)
         return ops.spconv_fwd(feats, kernel, tbl, n_out, out_rows=rows, gmask=gm)
@@ -89,7 +124,7 @@ class SparseConvFunction(Function):
         gout = gout.contiguous()
         gin = gk = None
         K = 1 if kernel.dim() == 2 else kernel.shape[0]
-        if ctx.wp_dgrad is not None and ctx.kver != (kernel._version, kernel.data_ptr()):
+        if (ctx.wp_dgrad is not None or ctx.ws_bwd is not None) and ctx.kver != (kernel._version, kernel.data_ptr()):
             raise RuntimeError("a convolution kernel changed between its forward and its backward pass (version %d -> %d): "
                                "the input-gradient weight image kept from the forward is stale" % (ctx.kver[0], kernel._version))
 
@@ -123,6 +158,10 @@ class SparseConvFunction(Function):
             if ctx.tl_bwd is not None:
                 gin = ops.spconv_fwd_tl(gout, ctx.wp_dgrad, ctx.tl_bwd, ctx.n_in, K, cin)
                 ctx.wp_dgrad = ctx.tl_bwd = None
+            elif ctx.ws_bwd is not None:
+                wb, pl, swap_b, direct = ctx.ws_bwd
+                gin = ops.spconv_fwd_ws(gout, wb, pl, nbr_bwd, ctx.n_in, K, cin, swap=swap_b, direct=direct)
+                ctx.ws_bwd = None
             elif mode == "bf16x6" and ops.x6_eligible(K, cout, cin, ctx.n_in):
                 wp = ctx.wp_dgrad if ctx.wp_dgrad is not None else ops.weight_image(kernel, flip, True, ops.PREP_X6)
                 ctx.wp_dgrad = None
@@ -131,7 +170,7 @@ class SparseConvFunction(Function):
                 gin = ops.spconv_fwd(gout, ops.weight_transpose(kernel, flip), tbl, ctx.n_in, out_rows=rows, gmask=gm)
         if side is not None:
             main.wait_stream(side)                        # join: later work on this stream sees the weight gradient
-        return gin, gk, None, None, None, None, None, None, None, None, None, None
+        return gin, gk, None, None, None, None, None, None, None, None, None, None, None
 
 
 class BatchNormActFunction(Function):
@@ -222,13 +261,15 @@ def cat(ts):
     return out
 
 
-def sparse_conv(feats, kernel, maps, n_out, tiles=None, counts=None, lists=None, transposed=False):
+def sparse_conv(feats, kernel, maps, n_out, tiles=None, counts=None, lists=None, transposed=False, fine_unique=False):
     """maps = CoordinateManager.kmap(...); tiles = .kmap_tiles(...) or None; counts = .kmap_counts(...) or None;
-    lists = .kmap_lists(...) or None; transposed: the conv is a MinkowskiConvolutionTranspose."""
+    lists = .kmap_lists(...) or None; transposed: the conv is a MinkowskiConvolutionTranspose; fine_unique: the map is a
+    2^3 stride-2 map (every row of its fine side has exactly one pair)."""
     nbr_fwd, nbr_bwd, flip = maps
     tf, tb = tiles if tiles is not None else (None, None)
     lf, lb = lists if lists is not None else (None, None)
-    return SparseConvFunction.apply(feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tf, tb, counts, lf, lb, bool(transposed))
+    return SparseConvFunction.apply(feats, kernel, nbr_fwd, nbr_bwd, flip, n_out, tf, tb, counts, lf, lb, bool(transposed),
+                                    bool(fine_unique))
 
 
 _tls = threading.local()

@@ -89,7 +89,8 @@ class MinkowskiConvolutionBase(nn.Module):
         if F_.CONV_MODE == "tl" and self.kernel_volume > 1 and F_.ops.tl_eligible(self.kernel_volume, self.in_channels,
                                                                                   self.out_channels):
             lists = cm.kmap_lists(s_in, s_out, self.kernel_size, self.dilation)
-        out = F_.sparse_conv(x.F, self.kernel, maps, cm.size(s_out), tiles, counts, lists, transposed=self.TRANSPOSED)
+        out = F_.sparse_conv(x.F, self.kernel, maps, cm.size(s_out), tiles, counts, lists, transposed=self.TRANSPOSED,
+                             fine_unique=self.kernel_size == 2 and self.stride == 2 and self.dilation == 1)
         if self.bias is not None:
             out = out + self.bias
         return SparseTensor(out, tensor_stride=s_out, coordinate_manager=cm)

@@ -731,6 +731,37 @@ def spconv_wgrad_tl(feats, gout, tl, K, swap=False):
     return gw
 
 
+def spconv_fwd_ws(feats, wp, tl, nbr_dst, n_dst, K, cout, swap=False, direct=False):
+    """Convolution of a small map from the pair arrays of `tl` (weight-stationary workgroups + ordered sum over the
+    offsets): out[r] = sum_k feats[src of (k, r)] @ B[k], B a weight_prep_tl image.  nbr_dst int32 [K, n_dst]: the
+    neighbour table of the destination side, plain row order.  swap: `tl` belongs to the map's transposed direction.
+    direct: every destination row has exactly one pair in the map (fine side of a 2^3 stride-2 map): rows are written
+    straight to the output, nbr_dst may be None."""
+    dev = feats.device
+    lib = _prep(dev)
+    feats = _f32c(feats, "features")
+    n_in, cin = feats.shape
+    table_rows = n_in if swap else n_dst
+    if tl.K != K or tl.n_out != table_rows:
+        raise ValueError("pair lists are for a [%d, %d] table, the convolution wants [%d, %d]" % (tl.K, tl.n_out, K, table_rows))
+    if not (direct and nbr_dst is None) and (nbr_dst.dtype != torch.int32 or tuple(nbr_dst.shape) != (K, n_dst)):
+        raise ValueError("nbr_dst must be int32 [%d, %d], got %s %s" % (K, n_dst, nbr_dst.dtype, tuple(nbr_dst.shape)))
+    need = _cached("osn_weight_prep_tl_bytes", K, cin, cout, 0)
+    if wp.numel() != need:
+        raise ValueError("prepared weight has %d bytes, a [%d, %d, %d] conv needs %d" % (wp.numel(), K, cin, cout, need))
+    pl = pair_lists(tl)
+    out = torch.empty((n_dst, cout), dtype=torch.float32, device=dev)
+    ws = _ws(_cached("osn_spconv_fwd_ws_ws_bytes", n_dst, K, cout, int(bool(direct))), dev)
+    tok = _prof_start("spconv_fwd_ws", dev, n_in=n_in, n_out=n_dst, K=K, cin=cin, cout=cout)
+    with _Dev(dev):
+        check(lib.osn_spconv_fwd_ws(_p(feats), n_in, _p(wp), _p(pl), table_rows, int(bool(swap)), int(bool(direct)),
+                                    _p(nbr_dst.contiguous() if nbr_dst is not None else None),
+                                    _p(out), n_dst, K, cin, cout, _p(ws), ws.numel(), _stream(dev)), "osn_spconv_fwd_ws")
+    if tok is not None:
+        _profiler.stop(tok)
+    return out
+
+
 def stem_eligible(K, cin, cout):
     """The dedicated kernels of the U-Net's 3-channel stem conv (any conv with <= 4 input and 32 output channels)."""
     return cin <= 4 and cout == 32 and 1 < K <= 125

@@ -119,7 +119,8 @@ class CoordinateManager:
         stopping at every first use of a map.  (The pyramid's levels 1 ... 16 were built by the constructor with one
         host synchronisation; a level beyond them costs one read-back of its unique count here.)
         On the device all maps come from ONE C call that deals the levels' independent chains of launches to several
-        streams (ops.maps_build); pairs: also build the pair lists the weight gradients need (training)."""
+        streams (ops.maps_build); pairs: True = also build the pair arrays of every map (training: the weight gradients),
+        "ws" = only those a weight-stationary convolution reads in inference (2^3 stride-2 maps, maps of the deep levels)."""
         for s in strides:
             self.coords(s)
         levels = (1,) + tuple(strides)
@@ -184,7 +185,7 @@ class CoordinateManager:
                     bm = ops.tile_rows(rows)
                     e["bm_" + side] = bm
                     e["tl_" + side] = take(ops._cached("osn_tile_lists_bytes", rows, K, bm))
-            if pairs and "tl_fwd" in e:
+            if "tl_fwd" in e and (pairs is True or (pairs == "ws" and ((k == 2 and so == 2 * si) or n_out <= _F_mod().WS_MAX_ROWS))):
                 e["pl_fwd"] = take(ops._cached("osn_pair_lists_bytes", n_out, K, e["bm_fwd"]))
             plan.append(e)
         if not plan:

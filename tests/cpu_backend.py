@@ -231,6 +231,31 @@ def spconv_wgrad_tl(feats, gout, tl, K, swap=False):
     return gw
 
 
+def spconv_fwd_ws(feats, wp, tl, nbr_dst, n_dst, K, cout, swap=False, direct=False):
+    """Spec of osn_spconv_fwd_ws, evaluated FROM THE PAIR ARRAYS: partial[k][dst] = feats[src] @ B[k] for every pair of
+    offset k, then the sum over the offsets the destination table has at a row, ascending.  direct: every destination row
+    must occur exactly once in the whole map."""
+    w = wp[1]
+    poff, pin, pout = pair_arrays(tl)
+    src, dst = (pout, pin) if swap else (pin, pout)
+    out = feats.new_zeros((n_dst, cout))
+    seen = np.zeros(n_dst, dtype=np.int64)
+    for k in range(K):
+        a, b = int(poff[k]), int(poff[k + 1])
+        if b > a:
+            d = dst[a:b].long()
+            assert torch.unique(d).numel() == d.numel(), "a destination row twice in one offset"
+            if not direct:
+                assert bool((nbr_dst[k][d] >= 0).all()), "a pair the destination table does not know"
+            out[d] += feats[src[a:b].long()] @ w[k]
+            seen[d.numpy()] += 1
+        if not direct:
+            assert int((nbr_dst[k] >= 0).sum()) == b - a, "the destination table has entries without a pair"
+    if direct:
+        assert (seen == 1).all(), "direct mode needs exactly one pair per destination row"
+    return out
+
+
 def stem_eligible(K, cin, cout):
     return cin <= 4 and cout == 32 and 1 < K <= 125
 
@@ -397,7 +422,7 @@ def cat2_bwd(gout, ca, cb):
     return gout[:, :ca].contiguous(), gout[:, ca:ca + cb].contiguous()
 
 
-_NAMES = ["relu_fwd", "relu_bwd", "add", "cat2", "cat2_bwd", "fusion_project", "fusion_accumulate", "fusion_finish", "weight_image", "stem_eligible", "stem_conv_fwd", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "coords_pyramid", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
+_NAMES = ["relu_fwd", "relu_bwd", "add", "cat2", "cat2_bwd", "fusion_project", "fusion_accumulate", "fusion_finish", "weight_image", "stem_eligible", "stem_conv_fwd", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "spconv_fwd_ws", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "coords_pyramid", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
           "spconv_wgrad", "bn_stats", "bn_forward_train", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
           "fnv_hash", "ravel_hash", "feature_remap", "batch_coords"]
 

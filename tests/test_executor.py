@@ -56,8 +56,10 @@ def test_program_covers_the_module_tree(arch):
 
 
 def test_planned_kernels_are_the_per_module_choice():
-    """functional.SparseConvFunction's dispatch, restated: tile-list kernels from TL_FWD_MIN_ROWS table rows on, the
-    split-bf16 output-stationary kernel below, the stem kernel for 3 -> 32, pair-array weight gradient on every
+    """functional.SparseConvFunction's dispatch, restated: the stem kernel for 3 -> 32; the weight-stationary kernel in
+    direct mode for every launch that writes the fine side of a 2^3 stride-2 map; tile-list kernels from TL_FWD_MIN_ROWS
+    table rows on (TL_MID_MIN_ROWS for >= 96 channels); the weight-stationary kernel with partial rows for launches writing
+    at most WS_MAX_ROWS rows; the split-bf16 output-stationary kernel for the rest; pair-array weight gradient on every
     3^3 / 2^3 map and (identity map) for the 1x1 shortcuts up to 128 channels, the table weight gradient for the stem
     and the 96 -> 768 head."""
     from openscene_amd import executor as E
@@ -65,16 +67,32 @@ def test_planned_kernels_are_the_per_module_choice():
     from openscene_amd.mink_unet import mink_unet
     ex = E.for_model(mink_unet(3, 768, 3, "MinkUNet18A"))
     ks = ex.kernels(S100K, training=True)
+
+    def want(o, c_src, c_dst, n_src, n_dst, dst_fine):
+        if o["K"] == 1:
+            return "x6"
+        ws = F_.ws_kernel(o["K"], c_src, c_dst, n_src, n_dst, bool(o["fine_unique"]), dst_fine)
+        if ws == "ws_direct":
+            return ws
+        if F_.tl_rows_ok(n_dst, o["cin"], o["cout"]):
+            return "tl"
+        return ws or "x6"
     for (i, kf, kd, kw), o in zip(ks, ex.program.ops):
         n_in, n_out = S100K[o["lvl_in"]], S100K[o["lvl_out"]]
         if o["K"] == 125:
             continue
-        want_f = "tl" if (o["K"] > 1 and F_.tl_rows_ok(n_out, o["cin"], o["cout"])) else "x6"
-        want_d = "tl" if (o["K"] > 1 and F_.tl_rows_ok(n_in, o["cin"], o["cout"])) else "x6"
+        assert o["fine_unique"] == int(o["K"] == 8)
+        want_f = want(o, o["cin"], o["cout"], n_in, n_out, bool(o["transposed"]))
+        want_d = want(o, o["cout"], o["cin"], n_out, n_in, not o["transposed"])
         assert (kf, kd) == (want_f, want_d), (i, o, kf, kd)
         assert kw == ("wgrad_tl" if (o["K"] > 1 or max(o["cin"], o["cout"]) <= 128) else "wgrad")
-    # level 0 (101 k rows): every 3^3 / 2^3 conv; levels 1 and 2 (48 k / 13 k rows): the decoder's >= 96-channel convs
-    assert sum(k[1] == "tl" for k in ks) == 15 and sum(k[2] == "tl" for k in ks) >= 13
+    # level 0 (101 k rows): every 3^3 conv; levels 1 and 2 (48 k / 13 k rows): the decoder's >= 96-channel 3^3 convs
+    assert sum(k[1] == "tl" for k in ks) == 12 and sum(k[2] == "tl" for k in ks) >= 10
+    # the four transposed convs forward, the four strided convs backward: direct; the 3^3 convs of the two deepest levels
+    # (3 k and 730 rows) and the 2^3 launches that write them: partial rows
+    assert sum(k[1] == "ws_direct" for k in ks) == 4 and sum(k[2] == "ws_direct" for k in ks) == 4
+    assert sum(k[1] == "ws" for k in ks) == 12 + 2 and sum(k[2] == "ws" for k in ks) == 12 + 2
+    assert not any(k[1] == "x6" and o["K"] > 1 and S100K[o["lvl_out"]] <= 4096 for k, o in zip(ks, ex.program.ops))
 
 
 def test_executor_is_not_used_outside_its_configuration(monkeypatch):

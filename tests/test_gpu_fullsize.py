@@ -289,7 +289,7 @@ class _KindRecorder:
         pass
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "tl"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "tl", "ws"])
 @pytest.mark.parametrize("kind", ["row_scales", "cancellation", "gradient_sized", "wide_elements"])
 def test_conv_adversarial_operands(kind, mode, monkeypatch):
     """bf16x6 drops product terms <= 2^-24 of |a||b| and rounds each operand's third piece at 2^-25 of the
@@ -298,12 +298,17 @@ def test_conv_adversarial_operands(kind, mode, monkeypatch):
     Forward, input gradient and weight gradient, all three arithmetic modes, same bound.  "tl" is the product
     default: the tile-list kernel (16x16x32 MFMA, LDS read-add-write accumulation) for forward and input gradient
     and the pair-array weight gradient (transpose-read fragments) -- forced onto this 60 k-point cloud by
-    TL_FWD_MIN_ROWS = 0, with the tile-ordered table and lists the coordinate manager would hand them."""
+    TL_FWD_MIN_ROWS = 0, with the tile-ordered table and lists the coordinate manager would hand them.  "ws": the
+    weight-stationary kernel of the small maps (per-offset partial rows, ordered sum) forced onto the same cloud."""
     from openscene_amd import functional as F_
     from openscene_amd import ops
-    monkeypatch.setattr(F_, "CONV_MODE", mode)
+    monkeypatch.setattr(F_, "CONV_MODE", "tl" if mode == "ws" else mode)
     if mode == "tl":
         monkeypatch.setattr(F_, "TL_FWD_MIN_ROWS", 0)
+    if mode == "ws":
+        monkeypatch.setattr(F_, "TL_FWD_MIN_ROWS", 1 << 30)
+        monkeypatch.setattr(F_, "TL_MID_MIN_ROWS", 1 << 30)
+        monkeypatch.setattr(F_, "WS_MAX_ROWS", 1 << 30)
     v = syn.shuffled(syn.grid_voxels(syn.room_points(3, n_pts=60000), 0.02), 3)
     cm = oc.CoordinateManager(syn.batch_coords([v]))
     nbr_np = cm.kmap(1, 1, 3)
@@ -334,7 +339,7 @@ def test_conv_adversarial_operands(kind, mode, monkeypatch):
     nbr = torch.from_numpy(nbr_np).to(d)
     fg = feats.to(d).requires_grad_(True)
     wg = w.to(d).requires_grad_(True)
-    if mode == "tl":
+    if mode in ("tl", "ws"):
         counts = ops.kmap_count(nbr)
         tiles = ops.kmap_sort(nbr, counts)                            # (order, sorted table, group masks)
         tl = ops.tile_lists(tiles[1], out_rows=tiles[0])
@@ -345,7 +350,7 @@ def test_conv_adversarial_operands(kind, mode, monkeypatch):
             out.backward(gout.to(d))
         finally:
             ops.set_profiler(None)
-        assert rec.kinds.count("spconv_fwd_tl") == 2 and rec.kinds.count("spconv_wgrad_tl") == 1, rec.kinds
+        assert rec.kinds.count("spconv_fwd_" + mode) == 2 and rec.kinds.count("spconv_wgrad_tl") == 1, rec.kinds
     else:
         out = F_.sparse_conv(fg, wg, (nbr, nbr, True), n)
         out.backward(gout.to(d))

@@ -72,18 +72,26 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "tl"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "tl", "ws"])
 @pytest.mark.parametrize("kind,key,cin,cout", CASES)
 def test_forward_and_gradients(kind, key, cin, cout, mode, monkeypatch):
     """All kernel generations / arithmetic modes of the forward / input-gradient convolution meet the SAME
     tolerance: the split-bf16 arithmetic (three bf16 pieces per operand, six MFMAs per product block) is
-    fp32-accurate.  "tl" = the tile-list kernel (spconv_tl.hip), fed with lists built from the oracle's table."""
+    fp32-accurate.  "tl" = the tile-list kernel (spconv_tl.hip), fed with lists built from the oracle's table;
+    "ws" = the weight-stationary kernel (spconv_ws.hip) on every map size, from the pair arrays of those lists, the
+    2^3 stride-2 maps declared as such (=> direct mode for the launches that write their fine side)."""
     from openscene_amd import functional as F_
     from openscene_amd import ops
-    monkeypatch.setattr(F_, "CONV_MODE", mode)
-    monkeypatch.setattr(F_, "TL_FWD_MIN_ROWS", 0)          # "tl": every map size goes through the tile-list kernel (split launches on small maps)
-    if mode == "tl" and not ops.tl_eligible(key[2] ** 3, cin, cout):
+    ws = mode == "ws"
+    monkeypatch.setattr(F_, "CONV_MODE", "tl" if ws else mode)
+    monkeypatch.setattr(F_, "TL_FWD_MIN_ROWS", (1 << 30) if ws else 0)   # "tl": every map size goes through the tile-list kernel (split launches on small maps)
+    if ws:
+        monkeypatch.setattr(F_, "TL_MID_MIN_ROWS", 1 << 30)
+        monkeypatch.setattr(F_, "WS_MAX_ROWS", 1 << 30)
+    if mode in ("tl", "ws") and not ops.tl_eligible(key[2] ** 3, cin, cout):
         pytest.skip("shape outside the tile-list kernel (takes the bf16x6 path, tested above)")
+    if ws and key[2] == 1:
+        pytest.skip("1x1 convs have no pair arrays (identity map)")
     cm = cloud(kind)
     si, so_, k = key
     K = k ** 3
@@ -112,15 +120,22 @@ def test_forward_and_gradients(kind, key, cin, cout, mode, monkeypatch):
     fg = feats.to(d).requires_grad_(True)
     wg = w.to(d).requires_grad_(True)
     lists = None
-    if mode == "tl" and K > 1:
+    if mode in ("tl", "ws") and K > 1:
         lists = (ops.tile_lists(maps[0]), ops.tile_lists(maps[1]) if maps[1] is not maps[0] else None)
         if lists[1] is None:
             lists = (lists[0], lists[0])
-    out = F_.sparse_conv(fg, wg, maps, n_out, lists=lists)
+    launches = []
+    if ws:
+        real = ops.spconv_fwd_ws
+        monkeypatch.setattr(ops, "spconv_fwd_ws", lambda *a, **kw: (launches.append(bool(kw.get("direct"))), real(*a, **kw))[1])
+    # a conv from the coarse to the fine level runs as the transposed conv of the strided map, as the modules call it
+    out = F_.sparse_conv(fg, wg, maps, n_out, lists=lists, transposed=ws and si > so_, fine_unique=ws and k == 2)
     close(out, ref, "forward")
     out.backward(gout.to(d))
     close(fg.grad, f64.grad, "input gradient")
     close(wg.grad, w64.grad, "weight gradient")
+    if ws:      # forward and input gradient both ran on the weight-stationary kernel; direct where the fine side is written
+        assert launches == ([si > so_, si < so_] if k == 2 else [False, False]), launches
 
 
 def test_out_rows_indirection_and_determinism():

@@ -41,6 +41,9 @@ def main():
         shapes = [(8, 8, 3, 128, 128), (8, 8, 3, 256, 128), (8, 8, 3, 128, 256), (8, 8, 3, 256, 256), (16, 16, 3, 256, 256),
                   (16, 16, 3, 128, 256), (4, 4, 3, 64, 64), (4, 4, 3, 128, 128), (4, 8, 2, 64, 64), (8, 4, 2, 128, 128),
                   (8, 16, 2, 128, 128), (16, 8, 2, 256, 128)]
+    if os.environ.get("SHAPES", "all") == "k2":
+        shapes = [(2, 1, 2, 96, 96), (1, 2, 2, 32, 32), (1, 2, 2, 96, 96), (4, 2, 2, 128, 96), (2, 4, 2, 32, 32), (8, 4, 2, 128, 128),
+                  (4, 8, 2, 64, 64), (16, 8, 2, 256, 128), (8, 16, 2, 128, 128)]
     if os.environ.get("SHAPES", "all") == "l1":
         shapes = [s for s in shapes if s[0] == 2 and s[1] == 2]
     for si, so, ks, cin, cout in shapes:
@@ -72,6 +75,12 @@ def main():
         row.update({"pairs": pairs, "x6_us": t_old, "tl_us": t_new, "tl_TF": fl / t_new / 1e6, "x6_TF": fl / t_old / 1e6,
                     "lists_us": t_list, "prep_tl_us": timed(lambda: ops.weight_prep_tl(w, want_dgrad=False), reps),
                     "max_rel_diff": (a - b).abs().max().item() / a.abs().max().item()})
+        direct = K == 8 and n_out > n_in
+        if K > 1 and (direct or (n_out <= 20000 and n_in <= 20000)):
+            ops.pair_lists(tl)
+            t_ws = timed(lambda: ops.spconv_fwd_ws(x, wf, tl, nbr, n_out, K, cout, direct=direct), reps)
+            c = ops.spconv_fwd_ws(x, wf, tl, nbr, n_out, K, cout, direct=direct)
+            row.update({"ws_us": t_ws, "ws_TF": fl / t_ws / 1e6, "ws_rel_diff": (a - c).abs().max().item() / a.abs().max().item()})
         res.append(row)
         print(json.dumps(row), flush=True)
 
