@@ -34,6 +34,12 @@ BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, same guide
 # bf16x6 kernels issue SIX bf16 MFMAs per fp32-equivalent product block, so their roof in the
 # fp32-equivalent FLOPs this file counts (2 * pairs * cin * cout) is the bf16 peak / 6
 X6_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 6.0
+LOSS_HIP = True                # the distillation loss through openscene_amd.losses (csrc/loss.hip); --torch-loss clears it
+
+
+def distill_loss(out, sel, target):
+    from openscene_amd.losses import distill_loss as f
+    return f(out, sel, target, "cosine")
 
 
 class LaunchProfiler:
@@ -354,7 +360,7 @@ def variant_step_ms(device, arch, feature, coords, conv_mode=None, steps=5, warm
                 with torch.no_grad():
                     return model(SparseTensor(feats, coords))
             out = model(SparseTensor(feats, coords))
-            loss = (1 - cos(out.index_select(0, sel), target)).mean()
+            loss = distill_loss(out, sel, target) if LOSS_HIP else (1 - cos(out.index_select(0, sel), target)).mean()
             optim.zero_grad(set_to_none=True)
             loss.backward()
             optim.step()
@@ -463,6 +469,8 @@ def main():
     ap.add_argument("--prefetch-maps", action="store_true", help="build the maps of the NEXT batch on a side stream "
                     "while a step runs (openscene_amd.sparse.MapPrefetcher) instead of inside the step as "
                     "MinkowskiEngine does; measured 4 %% SLOWER on S100k (DESIGN.md section 4), off by default")
+    ap.add_argument("--torch-loss", action="store_true", help="cosine loss through torch's own operators (index_select, "
+                    "CosineSimilarity, mean and their autograd chain) instead of openscene_amd.losses.distill_loss")
     ap.add_argument("--no-prefetch-pyramid", action="store_true", help="build the coordinate pyramid of a batch inside its own step "
                     "(after the previous step has drained) instead of queueing it on a side stream while the previous step runs; "
                     "every step still builds exactly one pyramid and one set of kernel maps inside the timed region")
@@ -474,6 +482,8 @@ def main():
                     "(for rocprofv3 runs: every traced kernel then belongs to the training steps)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    global LOSS_HIP
+    LOSS_HIP = not args.torch_loss
     if args.cpu_baseline_only:
         out_dim = 512 if "lseg" in args.feature else 768
         print(json.dumps(cpu_baseline(0, args.arch, out_dim)))
@@ -576,7 +586,9 @@ def main():
             sel = mask.nonzero(as_tuple=False).squeeze(1)
             sinput = SparseTensor(feats, next_coords())            # builds every map (ME does per forward)
         out = net(sinput)
-        loss = (1 - cos(out.index_select(0, sel), feat_3d)).mean()  # = out[mask], run/distill.py:322-326
+        # (1 - cos(out[mask], feat_3d)).mean(), run/distill.py:322-326: one fused forward and one fused backward launch
+        # (openscene_amd.losses, csrc/loss.hip); --torch-loss keeps torch's own ~25-launch chain
+        loss = distill_loss(out, sel, feat_3d) if LOSS_HIP else (1 - cos(out.index_select(0, sel), feat_3d)).mean()
         optim.zero_grad(set_to_none=True)
         loss.backward()
         if exchange is not None:

@@ -351,6 +351,28 @@ int osn_bn_backward_multi(const float* x, const float* y, const float* const* gy
                           int training, float* gx, float* gres, float* ggamma, float* gbeta,
                           int64_t n, int c, void* ws, size_t ws_bytes, osn_stream_t stream);
 
+/* ---- distillation loss on the supervised rows ------------------------------- *
+ * Replaces run/distill.py:322-328 and its autograd chain:
+ *     output_3d = output_3d[mask]
+ *     loss = (1 - torch.nn.CosineSimilarity()(output_3d, feat_3d)).mean()      kind 0 ('cosine')
+ *     loss = torch.nn.L1Loss()(output_3d, feat_3d)                             kind 1 ('l1')
+ *   out     float [n, d]       the network output, input row order
+ *   sel     int64 [n_sel]      rows the loss sees (= mask.nonzero(): distinct, any order), target[j] belongs to out[sel[j]]
+ *   target  float [n_sel, d]   feat_3d
+ *   loss    float [1]  (device)
+ *   state   osn_distill_loss_state_bytes(n, n_sel) bytes kept by the caller from the forward to the backward call
+ *   gloss   float [1] (device) gradient of the loss, or null (= 1)
+ *   gout    float [n, d]       receives d loss / d out: the closed-form row gradient on the selected rows, ZEROS elsewhere
+ *                              (what autograd's index backward produces with an index_add into a zero-filled tensor)
+ * osn_distill_loss_check synchronises the stream and reports an index outside [0, n) or a row selected twice
+ * (OSN_E_ARG); the kernels themselves never read or write out of bounds.  d % 4 == 0.                          */
+size_t osn_distill_loss_state_bytes(int64_t n, int64_t n_sel);
+int osn_distill_loss_fwd(const float* out, const int64_t* sel, const float* target, int64_t n, int64_t n_sel, int d, int kind,
+                         float* loss, void* state, size_t state_bytes, osn_stream_t stream);
+int osn_distill_loss_bwd(const float* out, const float* target, const float* gloss, int64_t n, int64_t n_sel, int d, int kind,
+                         float* gout, const void* state, size_t state_bytes, osn_stream_t stream);
+int osn_distill_loss_check(const void* state, int64_t n, int64_t n_sel, osn_stream_t stream);
+
 /* ---- row-aligned elementwise pieces --------------------------------------- *
  * Replaces the stand-alone [ME] MinkowskiReLU (models/mink_unet.py:114, used un-fused by the reference's own module
  * chain), the BasicBlock residual `out += residual` when it is not fused into a batch norm, and ME.cat of two tensors

@@ -1,0 +1,69 @@
+"""Distillation loss on the supervised rows -- the mirror of run/distill.py:322-328:
+
+    output_3d = model(sinput)[mask]
+    loss = (1 - torch.nn.CosineSimilarity()(output_3d, feat_3d)).mean()      # loss_type: cosine
+    loss = torch.nn.L1Loss()(output_3d, feat_3d)                             # loss_type: l1
+
+as ONE autograd node over the full network output: the forward pass reads the selected rows once, the backward pass
+writes the [N, D] output gradient once (zeros on the rows the loss does not see), csrc/loss.hip."""
+import torch
+from torch.autograd import Function
+
+from . import ops
+from ._lib import check
+
+KINDS = {"cosine": 0, "l1": 1}
+
+
+class _DistillLoss(Function):
+    @staticmethod
+    def forward(ctx, out, sel, target, kind, validate):
+        dev = out.device
+        lib = ops._prep(dev)
+        out = ops._f32c(out, "output")
+        target = ops._f32c(target, "target")
+        if sel.dtype != torch.int64 or sel.dim() != 1 or sel.device != dev:
+            raise ValueError("sel must be an int64 vector of row indices on the output's device")
+        sel = sel.contiguous()
+        n, d = out.shape
+        n_sel = sel.shape[0]
+        if tuple(target.shape) != (n_sel, d):
+            raise ValueError("target is %s, the selected output rows are (%d, %d)" % (tuple(target.shape), n_sel, d))
+        if n_sel == 0:
+            raise ValueError("the loss needs at least one supervised row")
+        state = torch.empty(int(ops._cached("osn_distill_loss_state_bytes", n, n_sel)), dtype=torch.uint8, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        with ops._Dev(dev):
+            check(lib.osn_distill_loss_fwd(ops._p(out), ops._p(sel), ops._p(target), n, n_sel, d, kind, ops._p(loss), ops._p(state),
+                                           state.numel(), ops._stream(dev)), "osn_distill_loss_fwd")
+            if validate:
+                check(lib.osn_distill_loss_check(ops._p(state), n, n_sel, ops._stream(dev)), "osn_distill_loss_check")
+        ctx.save_for_backward(out, target, state)
+        ctx.cfg = (n, n_sel, d, kind)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        out, target, state = ctx.saved_tensors
+        n, n_sel, d, kind = ctx.cfg
+        dev = out.device
+        lib = ops._prep(dev)
+        gloss = gloss.to(torch.float32).contiguous()
+        gout = torch.empty_like(out)
+        with ops._Dev(dev):
+            check(lib.osn_distill_loss_bwd(ops._p(out), ops._p(target), ops._p(gloss), n, n_sel, d, kind, ops._p(gout), ops._p(state),
+                                           state.numel(), ops._stream(dev)), "osn_distill_loss_bwd")
+        return gout, None, None, None, None
+
+
+def distill_loss(output, sel, target, loss_type="cosine", validate=False):
+    """Scalar loss of run/distill.py:322-328 over `output[sel]` against `target` (feat_3d).
+    output float32 [N, D] (the network output, input row order); sel: the supervised rows -- int64 indices (distinct; e.g.
+    mask.nonzero().squeeze(1), which the loader hands out next to the mask) or the bool mask itself (resolved here: a host
+    synchronisation in the middle of the step); target float [len(sel), D].
+    validate: check the indices on the device and raise on an index out of range or a duplicate (synchronises)."""
+    if loss_type not in KINDS:
+        raise ValueError("loss_type %r (the reference has 'cosine' and 'l1')" % (loss_type,))
+    if sel.dtype == torch.bool:
+        sel = sel.nonzero(as_tuple=False).squeeze(1)
+    return _DistillLoss.apply(output, sel, target, KINDS[loss_type], bool(validate))

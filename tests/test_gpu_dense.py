@@ -190,6 +190,52 @@ def _query_inputs(n_vox, n_pts, d, c, seed):
     return x, t, gather
 
 
+@pytest.mark.parametrize("loss_type", ["cosine", "l1"])
+@pytest.mark.parametrize("n,n_sel,d", [(5000, 1200, 768), (777, 777, 512), (64, 1, 20)])
+def test_distill_loss_forward_and_gradient(n, n_sel, d, loss_type):
+    """a14: loss of run/distill.py:322-328 on output[sel] and its gradient with respect to the full output, against the
+    float64 oracle (itself pinned to torch's autograd of those lines): loss within 1e-6 relative, gradient rows within
+    2e-6 of the row's largest element, rows outside the selection exactly zero; the upstream gradient scales it."""
+    from oracle import loss as ol
+    from openscene_amd.losses import distill_loss
+    g = torch.Generator().manual_seed(n + d)
+    out = torch.randn(n, d, generator=g) * 2.5
+    sel = torch.randperm(n, generator=g)[:n_sel].sort().values
+    target = torch.nn.functional.normalize(torch.randn(n_sel, d, generator=g), dim=1).half().float()
+    ref_loss, ref_grad = ol.distill_loss(out.numpy(), sel.numpy(), target.numpy(), loss_type)
+    dv = dev()
+    x = out.to(dv).requires_grad_(True)
+    loss = distill_loss(x, sel.to(dv), target.to(dv), loss_type, validate=True)
+    (loss * 2.5).backward()
+    assert abs(loss.item() - ref_loss) <= 1e-6 * max(1.0, abs(ref_loss))
+    got = x.grad.cpu().double().numpy() / 2.5
+    scale = np.abs(ref_grad).max(axis=1, keepdims=True)
+    assert (np.abs(got - ref_grad) <= 2e-6 * scale + 1e-30).all()
+    keep = np.zeros(n, dtype=bool)
+    keep[sel.numpy()] = True
+    assert not got[~keep].any()
+    # the bool mask itself is accepted (resolved with a host synchronisation)
+    mask = torch.from_numpy(keep).to(dv)
+    loss2 = distill_loss(x.detach(), mask, target.to(dv), loss_type)
+    assert loss2.item() == loss.item()
+
+
+def test_distill_loss_rejects_bad_selections():
+    from openscene_amd._lib import OpenSceneAmdError
+    from openscene_amd.losses import distill_loss
+    dv = dev()
+    out = torch.randn(100, 32, device=dv)
+    tgt = torch.randn(3, 32, device=dv)
+    with pytest.raises(OpenSceneAmdError):
+        distill_loss(out, torch.tensor([1, 5, 5], device=dv), tgt, validate=True)          # a row twice
+    with pytest.raises(OpenSceneAmdError):
+        distill_loss(out, torch.tensor([1, 5, 100], device=dv), tgt, validate=True)        # outside the output
+    with pytest.raises(ValueError):
+        distill_loss(out, torch.tensor([1, 5], device=dv), tgt)
+    with pytest.raises(ValueError):
+        distill_loss(out, torch.tensor([1, 5, 7], device=dv), tgt, loss_type="l2")
+
+
 @pytest.mark.parametrize("n_vox,n_pts,d,c", [(4000, 6001, 768, 20), (3000, 3000, 512, 21), (2500, 4000, 768, 160),
                                              (1000, 1500, 768, 43), (700, 900, 512, 300), (130, 1, 768, 2),
                                              # column-split kernel (> 64 labels): two tiles per wave, ragged last feature

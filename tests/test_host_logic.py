@@ -256,3 +256,28 @@ def test_forward_features_is_the_input_of_the_final_conv(cpu_ops):
     assert torch.allclose(out, f @ model.final.kernel, atol=1e-12)
     text = torch.randn(5, 24, dtype=torch.float64)
     assert torch.allclose(out @ text.t(), f @ head_times_text(model.final.kernel, text).double(), atol=1e-5)
+
+
+@pytest.mark.parametrize("loss_type", ["cosine", "l1"])
+def test_distill_loss_oracle_is_the_reference_expression(loss_type):
+    """oracle/loss.py pinned to torch's own forward and autograd of run/distill.py:322-328 (float64): the loss on
+    `output[mask]` and its gradient with respect to the FULL output -- zeros on the rows the mask leaves out."""
+    from oracle import loss as ol
+    g = torch.Generator().manual_seed(3)
+    n, d = 300, 48
+    out = torch.randn(n, d, generator=g, dtype=torch.float64) * 3
+    mask = torch.zeros(n, dtype=torch.bool)
+    mask[torch.randperm(n, generator=g)[:120]] = True
+    feat_3d = torch.nn.functional.normalize(torch.randn(120, d, generator=g, dtype=torch.float64), dim=1)
+    out[mask.nonzero()[5]] = 0.0                                   # a zero row: CosineSimilarity's eps clamp
+    x = out.clone().requires_grad_(True)
+    output_3d = x[mask]
+    if loss_type == "cosine":
+        ref = (1 - torch.nn.CosineSimilarity()(output_3d, feat_3d)).mean()
+    else:
+        ref = torch.nn.L1Loss()(output_3d, feat_3d)
+    ref.backward()
+    loss, grad = ol.distill_loss(out.numpy(), mask.nonzero().squeeze(1).numpy(), feat_3d.numpy(), loss_type)
+    assert abs(loss - ref.item()) <= 1e-12 * max(1.0, abs(ref.item()))
+    np.testing.assert_allclose(grad, x.grad.numpy(), rtol=1e-10, atol=1e-14)
+    assert not grad[~mask.numpy()].any()
