@@ -466,9 +466,11 @@ def main():
     ap.add_argument("--feature", default="openseg", help="openseg (768-d) | lseg (512-d)")
     ap.add_argument("--scene-points", type=int, default=120000, help="surface samples of the synthetic scene "
                     "(120000 = S100k, the headline workload; smaller values are for overhead studies only)")
-    ap.add_argument("--prefetch-maps", action="store_true", help="build the maps of the NEXT batch on a side stream "
-                    "while a step runs (openscene_amd.sparse.MapPrefetcher) instead of inside the step as "
-                    "MinkowskiEngine does; measured 4 %% SLOWER on S100k (DESIGN.md section 4), off by default")
+    ap.add_argument("--prefetch-maps", action="store_true", help="(default since round 3) build the pyramid AND the kernel maps "
+                    "of the NEXT batch on a side stream while a step runs (openscene_amd.sparse.MapPrefetcher)")
+    ap.add_argument("--no-prefetch-maps", action="store_true", help="queue only the coordinate pyramid of the next batch ahead; "
+                    "its kernel maps are built inside the step (the round-3 default until the maps came from one C call on one "
+                    "stream: 11.10 ms against 10.57 ms per step with the maps ahead as well, profiles/r03_s10)")
     ap.add_argument("--torch-loss", action="store_true", help="cosine loss through torch's own operators (index_select, "
                     "CosineSimilarity, mean and their autograd chain) instead of openscene_amd.losses.distill_loss")
     ap.add_argument("--no-prefetch-pyramid", action="store_true", help="build the coordinate pyramid of a batch inside its own step "
@@ -557,10 +559,13 @@ def main():
     # the loader knows a batch's coordinates one step ahead (DataLoader prefetch, dataset/feature_loader.py): by default its
     # coordinate PYRAMID (hash insert, unique, four coarse levels, the one size read-back -- work during which the GPU can do
     # nothing else) is queued on a side stream while the previous step's backward pass runs; the kernel maps are built
-    # inside the step.  --prefetch-maps moves the maps there as well (measured slower), --no-prefetch-pyramid nothing.
-    full_prefetch = args.prefetch_maps or args.prefetch_maps_threaded
+    # inside the step.  Default: pyramid AND kernel maps (+ pair arrays) of the next batch go there -- every step still builds
+    # exactly one pyramid and one set of maps inside the timed region, during the previous step's backward pass instead of
+    # in front of its own forward pass.  --no-prefetch-maps: pyramid only; --no-prefetch-pyramid: nothing ahead.
+    full_prefetch = (not args.no_prefetch_maps and not args.no_prefetch_pyramid) or args.prefetch_maps_threaded
     prefetch = full_prefetch or not args.no_prefetch_pyramid
-    pf = MapPrefetcher(device, threaded=args.prefetch_maps_threaded, pyramid_only=not full_prefetch) if prefetch else None
+    pf = (MapPrefetcher(device, threaded=args.prefetch_maps_threaded, pyramid_only=not full_prefetch, pairs=True)
+          if prefetch else None)
     def prepare_next():
         """Inputs of the NEXT step, queued on the prefetcher's stream: shifted coordinates, the rows the mask selects (a
         size read-back of its own) and the coordinate pyramid (full prefetch: every map)."""
@@ -610,7 +615,7 @@ def main():
         step()
     from openscene_amd import executor as _ex
     ex = _ex.for_model(model.net3d) if _ex.ENABLED else None
-    prof = ExecProfiler(ex) if (ex is not None and not args.no_kernel_events and not full_prefetch) else None
+    prof = ExecProfiler(ex) if (ex is not None and not args.no_kernel_events) else None
     legacy = LaunchProfiler() if (ex is None and not args.no_kernel_events) else None
     survey_groups, survey_shapes, dom_key, dom_tags = {}, {}, None, []
     dom_fwd_only = False
@@ -1035,7 +1040,7 @@ def main():
         "query": qres, "voxelizer": vox_res, "phases": extra, "roofline": roofline, "cpu_baseline": cpu, "comm": comm,
         "kernels": kernels, "stages": stages, "loss": float(loss.detach()),
         "host_path": "network executor (one C call per forward / backward pass)" if ex is not None else "per-module (Python autograd)",
-        "input_pipeline": ("every map of step i+1 built on a side stream during step i" if full_prefetch else
+        "input_pipeline": ("coordinate pyramid, kernel maps and pair arrays of step i+1 built on a side stream during step i" if full_prefetch else
                            "coordinate pyramid (+ mask rows) of step i+1 queued on a side stream during step i; kernel maps inside the step"
                            if prefetch else "pyramid and maps inside the step"),
     }

@@ -331,10 +331,11 @@ class MapPrefetcher:
 
     submit() blocks the host only on the side stream (the size read-back of the pyramid).
 
-    Measured on MI355X / S100k (one scene per step): 18.3 ms per step with the prefetcher vs 17.6 ms
-    without -- the side-stream kernels queue behind the main stream's workgroups, the host waits on the
-    read-backs for longer than the maps take alone, and the step turns host-bound.  It is kept for
-    loaders that run two batches ahead (submit from a worker thread); `bench.py --prefetch-maps`."""
+    Measured on MI355X / S100k (one scene per step).  Round 2 (per-module host path, ~90 C calls per map set): 18.3 ms per
+    step with the prefetcher against 17.6 ms without -- the step was host-bound and the prefetcher's read-backs stalled it.
+    Round 3 (network executor, every map from one C call on one stream): 10.57 ms with pyramid + maps ahead, 11.10 ms with
+    the pyramid only (`bench.py --no-prefetch-maps`), 11.9 ms with nothing ahead -- the maps' ~130 latency-bound launches
+    run beside the previous step's backward pass instead of in front of the forward pass."""
 
     def __init__(self, device, threaded=False, pyramid_only=False, **prebuild_args):
         """threaded: build on a worker thread, so that the caller never blocks on the pyramid's size read-backs (the
