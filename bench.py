@@ -192,6 +192,8 @@ class ExecProfiler:
                 n = "wgrad_tl_kernel<%d,%d>" % (blk(cin), blk(cout))
             elif kernel == "stem":
                 n = "stem_fwd_kernel"
+            elif kernel == "wgrad_stem":
+                n = "stem_wgrad_kernel"
             else:
                 pad = lambda c: min((c + 31) // 32 * 32, 128)
                 n = "spconv_wgrad_kernel<%d>" % (((pad(cin) // 32) * (pad(cout) // 32) + 3) // 4,)

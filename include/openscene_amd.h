@@ -298,6 +298,12 @@ int osn_spconv_fwd_ws(const float* in, int64_t n_in, const void* Wp, const void*
  * and cout == 32 (no contraction worth a matrix unit; the op streams the 125 x n_out table once).            */
 int osn_stem_conv_fwd(const float* in, const float* W, const int32_t* nbr, float* out, int64_t n_out, int K,
                       int cin, int cout, osn_stream_t stream);
+/* Its weight gradient gW[k][ci][n] = sum_o in[nbr[k][o]][ci] * gout[o][n] ([ME] MinkowskiConvolutionFunction backward for
+ * the same layer): dense over the table (an absent neighbour is a zero row), fp32 fmaf chains down the rows in ascending
+ * order, per-workgroup partial sums added in workgroup order -- bitwise reproducible.  ws: osn_stem_conv_wgrad_ws_bytes. */
+size_t osn_stem_conv_wgrad_ws_bytes(int K, int cin);
+int osn_stem_conv_wgrad(const float* in, const float* gout, const int32_t* nbr, float* gW, int64_t n_out, int K, int cin,
+                        int cout, void* ws, size_t ws_bytes, osn_stream_t stream);
 
 /* ---- batch norm (+ReLU, +residual) -------------------------------------- *
  * Replaces [ME] MinkowskiBatchNorm (= torch.nn.BatchNorm1d on .F), MinkowskiReLU
@@ -504,7 +510,7 @@ typedef struct osn_net_desc {
     const osn_net_buf* bufs;
 } osn_net_desc;
 enum { OSN_NET_K_NONE = 0, OSN_NET_K_STEM = 1, OSN_NET_K_TL = 2, OSN_NET_K_X6 = 3, OSN_NET_K_WGRAD_TL = 4, OSN_NET_K_WGRAD = 5,
-       OSN_NET_K_WS = 6, OSN_NET_K_WS_DIRECT = 7 };
+       OSN_NET_K_WS = 6, OSN_NET_K_WS_DIRECT = 7, OSN_NET_K_WGRAD_STEM = 8 };
 enum { OSN_NET_IMG_X6_FWD = 1, OSN_NET_IMG_X6_DGRAD = 2, OSN_NET_IMG_TL_FWD = 4, OSN_NET_IMG_TL_DGRAD = 8 };
 typedef struct osn_net_plan {                 /* every array is caller-provided HOST memory                       */
     uint64_t fwd_arena_bytes, bwd_arena_bytes, ws_bytes;

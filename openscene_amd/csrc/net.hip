@@ -180,7 +180,10 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
         // table kernel: 188 us against 215 us measured)
         const bool wg_tl = (o.K > 1 || (o.cin <= 128 && o.cout <= 128)) && tl_eligible(o.K, o.cin, o.cout, n_in) &&
                            !stem_eligible(o.K, o.cin, o.cout);
-        if (wg_tl) {
+        if (stem_eligible(o.K, o.cin, o.cout)) {
+            L.wgrad_k[i] = OSN_NET_K_WGRAD_STEM;
+            need_ws(osn_stem_conv_wgrad_ws_bytes(o.K, o.cin));
+        } else if (wg_tl) {
             L.wgrad_k[i] = OSN_NET_K_WGRAD_TL;
             // partial sums per work item live in the backward arena until the ONE batched reduction at the end of the pass
             L.gpart_off[i] = b; b += up256(osn_spconv_wgrad_tl_ws_bytes(o.K, o.cin, o.cout));
@@ -520,6 +523,9 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
                     rc = osn_wgrad_tl_reduce_batch(jobs.data(), int(jobs.size()), wstream);
                     jobs.clear();
                 }
+            } else if (L.wgrad_k[i] == OSN_NET_K_WGRAD_STEM) {
+                OSN_REQUIRE(v.nbr_f, OSN_E_ARG, "osn_net_backward: op %d: the stem weight gradient needs the plain table", i);
+                rc = osn_stem_conv_wgrad(in, gx, v.nbr_f, w.gW, n_out, o.K, o.cin, o.cout, wws, wws_bytes, wstream);
             } else {
                 rc = osn_spconv_wgrad(in, gx, o.K > 1 ? v.nbr_f : nullptr, o.K > 1 && m ? m->counts : nullptr, nullptr, w.gW, n_out, o.K,
                                       o.cin, o.cout, wws, wws_bytes, wstream);

@@ -5,8 +5,12 @@
 // stream the 125 x N neighbour table once (50 MB on S100k) and gather 12 bytes per pair.  The generic MFMA
 // kernel spent 191 us on it; this one 127 us (measured; a pair-driven variant would skip the 89 % empty
 // table entries).  One thread per output row, 32 accumulators, offsets in ascending order: a plain fmaf
-// chain, bitwise reproducible, exact fp32 products.  (A dedicated weight-gradient kernel was measured slower
-// than the generic fp32-MFMA one -- 314 vs 257 us -- and is not kept.)
+// chain, bitwise reproducible, exact fp32 products.
+// Weight gradient (round 3): the generic fp32-MFMA table kernel needs 260 us for it, and the stem is the LAST weight
+// gradient of a backward pass -- nothing is left to hide it behind.  stem_wgrad_kernel treats the table densely (an absent
+// neighbour contributes a zero row): per chunk of 64 output rows a workgroup stages the gradient rows and, for 32 offsets,
+// the gathered input rows in LDS, and thread (4 offsets, channel n) runs a plain fmaf chain down the rows -- LDS-broadcast
+// operands, 12 accumulators, no cross-lane reduction; per-workgroup partial sums, summed in workgroup order.
 #include "common.h"
 
 namespace osn {
@@ -58,9 +62,120 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     }
 }
 
+constexpr int SW_ROWS = 64;        // output rows per chunk
+constexpr int SW_KB = 32;          // offsets per workgroup (8 thread groups x 4)
+constexpr int SW_PARTS = 128;      // row parts (workgroups along the rows) = partial sums per weight element
+
+// partial[part][k][ci][n] = sum over the part's rows o of in[nbr[k][o]][ci] * gout[o][n]      (cout == 32)
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+                                                         const int32_t* __restrict__ nbr, float* __restrict__ partial,
+                                                         int64_t n_out, int K, int cin) {
+    __shared__ __attribute__((aligned(16))) float A[SW_KB * SW_ROWS * STEM_CMAX];      // [offset][row][channel]
+    __shared__ __attribute__((aligned(16))) float G[SW_ROWS * STEM_COUT];
+    const int tid = threadIdx.x, n = tid & 31, kq = tid >> 5;
+    const int k0 = blockIdx.y * SW_KB;
+    float acc[4][STEM_CMAX];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < STEM_CMAX; ++c) acc[j][c] = 0.f;
+    const int64_t n_chunks = (n_out + SW_ROWS - 1) / SW_ROWS;
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {            // ascending rows: fixed summation order
+        const int64_t r0 = ch * SW_ROWS;
+        // ---- gathered input rows of 32 offsets x 64 rows (zeros for an absent neighbour), gradient rows
+        // (256 row parts and the table entries fetched one chunk ahead were measured slower: 150 us against 128 us)
+        int idx[SW_KB * SW_ROWS / 256];
+#pragma unroll
+        for (int u = 0; u < SW_KB * SW_ROWS / 256; ++u) {
+            const int e = tid + 256 * u;
+            const int kk = e / SW_ROWS, o = e % SW_ROWS;
+            idx[u] = (k0 + kk < K && r0 + o < n_out) ? nbr[int64_t(k0 + kk) * n_out + r0 + o] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < SW_KB * SW_ROWS / 256; ++u) {
+            const int e = tid + 256 * u;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx[u] >= 0) {
+                const float* x = in + int64_t(idx[u]) * cin;
+                v.x = x[0];
+                if (cin > 1) v.y = x[1];
+                if (cin > 2) v.z = x[2];
+                if (cin > 3) v.w = x[3];
+            }
+            *reinterpret_cast<float4*>(&A[e * STEM_CMAX]) = v;
+        }
+#pragma unroll
+        for (int u = 0; u < SW_ROWS * STEM_COUT / 4 / 256; ++u) {
+            const int e = tid + 256 * u;
+            const int o = e / (STEM_COUT / 4);
+            *reinterpret_cast<float4*>(&G[e * 4]) =
+                r0 + o < n_out ? *reinterpret_cast<const float4*>(gout + r0 * STEM_COUT + int64_t(e) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int o = 0; o < SW_ROWS; ++o) {
+            const float g = G[o * STEM_COUT + n];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 a = *reinterpret_cast<const float4*>(&A[((4 * kq + j) * SW_ROWS + o) * STEM_CMAX]);     // broadcast
+                acc[j][0] = fmaf(a.x, g, acc[j][0]);
+                acc[j][1] = fmaf(a.y, g, acc[j][1]);
+                acc[j][2] = fmaf(a.z, g, acc[j][2]);
+                acc[j][3] = fmaf(a.w, g, acc[j][3]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + 4 * kq + j;
+        if (k < K)
+            for (int c = 0; c < cin; ++c)
+                partial[((int64_t(blockIdx.x) * K + k) * cin + c) * STEM_COUT + n] = acc[j][c];
+    }
+}
+
+// gW[e] = partial[0][e] + partial[1][e] + ...   (fixed order)
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ partial, int parts, int total, float* __restrict__ gW) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    float s = 0.f;
+    for (int p = 0; p < parts; ++p) s += partial[int64_t(p) * total + e];
+    gW[e] = s;
+}
+
 }  // namespace osn
 
 using namespace osn;
+
+extern "C" size_t osn_stem_conv_wgrad_ws_bytes(int K, int cin) {
+    return size_t(SW_PARTS) * size_t(K > 0 ? K : 1) * size_t(cin > 0 ? cin : 1) * STEM_COUT * 4;
+}
+
+extern "C" int osn_stem_conv_wgrad(const float* in, const float* gout, const int32_t* nbr, float* gW, int64_t n_out, int K,
+                                   int cin, int cout, void* ws, size_t ws_bytes, osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_stem_conv_wgrad: n_out out of range");
+    OSN_REQUIRE(K >= 1 && K <= 125 && cin >= 1 && cin <= STEM_CMAX && cout == STEM_COUT, OSN_E_ARG,
+                "osn_stem_conv_wgrad: needs K <= 125, cin <= %d, cout == %d (K=%d cin=%d cout=%d)", STEM_CMAX, STEM_COUT, K, cin, cout);
+    OSN_REQUIRE(gW, OSN_E_ARG, "osn_stem_conv_wgrad: null gradient pointer");
+    const int total = K * cin * STEM_COUT;
+    if (n_out == 0) {
+        OSN_HIP(hipMemsetAsync(gW, 0, size_t(total) * 4, st));
+        return OSN_OK;
+    }
+    OSN_REQUIRE(in && gout && nbr && aligned16(gout), OSN_E_ARG, "osn_stem_conv_wgrad: null or unaligned pointer");
+    OSN_REQUIRE(ws && ws_bytes >= osn_stem_conv_wgrad_ws_bytes(K, cin), OSN_E_WS, "osn_stem_conv_wgrad: workspace %zu < %zu",
+                ws_bytes, osn_stem_conv_wgrad_ws_bytes(K, cin));
+    const int64_t n_chunks = cdiv(n_out, SW_ROWS);
+    const int parts = int(n_chunks < SW_PARTS ? n_chunks : SW_PARTS);
+    float* partial = static_cast<float*>(ws);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(unsigned(parts), unsigned(cdiv(K, SW_KB))), dim3(256), 0, st, in, gout, nbr, partial,
+                       n_out, K, cin);
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(unsigned(cdiv(total, 256))), dim3(256), 0, st, partial, parts, total, gW);
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}
 
 extern "C" int osn_stem_conv_fwd(const float* in, const float* W, const int32_t* nbr, float* out, int64_t n_out, int K,
                                  int cin, int cout, osn_stream_t stream) {

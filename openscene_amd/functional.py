@@ -131,6 +131,8 @@ class SparseConvFunction(Function):
         def weight_grad():
             cin, cout = kernel.shape[-2], kernel.shape[-1]
             tl, swap = ctx.wg_lists
+            if ctx.stem:
+                return ops.stem_conv_wgrad(feats, gout, nbr_fwd, K).reshape(kernel.shape)
             if CONV_MODE == "tl" and ops.tl_eligible(K, cin, cout, ctx.n_in):
                 if K > 1 and tl is not None:
                     return ops.spconv_wgrad_tl(feats, gout, tl, K, swap=swap).reshape(kernel.shape)

@@ -731,6 +731,26 @@ def spconv_wgrad_tl(feats, gout, tl, K, swap=False):
     return gw
 
 
+def stem_conv_wgrad(feats, gout, nbr, K):
+    """gW [K, cin, 32] of the stem convolution (stem_eligible shapes) from the plain neighbour table."""
+    dev = feats.device
+    lib = _prep(dev)
+    feats = _f32c(feats, "features")
+    gout = _f32c(gout, "grad_output")
+    cin, (n_out, cout) = feats.shape[1], gout.shape
+    if nbr.dtype != torch.int32 or tuple(nbr.shape) != (K, n_out):
+        raise ValueError("nbr must be int32 [%d, %d], got %s %s" % (K, n_out, nbr.dtype, tuple(nbr.shape)))
+    gw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
+    ws = _ws(_cached("osn_stem_conv_wgrad_ws_bytes", K, cin), dev)
+    tok = _prof_start("stem_wgrad", dev, n_in=feats.shape[0], n_out=n_out, K=K, cin=cin, cout=cout)
+    with _Dev(dev):
+        check(lib.osn_stem_conv_wgrad(_p(feats), _p(gout), _p(nbr.contiguous()), _p(gw), n_out, K, cin, cout, _p(ws), ws.numel(),
+                                      _stream(dev)), "osn_stem_conv_wgrad")
+    if tok is not None:
+        _profiler.stop(tok)
+    return gw
+
+
 def spconv_fwd_ws(feats, wp, tl, nbr_dst, n_dst, K, cout, swap=False, direct=False):
     """Convolution of a small map from the pair arrays of `tl` (weight-stationary workgroups + ordered sum over the
     offsets): out[r] = sum_k feats[src of (k, r)] @ B[k], B a weight_prep_tl image.  nbr_dst int32 [K, n_dst]: the

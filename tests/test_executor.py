@@ -51,7 +51,7 @@ def test_program_covers_the_module_tree(arch):
     # the library accepts the program and plans every stage
     ks = ex.kernels(S100K, training=True)
     assert len(ks) == len(p.ops) and all(k[1] != "none" and k[3] != "none" for k in ks)
-    assert ks[0][1:] == ("stem", "none", "wgrad")
+    assert ks[0][1:] == ("stem", "none", "wgrad_stem")
     assert int(ex._plan.fwd_arena_bytes) > 4 * S100K[0] * 96 * 10
 
 
