@@ -22,6 +22,9 @@ import os
 import sys
 import time
 
+# (before the HIP runtime initialises; openscene_amd sets the same default on import, see openscene_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
+
 import numpy as np
 import torch
 

@@ -14,10 +14,17 @@ Python surface (mirrors the reference's own, file:line in each module):
 There is no CPU fallback: every op raises if libopenscene_amd.so is missing or
 the tensors are not on a gfx950 device.
 """
+import os
 import sys
 import types
 
 __version__ = "0.1.0"
+
+# HIP maps streams to at most this many hardware queues per process (read once, when the runtime initialises).  The training
+# step uses three streams (main, weight gradients, next batch's maps); a fourth ACTIVE hardware queue -- RCCL's stream in a
+# multi-GPU run -- slows every launch on this part: 13.4 ms per step against 10.1 ms with the cap at 3 (and 20 ms with 8),
+# measured with a one-rank RCCL group (profiles/r03_s12_hw_queues.txt).  Streams beyond the cap share a queue.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
 
 
 def install_minkowski_alias(force=False):

@@ -11,6 +11,9 @@ for rep in $(seq 1 $R_N); do
     i=$((i+1))
     envs="${v%%|*}"; flags="${v#*|}"
     env $envs timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-events --train-only $flags > $O/ab_${i}_$rep.json 2>> $O/ab.err
-    echo "AB[$envs|$flags] $(python -c "import json;d=json.loads(open('$O/ab_${i}_$rep.json').read().strip().splitlines()[-1]);print(round(d['ms_per_step'],3))")"
+    echo "AB[$envs|$flags] $(python -c "
+import json
+for l in open('$O/ab_${i}_$rep.json'):
+    if l.startswith('{'): print(round(json.loads(l)['ms_per_step'], 3))")"
   done
 done
