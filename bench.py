@@ -78,6 +78,8 @@ class LaunchProfiler:
                 n = "spconv_tl_kernel<%d>" % best
             elif kind == "spconv_fwd_ws":
                 n = "spconv_ws_kernel"
+            elif kind == "dense_fwd":
+                n = "dense_kernel"
             elif kind == "spconv_wgrad_tl":
                 blk = lambda c: min((c + 31) // 32, 4)
                 n = "wgrad_tl_kernel<%d,%d>" % (blk(m["cin"]), blk(m["cout"]))
@@ -195,6 +197,8 @@ class ExecProfiler:
                 n = "wgrad_tl_kernel<%d,%d>" % (blk(cin), blk(cout))
             elif kernel == "stem":
                 n = "stem_fwd_kernel"
+            elif kernel == "dense":
+                n = "dense_kernel<%d>" % (lambda ns: ns if ns <= 4 else (4 if ns % 4 == 0 else (3 if ns % 3 == 0 else 4)))((cin + 31) // 32)
             elif kernel == "wgrad_stem":
                 n = "stem_wgrad_kernel"
             else:
@@ -986,7 +990,7 @@ def main():
             except Exception:
                 pmc = None
         tflops = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
-        mfma_peak = X6_PEAK_TFLOPS if ("x6" in name or "_tl_" in name or "_ws_" in name) else FP32_PEAK_TFLOPS
+        mfma_peak = X6_PEAK_TFLOPS if ("x6" in name or "_tl_" in name or "_ws_" in name or "dense_" in name) else FP32_PEAK_TFLOPS
         # which roof binds this kernel: the one whose time-at-peak is larger (arithmetic intensity vs ridge)
         t_hbm = gk["bytes"] / (HBM_PEAK_GBS * 1e9)
         t_mfma = gk["flops"] / (mfma_peak * 1e12)
@@ -1006,7 +1010,7 @@ def main():
                   "hbm_GBps": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
                   "mfma_TFLOPs": tflops, "mfma_peak_TFLOPs": mfma_peak, "mfma_frac": tflops / mfma_peak,
                   "mfma_peak_note": ("dense bf16 peak / 6 (six bf16 MFMAs per fp32-equivalent product)"
-                                     if ("x6" in name or "_tl_" in name or "_ws_" in name) else "fp32 MFMA peak"),
+                                     if ("x6" in name or "_tl_" in name or "_ws_" in name or "dense_" in name) else "fp32 MFMA peak"),
                   "step_hbm_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   "step_mfma_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / X6_PEAK_TFLOPS,
                   "step_fp32_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}

@@ -270,6 +270,13 @@ int osn_spconv_wgrad_tl_partial(const float* in, const float* gout, const void* 
                                 osn_wgrad_job* job_host, osn_stream_t stream);
 int osn_wgrad_tl_reduce_batch(const osn_wgrad_job* jobs_host, int n_jobs, osn_stream_t stream);
 
+/* 1x1 convolution = row-wise matrix product ([ME] MinkowskiConvolution(kernel_size=1): the head `final`,
+ * models/mink_unet.py:108-113, and the BasicBlock shortcuts, models/resnet_base.py:101-107; with the input-gradient image
+ * their backward):  out[n, cout] = in[n, cin] @ B,  B given as an osn_weight_prep_tl image with K = 1 (forward image:
+ * B = W; input-gradient image: B = W^T, `cin` then counts the conv's OUTPUT channels).  Same split-bf16 arithmetic as
+ * osn_spconv_fwd_tl; no workspace.  Needs cin % 4 == 0, cin >= 8, cout % 4 == 0.                                    */
+int osn_dense_fwd(const float* in, const void* Wp, float* out, int64_t n, int cin, int cout, osn_stream_t stream);
+
 /* Convolution of a SMALL map (<= 16 k rows) from its per-offset pair arrays, weight-stationary ([ME]
  * MinkowskiConvolution[Transpose] forward, models/mink_unet.py:51-113 on the 1/4 .. 1/16 levels; with the input-gradient
  * weight image also their backward):  a workgroup keeps W[k] of ONE offset in registers and multiplies a chunk of that
@@ -510,7 +517,7 @@ typedef struct osn_net_desc {
     const osn_net_buf* bufs;
 } osn_net_desc;
 enum { OSN_NET_K_NONE = 0, OSN_NET_K_STEM = 1, OSN_NET_K_TL = 2, OSN_NET_K_X6 = 3, OSN_NET_K_WGRAD_TL = 4, OSN_NET_K_WGRAD = 5,
-       OSN_NET_K_WS = 6, OSN_NET_K_WS_DIRECT = 7, OSN_NET_K_WGRAD_STEM = 8 };
+       OSN_NET_K_WS = 6, OSN_NET_K_WS_DIRECT = 7, OSN_NET_K_WGRAD_STEM = 8, OSN_NET_K_DENSE = 9 };
 enum { OSN_NET_IMG_X6_FWD = 1, OSN_NET_IMG_X6_DGRAD = 2, OSN_NET_IMG_TL_FWD = 4, OSN_NET_IMG_TL_DGRAD = 8 };
 typedef struct osn_net_plan {                 /* every array is caller-provided HOST memory                       */
     uint64_t fwd_arena_bytes, bwd_arena_bytes, ws_bytes;

@@ -50,6 +50,7 @@ static int ws_kernel(const osn_net_desc* net, const osn_net_op& o, int ca, int c
     if (net->ws_max_rows > 0 && n_dst <= net->ws_max_rows) return OSN_NET_K_WS;
     return 0;
 }
+static bool dense_eligible(int cin, int cout) { return (cin & 3) == 0 && cin >= 8 && (cout & 3) == 0; }
 static bool x6_eligible(int K, int cin, int cout, int64_t n_out) {
     if ((cin & 3) || cin < 8) return false;
     if (int64_t(3) * K * cout * ((cin + 31) / 32 * 32) >= (int64_t(1) << 30)) return false;
@@ -131,6 +132,9 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
         if (stem_eligible(o.K, o.cin, o.cout)) {
             OSN_REQUIRE(!o.transposed, OSN_E_ARG, "osn_net: op %d: transposed stem", i);
             L.fwd_k[i] = OSN_NET_K_STEM;
+        } else if (o.K == 1 && dense_eligible(o.cin, o.cout)) {
+            L.fwd_k[i] = OSN_NET_K_DENSE;
+            L.images[i] |= OSN_NET_IMG_TL_FWD;
         } else if (ws_kernel(net, o, o.cin, o.cout, n_in, n_out, o.transposed != 0) == OSN_NET_K_WS_DIRECT) {
             L.fwd_k[i] = OSN_NET_K_WS_DIRECT;
             L.images[i] |= OSN_NET_IMG_TL_FWD;
@@ -154,7 +158,10 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
         // ---- input gradient: a convolution of the output gradient with the transposed weights, [n_in, cin]
         if (o.need_dgrad) {
             const int wsk = tl_eligible(o.K, o.cin, o.cout, n_in) ? ws_kernel(net, o, o.cout, o.cin, n_out, n_in, o.transposed == 0) : 0;
-            if (wsk == OSN_NET_K_WS_DIRECT) {
+            if (o.K == 1 && dense_eligible(o.cin, o.cout) && dense_eligible(o.cout, o.cin)) {
+                L.dgrad_k[i] = OSN_NET_K_DENSE;
+                L.images[i] |= OSN_NET_IMG_TL_DGRAD;
+            } else if (wsk == OSN_NET_K_WS_DIRECT) {
                 L.dgrad_k[i] = OSN_NET_K_WS_DIRECT;
                 L.images[i] |= OSN_NET_IMG_TL_DGRAD;
                 need_ws(osn_spconv_fwd_ws_ws_bytes(n_in, o.K, o.cin, 1));
@@ -267,6 +274,9 @@ static int run_conv(int kernel, const float* in, int64_t n_in, float* out, int64
                     const int32_t* t_tbl, const uint32_t* t_g, const void* tl, const int32_t* tl_rows, int tl_bm,
                     const void* pl, int64_t pl_rows, int pl_swap, const osn_net_run* run, osn_stream_t stream, int op) {
     switch (kernel) {
+        case OSN_NET_K_DENSE:
+            OSN_REQUIRE(img_tl && K == 1 && n_in == n_out, OSN_E_ARG, "osn_net: op %d: the 1x1 kernel needs the fragment-order weight image", op);
+            return osn_dense_fwd(in, img_tl, out, n_out, cin, cout, stream);
         case OSN_NET_K_WS:
         case OSN_NET_K_WS_DIRECT:
             OSN_REQUIRE(pl && img_tl && nbr, OSN_E_ARG, "osn_net: op %d: pair arrays / tile-list weight image / destination table missing", op);

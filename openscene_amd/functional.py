@@ -74,6 +74,7 @@ class SparseConvFunction(Function):
         ctx.wp_dgrad = None
         ctx.tl_bwd = None
         ctx.ws_bwd = None
+        ctx.dense_bwd = None
         # the cached weight images are shared and refreshed in place: remember which version of the kernel the image kept
         # for the backward pass belongs to (a weight changed through .data between forward and backward bypasses autograd's
         # own saved-tensor check)
@@ -82,6 +83,11 @@ class SparseConvFunction(Function):
         ctx.stem = CONV_MODE != "fp32" and nbr_fwd is not None and ops.stem_eligible(K, cin, cout)
         if ctx.stem:
             return ops.stem_conv_fwd(feats, kernel, nbr_fwd, n_out)
+        if CONV_MODE == "tl" and K == 1 and ops.dense_eligible(cin, cout):
+            # 1x1 convs (head, shortcuts): the row-wise matrix-product kernel, forward and input gradient
+            if ctx.needs_input_grad[0] and ops.dense_eligible(cout, cin):
+                ctx.dense_bwd = ops.weight_image(kernel, False, True, ops.PREP_TL)
+            return ops.dense_fwd(feats, ops.weight_image(kernel, False, False, ops.PREP_TL), cout)
         if CONV_MODE == "tl" and K > 1 and ops.tl_eligible(K, cin, cout, ctx.n_in):
             # weight-stationary kernel from the map's pair arrays (those of the strided / self direction: a transposed conv
             # walks them the other way): forward, and -- decided here, launched in backward -- the input gradient, which on
@@ -124,7 +130,7 @@ class SparseConvFunction(Function):
         gout = gout.contiguous()
         gin = gk = None
         K = 1 if kernel.dim() == 2 else kernel.shape[0]
-        if (ctx.wp_dgrad is not None or ctx.ws_bwd is not None) and ctx.kver != (kernel._version, kernel.data_ptr()):
+        if (ctx.wp_dgrad is not None or ctx.ws_bwd is not None or ctx.dense_bwd is not None) and ctx.kver != (kernel._version, kernel.data_ptr()):
             raise RuntimeError("a convolution kernel changed between its forward and its backward pass (version %d -> %d): "
                                "the input-gradient weight image kept from the forward is stale" % (ctx.kver[0], kernel._version))
 
@@ -157,7 +163,10 @@ class SparseConvFunction(Function):
             cin, cout = kernel.shape[-2], kernel.shape[-1]
             tbl, rows, gm = (tiles_bwd[1], tiles_bwd[0], tiles_bwd[2]) if tiles_bwd is not None else (nbr_bwd, None, None)
             mode = "bf16x6" if CONV_MODE == "tl" else CONV_MODE
-            if ctx.tl_bwd is not None:
+            if ctx.dense_bwd is not None:
+                gin = ops.dense_fwd(gout, ctx.dense_bwd, cin)
+                ctx.dense_bwd = None
+            elif ctx.tl_bwd is not None:
                 gin = ops.spconv_fwd_tl(gout, ctx.wp_dgrad, ctx.tl_bwd, ctx.n_in, K, cin)
                 ctx.wp_dgrad = ctx.tl_bwd = None
             elif ctx.ws_bwd is not None:

@@ -731,6 +731,29 @@ def spconv_wgrad_tl(feats, gout, tl, K, swap=False):
     return gw
 
 
+def dense_eligible(cin, cout):
+    """Shapes the 1x1-convolution kernel takes (everything of the U-Net family; odd widths stay on the generic kernel)."""
+    return cin % 4 == 0 and cin >= 8 and cout % 4 == 0
+
+
+def dense_fwd(feats, wp, cout):
+    """out = feats @ B, B a weight_prep_tl image of a K = 1 weight (forward image, or the input-gradient image)."""
+    dev = feats.device
+    lib = _prep(dev)
+    feats = _f32c(feats, "features")
+    n, cin = feats.shape
+    need = _cached("osn_weight_prep_tl_bytes", 1, cin, cout, 0)
+    if wp.numel() != need:
+        raise ValueError("prepared weight has %d bytes, a [%d, %d] 1x1 conv needs %d" % (wp.numel(), cin, cout, need))
+    out = torch.empty((n, cout), dtype=torch.float32, device=dev)
+    tok = _prof_start("dense_fwd", dev, n_in=n, n_out=n, K=1, cin=cin, cout=cout)
+    with _Dev(dev):
+        check(lib.osn_dense_fwd(_p(feats), _p(wp), _p(out), n, cin, cout, _stream(dev)), "osn_dense_fwd")
+    if tok is not None:
+        _profiler.stop(tok)
+    return out
+
+
 def stem_conv_wgrad(feats, gout, nbr, K):
     """gW [K, cin, 32] of the stem convolution (stem_eligible shapes) from the plain neighbour table."""
     dev = feats.device

@@ -70,7 +70,7 @@ def test_planned_kernels_are_the_per_module_choice():
 
     def want(o, c_src, c_dst, n_src, n_dst, dst_fine):
         if o["K"] == 1:
-            return "x6"
+            return "dense"
         ws = F_.ws_kernel(o["K"], c_src, c_dst, n_src, n_dst, bool(o["fine_unique"]), dst_fine)
         if ws == "ws_direct":
             return ws

@@ -91,7 +91,7 @@ def test_training_step_runs_through_the_real_wrappers(mock_ops):
     assert (n_conv, n_bn) == (49, 48)                 # MinkUNet18A (a9 / a10)
     # one forward launch per conv, one input gradient each except the stem (its input needs none), one weight
     # gradient each; three BN calls per BatchNorm; at most one weight-prep launch per conv
-    n_fwd = c.get("osn_spconv_fwd", 0) + c.get("osn_spconv_fwd_x6", 0) + c.get("osn_spconv_fwd_tl", 0) + c.get("osn_spconv_fwd_tl_pc", 0) + c.get("osn_stem_conv_fwd", 0) + c.get("osn_spconv_fwd_ws", 0)
+    n_fwd = c.get("osn_spconv_fwd", 0) + c.get("osn_spconv_fwd_x6", 0) + c.get("osn_spconv_fwd_tl", 0) + c.get("osn_spconv_fwd_tl_pc", 0) + c.get("osn_stem_conv_fwd", 0) + c.get("osn_spconv_fwd_ws", 0) + c.get("osn_dense_fwd", 0)
     assert n_fwd == 2 * n_conv - 1, c
     assert c.get("osn_spconv_wgrad", 0) + c.get("osn_spconv_wgrad_tl", 0) + c.get("osn_stem_conv_wgrad", 0) == n_conv, c
     assert c.get("osn_pair_lists_build", 0) <= 10, c            # pair arrays: once per map, not per conv

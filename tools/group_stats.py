@@ -6,6 +6,7 @@ import sys
 
 def group(n):
     if 'spconv_tl' in n or 'tl_reduce_parts' in n: return 'conv fwd/dgrad TL'
+    if 'dense_kernel' in n: return 'conv 1x1 (dense kernel)'
     if 'spconv_ws' in n: return 'conv fwd/dgrad WS (small maps, 2^3 fine side)'
     if 'spconv_fwd_x6' in n or 'spconv_fwd_kernel' in n or 'spconv_fwd_pipe' in n or 'stem_fwd' in n: return 'conv fwd/dgrad x6+stem'
     if 'reduce_partial_rows' in n or 'fixup_units' in n: return 'conv partial reduce/fixup'
