@@ -60,16 +60,16 @@ def query_distill_fused(features, final_kernel, text_features, inds_reverse=None
 
 
 def _rows_times(features, M):
-    """features [N, c_in] (float32, device) @ M [c_in, c] at fp32 accuracy on the split-bf16 convolution kernel (K = 1)."""
+    """features [N, c_in] (float32, device) @ M [c_in, c] at fp32 accuracy on the split-bf16 1x1-convolution kernel (csrc/dense.hip)."""
     import torch
     c = M.shape[1]
     cp = (c + 3) // 4 * 4
     if cp != c:
         M = torch.cat([M, M.new_full((M.shape[0], cp - c), 0.0)], 1)
     n = features.shape[0]
-    if ops.tl_eligible(1, M.shape[0], cp, n):
+    if ops.dense_eligible(M.shape[0], cp):
         wf, _ = ops.weight_prep_tl(M.contiguous(), want_dgrad=False)
-        out = ops.spconv_fwd_tl(features, wf, None, n, 1, cp)
+        out = ops.dense_fwd(features, wf, cp)
     else:
         out = ops.spconv_fwd(features, M.contiguous(), None, n)
     return out[:, :c]
