@@ -139,8 +139,15 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 __global__ void stem_wgrad_reduce_kernel(const float* __restrict__ partial, int parts, int total, float* __restrict__ gW) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
+    // 16 loads in flight, then their adds in order (a loop of dependent load + add pairs is 128 memory round trips)
     float s = 0.f;
-    for (int p = 0; p < parts; ++p) s += partial[int64_t(p) * total + e];
+    for (int p0 = 0; p0 < parts; p0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = partial[int64_t(p0 + u < parts ? p0 + u : p0) * total + e];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += p0 + u < parts ? v[u] : 0.f;
+    }
     gW[e] = s;
 }
 

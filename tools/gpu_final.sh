@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round-end evidence in one call: full GPU tests + smoke, the default bench line (with the CPU baseline), the same bench command
+# under rocprofv3 (whole-run kernel stats + the dominant kernel's dispatch durations), per-step kernel stats of the training
+# step, and the PMC traffic passes of the tile-list kernels.   usage: gpu_final.sh <tag>
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$1
+mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+t0=$(date +%s)
+timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest exit $? in $(( $(date +%s) - t0 )) s"; tail -2 $O/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke exit $?"; tail -1 $O/smoke.log
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit $?"
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/whole -o trace -- python $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+python $R/tools/rocpd_stats.py $O/whole/trace_results.db > $O/kernel_stats_whole_run.csv
+python $R/tools/rocpd_stats.py $O/whole/trace_results.db --dispatches spconv_tl_kernel 400 > $O/tl_dispatches.txt
+rm -rf $O/whole
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o trace -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events --train-only > $O/prof.json 2> $O/prof.err
+python $R/tools/rocpd_stats.py $O/prof/trace_results.db 13 > $O/stats.csv
+python $R/tools/rocpd_stats.py $O/prof/trace_results.db --streams 13 > $O/streams.txt
+python $R/tools/group_stats.py $O/stats.csv > $O/groups.txt
+rm -rf $O/prof
+cat $O/groups.txt | head -24
+cd $R
+bash tools/pmc_tl.sh > $O/pmc_tl.log 2>&1; cp gpurun_out/pmc_tl/summary.txt $O/pmc_tl_summary.txt 2>/dev/null; rm -rf gpurun_out/pmc_tl/*_p*; tail -3 $O/pmc_tl.log
+python -c "
+import json
+for l in open('$O/bench.json'):
+    if l.startswith('{'):
+        d=json.loads(l); print(d['ms_per_step'], d['value'], d['roofline']['kernel'], d['roofline']['frac'], d['cpu_baseline'])"
