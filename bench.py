@@ -480,6 +480,7 @@ def main():
     ap.add_argument("--no-prefetch-maps", action="store_true", help="queue only the coordinate pyramid of the next batch ahead; "
                     "its kernel maps are built inside the step (the round-3 default until the maps came from one C call on one "
                     "stream: 11.10 ms against 10.57 ms per step with the maps ahead as well, profiles/r03_s10)")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of openscene_amd.optim.FlatAdam")
     ap.add_argument("--torch-loss", action="store_true", help="cosine loss through torch's own operators (index_select, "
                     "CosineSimilarity, mean and their autograd chain) instead of openscene_amd.losses.distill_loss")
     ap.add_argument("--no-prefetch-pyramid", action="store_true", help="build the coordinate pyramid of a batch inside its own step "
@@ -542,10 +543,16 @@ def main():
         from openscene_amd.distributed import FlatGradAllReduce
         exchange = FlatGradAllReduce(model, single_rank_collectives=args.dist_single)
         exchange.sync_buffers()     # rank 0's BN running statistics: needed before evaluation / checkpoints, not per step
-    try:
-        optim = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
-    except (TypeError, RuntimeError):
-        optim = torch.optim.Adam(net.parameters(), lr=1e-4)
+    if args.torch_adam or args.ddp:        # (DDP's reducer keeps views of the parameter storage: leave it alone)
+        try:
+            optim = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
+        except (TypeError, RuntimeError):
+            optim = torch.optim.Adam(net.parameters(), lr=1e-4)
+    else:
+        # Adam over one flat buffer in the layout of the executor's gradient buffer: one launch per step
+        # (openscene_amd.optim.FlatAdam; same update rule and checkpoint layout as torch.optim.Adam)
+        from openscene_amd.optim import FlatAdam
+        optim = FlatAdam(model, lr=1e-4)
 
     coords0 = build_scene(rank, device, args.scene_points)             # one scene per GPU (batch 8 over 8 GPUs), seed = rank
     n_vox = coords0.shape[0]

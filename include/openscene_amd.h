@@ -386,6 +386,14 @@ int osn_distill_loss_bwd(const float* out, const float* target, const float* glo
                          float* gout, const void* state, size_t state_bytes, osn_stream_t stream);
 int osn_distill_loss_check(const void* state, int64_t n, int64_t n_sel, osn_stream_t stream);
 
+/* ---- optimizer step over one flat buffer ------------------------------------------------------------ *
+ * Replaces optimizer.step() of torch.optim.Adam (run/distill.py:170-178 builds it, :333 steps it) for parameters,
+ * gradients and moment estimates laid out as four flat fp32 arrays of n elements (n % 4 == 0; the network executor's
+ * gradient buffer has that layout).  step = the 1-based count of this update.  The update rule of torch's Adam
+ * (amsgrad = False, maximize = False; L2 weight decay added to the gradient): one launch, 28 bytes per parameter.   */
+int osn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, osn_stream_t stream);
+
 /* ---- row-aligned elementwise pieces --------------------------------------- *
  * Replaces the stand-alone [ME] MinkowskiReLU (models/mink_unet.py:114, used un-fused by the reference's own module
  * chain), the BasicBlock residual `out += residual` when it is not fused into a batch norm, and ME.cat of two tensors

@@ -1,0 +1,135 @@
+"""Adam over one flat parameter buffer -- the mirror of ``torch.optim.Adam(model.parameters(), lr=...)``
+(run/distill.py:170-178, stepped at :333) for the case the network executor creates: every gradient is a slice of ONE flat
+fp32 buffer.  ``FlatAdam`` lays the parameters and both moment estimates out the same way (each parameter's slice starts on
+a 16-byte boundary) and an optimizer step is one launch (csrc/optim.hip: ``osn_adam_step``) instead of torch's fused
+multi-tensor Adam (5 launches, 236 us per step for MinkUNet18A; this: ~60 us).
+
+    optim = FlatAdam(model, lr=1e-4)        # re-points every parameter's storage into the flat buffer (values kept)
+    loss.backward(); optim.step()
+
+Update rule, hyper-parameters and state semantics are torch.optim.Adam's (amsgrad=False, maximize=False, L2 weight decay);
+`state_dict()` / `load_state_dict()` use torch's layout (`exp_avg`, `exp_avg_sq`, `step` per parameter), so checkpoints
+written by the reference's save_checkpoint (run/distill.py:232-239) load here and vice versa."""
+import torch
+
+from . import ops
+from ._lib import check
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, model_or_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        params = self._ordered(model_or_params)
+        if not params:
+            raise ValueError("FlatAdam got no parameters")
+        if not all(p.dtype == torch.float32 and p.device == params[0].device for p in params):
+            raise ValueError("FlatAdam needs float32 parameters on one device")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        dev = params[0].device
+        self.offsets, off = [], 0
+        for p in params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.total = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.steps = 0
+        self._grad_scratch = None
+        with torch.no_grad():
+            for p, o in zip(params, self.offsets):
+                view = self.flat[o:o + p.numel()].view_as(p)
+                view.copy_(p)
+                p.data = view                      # same values, new storage: cached weight images follow the data pointer
+        ops.clear_weight_cache()
+        self._params = params
+
+    @staticmethod
+    def _ordered(model_or_params):
+        """The parameters in the order of the executor's gradient buffer when the model has one (so that the gradients arrive
+        as one flat array with the optimizer's own layout), else in the order given."""
+        if isinstance(model_or_params, torch.nn.Module):
+            from . import executor as E
+            from .mink_unet import MinkUNetBase
+            seen, out = set(), []
+            for m in model_or_params.modules():
+                if isinstance(m, MinkUNetBase):
+                    ex = E.for_model(m) if E.ENABLED else None
+                    if ex is not None:
+                        for p in ex.program.params:
+                            if id(p) not in seen:
+                                seen.add(id(p)); out.append(p)
+            for p in model_or_params.parameters():
+                if id(p) not in seen:
+                    seen.add(id(p)); out.append(p)
+            return [p for p in out if p.requires_grad]
+        return [p for p in model_or_params if p.requires_grad]
+
+    def _flat_grads(self):
+        """The gradients as one flat array in this optimizer's layout: the executor's buffer itself when every p.grad is a
+        slice of it at the right offset, else a gathered copy (parameters without a gradient contribute zeros: like torch's
+        Adam they would be skipped -- no MinkUNet parameter is unused)."""
+        ps = self._params
+        g0 = ps[0].grad
+        if g0 is not None:
+            base = g0.data_ptr() - 4 * self.offsets[0]
+            ok = all(p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 and
+                     p.grad.data_ptr() == base + 4 * o for p, o in zip(ps, self.offsets))
+            if ok:
+                root = g0._base if g0._base is not None else g0
+                if root.data_ptr() == base and root.numel() >= self.total and root.dim() == 1:
+                    return root[:self.total], True
+        if self._grad_scratch is None:
+            self._grad_scratch = torch.zeros_like(self.flat)
+        views = [self._grad_scratch[o:o + p.numel()].view_as(p) for p, o in zip(ps, self.offsets)]
+        have = [(v, p.grad) for v, p in zip(views, ps) if p.grad is not None]
+        for v, p in zip(views, ps):
+            if p.grad is None:
+                v.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        return self._grad_scratch, False
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        group = self.param_groups[0]
+        grads, _ = self._flat_grads()
+        dev = self.flat.device
+        lib = ops._prep(dev)
+        self.steps += 1
+        b1, b2 = group["betas"]
+        with ops._Dev(dev):
+            check(lib.osn_adam_step(ops._p(self.flat), ops._p(grads), ops._p(self.exp_avg), ops._p(self.exp_avg_sq), self.total,
+                                    self.steps, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                    float(group["weight_decay"]), ops._stream(dev)), "osn_adam_step")
+        # the kernel wrote the parameters behind autograd's back: move their version counters (weight-image cache, saved-tensor checks)
+        torch.autograd.graph.increment_version(self._params)
+        return loss
+
+    # ---- torch.optim.Adam's checkpoint layout
+    def state_dict(self):
+        state = {}
+        for i, (p, o) in enumerate(zip(self._params, self.offsets)):
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": self.exp_avg[o:o + n].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).clone()}
+        groups = [{**{k: v for k, v in g.items() if k != "params"}, "params": list(range(len(self._params)))} for g in self.param_groups]
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        for k, v in sd["param_groups"][0].items():
+            if k != "params":
+                self.param_groups[0][k] = v
+        steps = 0
+        for i, (p, o) in enumerate(zip(self._params, self.offsets)):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            n = p.numel()
+            self.exp_avg[o:o + n].view_as(p).copy_(st["exp_avg"])
+            self.exp_avg_sq[o:o + n].view_as(p).copy_(st["exp_avg_sq"])
+            steps = max(steps, int(float(st["step"])))
+        self.steps = steps

@@ -190,6 +190,53 @@ def _query_inputs(n_vox, n_pts, d, c, seed):
     return x, t, gather
 
 
+@pytest.mark.parametrize("flat_grads", [False, True])
+@pytest.mark.parametrize("weight_decay", [0.0, 0.01])
+def test_flat_adam_equals_torch_adam(flat_grads, weight_decay):
+    """openscene_amd.optim.FlatAdam (one launch over a flat buffer) against torch.optim.Adam on the same gradients for five
+    steps: parameters within 1e-6 relative of torch's, moments too; gradients given as separate tensors (gathered) and as
+    slices of one flat buffer in the optimizer's layout (read in place, as the network executor delivers them); the
+    checkpoint layout is torch's."""
+    from openscene_amd.optim import FlatAdam
+    dv = dev()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(27, 32, 32), (96,), (96, 768), (3, 5), (1,)]          # odd sizes: every slice still starts 16-byte aligned
+    init = [torch.randn(s, generator=g) for s in shapes]
+    ref_p = [torch.nn.Parameter(t.clone().to(dv)) for t in init]
+    our_p = [torch.nn.Parameter(t.clone().to(dv)) for t in init]
+    ref = torch.optim.Adam(ref_p, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=weight_decay)
+    ours = FlatAdam(our_p, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=weight_decay)
+    assert all(torch.equal(a.detach(), b.detach()) for a, b in zip(ref_p, our_p))          # flattening kept the values
+    for step in range(5):
+        grads = [torch.randn(s, generator=g) * (10.0 ** (step - 2)) for s in shapes]
+        flat = torch.zeros(ours.total, device=dv)
+        for p, q, gr, o in zip(ref_p, our_p, grads, ours.offsets):
+            p.grad = gr.to(dv)
+            if flat_grads:
+                v = flat[o:o + gr.numel()].view(gr.shape)
+                v.copy_(gr)
+                q.grad = v
+            else:
+                q.grad = gr.to(dv)
+        assert ours._flat_grads()[1] == flat_grads
+        versions = [q._version for q in our_p]
+        ref.step()
+        ours.step()
+        assert all(q._version > v for q, v in zip(our_p, versions))
+        for p, q in zip(ref_p, our_p):
+            assert torch.allclose(q.detach(), p.detach(), rtol=2e-6, atol=1e-7), (step, (q - p).abs().max().item())
+    sd_r, sd_o = ref.state_dict(), ours.state_dict()
+    for i in range(len(shapes)):
+        assert torch.allclose(sd_o["state"][i]["exp_avg"], sd_r["state"][i]["exp_avg"], rtol=2e-6, atol=1e-9)
+        assert torch.allclose(sd_o["state"][i]["exp_avg_sq"], sd_r["state"][i]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+        assert float(sd_o["state"][i]["step"]) == float(sd_r["state"][i]["step"]) == 5.0
+    # torch's checkpoint loads into the flat optimizer
+    again = FlatAdam([torch.nn.Parameter(t.clone().to(dv)) for t in init], lr=1.0)
+    again.load_state_dict(sd_r)
+    assert again.steps == 5 and again.param_groups[0]["lr"] == 3e-3
+    assert torch.allclose(again.state_dict()["state"][2]["exp_avg"], sd_r["state"][2]["exp_avg"])
+
+
 @pytest.mark.parametrize("loss_type", ["cosine", "l1"])
 @pytest.mark.parametrize("n,n_sel,d", [(5000, 1200, 768), (777, 777, 512), (64, 1, 20)])
 def test_distill_loss_forward_and_gradient(n, n_sel, d, loss_type):
