@@ -592,11 +592,22 @@ def main():
 
     pending = [prepare_next()] if prefetch else None
 
+    host_t = {}                                  # OSN_BENCH_HOST_TIMES=1: host seconds per segment of step() (no synchronisation added)
+    host_on = os.environ.get("OSN_BENCH_HOST_TIMES") == "1"
+
+    def seg(name, t_prev):
+        if not host_on:
+            return t_prev
+        t = time.perf_counter()
+        host_t[name] = host_t.get(name, 0.0) + (t - t_prev)
+        return t
+
     def step():
         # `out[mask]` with a bool mask makes torch read the selected-row count back in the MIDDLE of the step
         # (host stalls until the forward has drained, then refills an empty queue).  The row indices of the mask
         # are batch data (openscene_amd.loader hands them out): resolve them here, next to the size read-backs
         # of the coordinate pyramid, and the rest of the step runs without a host sync.
+        t_ = time.perf_counter() if host_on else 0.0
         if prefetch:
             # the pyramid (full prefetch: and the maps) of this batch was queued on the side stream while the previous
             # step ran; every step still builds exactly one pyramid and one set of maps
@@ -606,17 +617,23 @@ def main():
         else:
             sel = mask.nonzero(as_tuple=False).squeeze(1)
             sinput = SparseTensor(feats, next_coords())            # builds every map (ME does per forward)
+        t_ = seg("take", t_)
         out = net(sinput)
+        t_ = seg("forward", t_)
         # (1 - cos(out[mask], feat_3d)).mean(), run/distill.py:322-326: one fused forward and one fused backward launch
         # (openscene_amd.losses, csrc/loss.hip); --torch-loss keeps torch's own ~25-launch chain
         loss = distill_loss(out, sel, feat_3d) if LOSS_HIP else (1 - cos(out.index_select(0, sel), feat_3d)).mean()
         optim.zero_grad(set_to_none=True)
+        t_ = seg("loss", t_)
         loss.backward()
+        t_ = seg("backward", t_)
         if exchange is not None:
             exchange.reduce_gradients()                            # ONE all-reduce (RCCL over xGMI), mean over ranks
         optim.step()
+        t_ = seg("optimizer", t_)
         if prefetch:
             pending[0] = prepare_next()
+        seg("prepare_next", t_)
         return loss
 
     def sync():
@@ -708,11 +725,16 @@ def main():
             legacy.only = (d_name, d_K, d_cin, d_cout, d_g["meta"]["n_out"])
             dom_key = (d_name, d_K, d_cin, d_cout, 0)
     sync()
+    host_t.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_issue = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
+    if host_on and rank == 0:
+        print("host issue %.3f ms/step of %.3f ms/step; segments (ms/step): %s" % (
+            1e3 * t_issue / args.steps, 1e3 * dt / args.steps, {k: round(1e3 * v / args.steps, 3) for k, v in host_t.items()}), file=sys.stderr)
     timed_groups = None
     if prof is not None:
         prof.attach(False)

@@ -70,14 +70,12 @@ class FlatAdam(torch.optim.Optimizer):
         Adam they would be skipped -- no MinkUNet parameter is unused)."""
         ps = self._params
         g0 = ps[0].grad
-        if g0 is not None:
-            base = g0.data_ptr() - 4 * self.offsets[0]
-            ok = all(p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 and
-                     p.grad.data_ptr() == base + 4 * o for p, o in zip(ps, self.offsets))
-            if ok:
-                root = g0._base if g0._base is not None else g0
-                if root.data_ptr() == base and root.numel() >= self.total and root.dim() == 1:
-                    return root[:self.total], True
+        root = g0._base if g0 is not None else None
+        if (root is not None and root.dim() == 1 and root.dtype == torch.float32 and root.is_contiguous() and
+                root.numel() >= self.total and root.storage_offset() == 0 and
+                all(p.grad is not None and p.grad._base is root and p.grad.storage_offset() == o and p.grad.is_contiguous()
+                    for p, o in zip(ps, self.offsets))):
+            return root[:self.total], True
         if self._grad_scratch is None:
             self._grad_scratch = torch.zeros_like(self.flat)
         views = [self._grad_scratch[o:o + p.numel()].view_as(p) for p, o in zip(ps, self.offsets)]

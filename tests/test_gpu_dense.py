@@ -227,8 +227,9 @@ def test_flat_adam_equals_torch_adam(flat_grads, weight_decay):
             assert torch.allclose(q.detach(), p.detach(), rtol=2e-6, atol=1e-7), (step, (q - p).abs().max().item())
     sd_r, sd_o = ref.state_dict(), ours.state_dict()
     for i in range(len(shapes)):
-        assert torch.allclose(sd_o["state"][i]["exp_avg"], sd_r["state"][i]["exp_avg"], rtol=2e-6, atol=1e-9)
-        assert torch.allclose(sd_o["state"][i]["exp_avg_sq"], sd_r["state"][i]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+        for key in ("exp_avg", "exp_avg_sq"):          # (the first moment cancels: absolute bound at fp32 resolution of its largest element)
+            r_ = sd_r["state"][i][key]
+            assert torch.allclose(sd_o["state"][i][key], r_, rtol=2e-6, atol=2e-6 * float(r_.abs().max())), (i, key)
         assert float(sd_o["state"][i]["step"]) == float(sd_r["state"][i]["step"]) == 5.0
     # torch's checkpoint loads into the flat optimizer
     again = FlatAdam([torch.nn.Parameter(t.clone().to(dv)) for t in init], lr=1.0)

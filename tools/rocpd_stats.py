@@ -3,7 +3,8 @@
 (`rocprofv3 --kernel-trace --stats -d DIR -o NAME -- cmd` writes NAME_results.db on this ROCm), as CSV.
 usage: rocpd_stats.py trace_results.db [steps]   (steps: divide the calls / totals to per-step figures)
        rocpd_stats.py trace_results.db --dispatches PATTERN [N]   (durations in us of the last N dispatches of the kernels
-                                                                   whose name contains PATTERN, in launch order)"""
+                                                                   whose name contains PATTERN, in launch order)
+       rocpd_stats.py trace_results.db --timeline PATTERN [BEFORE_US [AFTER_US]]   (every dispatch around the last PATTERN launch)"""
 import re
 import sqlite3
 import sys
@@ -22,6 +23,25 @@ def dispatches(db, pattern, n):
     print("# last %d dispatches of kernels matching %r (us, launch order)" % (len(sel), pattern))
     for k, us in sel:
         print("%-60s %9.2f" % (k[:60], us))
+
+
+def timeline(db, pattern, before, after):
+    """Every dispatch (stream, start and end in us relative to the anchor's start, name) from `before` us before to `after`
+    us after the start of the LAST dispatch whose kernel name contains `pattern`."""
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(rocpd_kernel_dispatch)").fetchall()]
+    key = "stream_id" if "stream_id" in cols else "queue_id"
+    rows = cur.execute("select d.%s, d.start, d.end, s.kernel_name from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+                       "on d.kernel_id = s.id order by d.start" % key).fetchall()
+    anchors = [a for _, a, _, n in rows if pattern in n]
+    if not anchors:
+        print("no dispatch matches", pattern)
+        return
+    t0 = anchors[-1]
+    print("# stream  start_us  end_us  dur_us  kernel   (0 = start of the last %r dispatch)" % pattern)
+    for k, a, b, n in rows:
+        if t0 - before * 1e3 <= a <= t0 + after * 1e3:
+            print("%3s %9.1f %9.1f %7.1f  %s" % (k, (a - t0) / 1e3, (b - t0) / 1e3, (b - a) / 1e3, short(n)[:90]))
 
 
 def per_stream(db, steps):
@@ -85,6 +105,8 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     if len(sys.argv) > 3 and sys.argv[2] == "--dispatches":
         return dispatches(db, sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 64)
+    if len(sys.argv) > 3 and sys.argv[2] == "--timeline":
+        return timeline(db, sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 500.0, float(sys.argv[5]) if len(sys.argv) > 5 else 500.0)
     if len(sys.argv) > 2 and sys.argv[2] == "--streams":
         return per_stream(db, float(sys.argv[3]) if len(sys.argv) > 3 else 1.0)
     steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
