@@ -595,11 +595,16 @@ def main():
     host_t = {}                                  # OSN_BENCH_HOST_TIMES=1: host seconds per segment of step() (no synchronisation added)
     host_on = os.environ.get("OSN_BENCH_HOST_TIMES") == "1"
 
+    gpu_marks = []                               # (name, event) recorded on the main stream at the segment boundaries
+
     def seg(name, t_prev):
         if not host_on:
             return t_prev
         t = time.perf_counter()
         host_t[name] = host_t.get(name, 0.0) + (t - t_prev)
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        gpu_marks.append((name, ev))
         return t
 
     def step():
@@ -726,6 +731,7 @@ def main():
             dom_key = (d_name, d_K, d_cin, d_cout, 0)
     sync()
     host_t.clear()
+    del gpu_marks[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -733,6 +739,10 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if host_on and rank == 0:
+        gt = {}
+        for (n0, e0), (n1, e1) in zip(gpu_marks[:-1], gpu_marks[1:]):
+            gt[n1] = gt.get(n1, 0.0) + e0.elapsed_time(e1)
+        print("GPU time between the main stream's segment marks (ms/step): %s" % {k: round(v / args.steps, 3) for k, v in gt.items()}, file=sys.stderr)
         print("host issue %.3f ms/step of %.3f ms/step; segments (ms/step): %s" % (
             1e3 * t_issue / args.steps, 1e3 * dt / args.steps, {k: round(1e3 * v / args.steps, 3) for k, v in host_t.items()}), file=sys.stderr)
     timed_groups = None
