@@ -1088,6 +1088,9 @@ def main():
         "query": qres, "voxelizer": vox_res, "phases": extra, "roofline": roofline, "cpu_baseline": cpu, "comm": comm,
         "kernels": kernels, "stages": stages, "loss": float(loss.detach()),
         "host_path": "network executor (one C call per forward / backward pass)" if ex is not None else "per-module (Python autograd)",
+        "optimizer": ("torch.optim.Adam(fused=True)" if (args.torch_adam or args.ddp) else
+                      "openscene_amd.optim.FlatAdam (torch.optim.Adam's update rule over one flat buffer, one launch)"),
+        "loss_path": "torch operators" if args.torch_loss else "openscene_amd.losses.distill_loss (csrc/loss.hip)",
         "input_pipeline": ("coordinate pyramid, kernel maps and pair arrays of step i+1 built on a side stream during step i" if full_prefetch else
                            "coordinate pyramid (+ mask rows) of step i+1 queued on a side stream during step i; kernel maps inside the step"
                            if prefetch else "pyramid and maps inside the step"),
