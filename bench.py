@@ -824,12 +824,29 @@ def main():
                 return query_distill_fused(f96, w_final, text_f, inds_f)
 
         unf_ms, fus_ms = timed(infer_unfused, 10), timed(infer_fused, 10)
+        # a STREAM of scenes (run/evaluate.py walks the 312 validation scenes): the next scene's pyramid and maps are built on
+        # the prefetcher's stream during the current scene's forward pass (as the training step does) -- throughput, not latency
+        pf_i = MapPrefetcher(device, pairs="ws")
+        with torch.no_grad():
+            with torch.cuda.stream(pf_i.stream):
+                nxt = [pf_i.submit(coords0.clone())]
+
+            def infer_stream():
+                cm_ = pf_i.take(nxt[0])
+                with torch.cuda.stream(pf_i.stream):
+                    nxt[0] = pf_i.submit(coords0.clone())
+                f96, w_final = model.forward_features(SparseTensor(feats, coordinate_manager=cm_))
+                return query_distill_fused(f96, w_final, text_f, inds_f)
+            stream_ms = timed(infer_stream, 20)
         extra = {"inference_fwd": {"ms": fwd_ms, "voxels_per_s": n_vox / (fwd_ms * 1e-3),
                                    "what": "configs[1]: maps + eval-mode forward, %d-d output" % out_dim},
                  "maps_only": {"ms": maps_ms, "what": "coordinate pyramid + every kernel map + tile ordering of one scene"},
                  "inference_plus_query": {"ms": unf_ms, "what": "maps + eval forward + 150 k-point / 20-label query (run/evaluate.py:283-292)"},
                  "inference_plus_query_fused_head": {"ms": fus_ms, "what": "the same with the final 1x1 conv folded into the text "
-                                                     "matrix (SURVEY.md 8(f) row 2): no [N, %d] feature matrix" % out_dim}}
+                                                     "matrix (SURVEY.md 8(f) row 2): no [N, %d] feature matrix" % out_dim},
+                 "inference_stream_fused_head": {"ms": stream_ms, "voxels_per_s": n_vox / (stream_ms * 1e-3),
+                                                 "what": "scenes back to back (fused head + query): maps of scene i+1 built on the "
+                                                         "prefetch stream during the forward pass of scene i; ms per scene"}}
         gq = torch.Generator().manual_seed(5)
         n_pts = 150000
         inds_reverse = torch.randint(0, n_vox, (n_pts,), generator=gq).to(device)
