@@ -32,6 +32,11 @@ __global__ __launch_bounds__(WPB_THREADS) void weight_prep_batch_kernel(const os
                                   ? int64_t(j.K) * ((nc + 31) >> 5) * ((nn + 15) >> 4) * 512
                                   : int64_t(j.K) * nn * ((nc + 31) / 32 * 32);
     __bf16* out = static_cast<__bf16*>(j.out);
+    if (j.layout == OSN_PREP_TL) {                 // fragment layout: a thread's 8 elements are one lane's 16 bytes of a fragment
+        const int64_t e = e0 + int64_t(threadIdx.x) * WPB_PER_THREAD;
+        if (e < per_plane) weight_prep_tl_group(j.W, j.K, j.cin, j.cout, j.flip, j.for_dgrad, e >> 3, out);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < WPB_PER_THREAD; ++i) {
         const int64_t e = e0 + threadIdx.x + i * WPB_THREADS;
