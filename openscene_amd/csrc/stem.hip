@@ -62,6 +62,65 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     }
 }
 
+// The same convolution with the offsets of a row dealt to the FOUR WAVES of a workgroup (round 3): wave w takes the offsets
+// k = w, w + 4, ... of the workgroup's 64 rows (one thread per row leaves a 100 k-row map with 1.5 waves per SIMD and a chain
+// of 125 dependent table -> row -> FMA steps; this gives 6 waves per SIMD and a chain of 32, and k stays wave-uniform, so
+// the weights still come through the scalar cache), the four partial rows meet in LDS and are added in a fixed tree
+// ((p0 + p1) + (p2 + p3)): deterministic, fp32 products exact.
+__global__ __launch_bounds__(256) void stem_fwd4_kernel(const float* __restrict__ in, const float* __restrict__ W,
+                                                        const int32_t* __restrict__ nbr, float* __restrict__ out,
+                                                        int64_t n_out, int K, int cin) {
+    __shared__ float part[4][STEM_COUT][64 + 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t o = int64_t(blockIdx.x) * 64 + lane;
+    const bool row_ok = o < n_out;
+    const int64_t oc = row_ok ? o : 0;
+    float acc[STEM_COUT];
+#pragma unroll
+    for (int c = 0; c < STEM_COUT; ++c) acc[c] = 0.f;
+    for (int k0 = wave; k0 < K; k0 += 16) {                   // 4 offsets of this wave per trip: k0, k0 + 4, k0 + 8, k0 + 12
+        int idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) idx[u] = (row_ok && k0 + 4 * u < K) ? nbr[int64_t(k0 + 4 * u) * n_out + oc] : -1;
+        float x[4][STEM_CMAX];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int ci = 0; ci < STEM_CMAX; ++ci)
+                x[u][ci] = (idx[u] >= 0 && ci < cin) ? in[int64_t(idx[u]) * cin + ci] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + 4 * u < K) {
+                const float* w = W + int64_t(k0 + 4 * u) * cin * STEM_COUT;        // wave-uniform address
+#pragma unroll
+                for (int ci = 0; ci < STEM_CMAX; ++ci)
+                    if (ci < cin) {
+#pragma unroll
+                        for (int c = 0; c < STEM_COUT; ++c) acc[c] = fmaf(x[u][ci], w[ci * STEM_COUT + c], acc[c]);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < STEM_COUT; ++c) part[wave][c][lane] = acc[c];
+    __syncthreads();
+    // thread (row r, quarter q): channels 8 q .. 8 q + 7 of row r
+    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const int64_t orow = int64_t(blockIdx.x) * 64 + r;
+    if (orow < n_out) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 8 * q + j;
+            v[j] = (part[0][c][r] + part[1][c][r]) + (part[2][c][r] + part[3][c][r]);
+        }
+        float4* dst = reinterpret_cast<float4*>(out + orow * STEM_COUT + 8 * q);
+        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 constexpr int SW_ROWS = 64;        // output rows per chunk
 constexpr int SW_KB = 32;          // offsets per workgroup (8 thread groups x 4)
 constexpr int SW_PARTS = 128;      // row parts (workgroups along the rows) = partial sums per weight element
@@ -192,7 +251,11 @@ extern "C" int osn_stem_conv_fwd(const float* in, const float* W, const int32_t*
                 "osn_stem_conv_fwd: needs K <= 125, cin <= %d, cout == %d (K=%d cin=%d cout=%d)", STEM_CMAX, STEM_COUT, K, cin, cout);
     if (n_out == 0) return OSN_OK;
     OSN_REQUIRE(in && W && nbr && out && aligned16(out), OSN_E_ARG, "osn_stem_conv_fwd: null or unaligned pointer");
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3(unsigned(cdiv(n_out, 256))), dim3(256), 0, st, in, W, nbr, out, n_out, K, cin);
+    // four lanes per row from 4096 rows on (below that the single-lane kernel's launch is all there is)
+    if (n_out >= 4096)
+        hipLaunchKernelGGL(stem_fwd4_kernel, dim3(unsigned(cdiv(n_out, 64))), dim3(256), 0, st, in, W, nbr, out, n_out, K, cin);
+    else
+        hipLaunchKernelGGL(stem_fwd_kernel, dim3(unsigned(cdiv(n_out, 256))), dim3(256), 0, st, in, W, nbr, out, n_out, K, cin);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
 }
