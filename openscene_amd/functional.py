@@ -26,10 +26,11 @@ TL_MID_MIN_ROWS = int(os.environ.get("OSN_TL_MID_MIN_ROWS", "8192"))
 
 
 # Weight-stationary kernel (spconv_ws.hip) for the launches that write at most this many rows (measured, profiles/r03_s9:
-# 3 k rows 128 -> 128 34 us against 45, 256 -> 256 69 / 106-122; 700 rows 256 -> 256 30 / 43; a tie at 12.9 k rows), and --
+# 3 k rows 128 -> 128 34 us against 45, 256 -> 256 69 / 106-122; 700 rows 256 -> 256 30 / 43; a tie at 12.9 k rows; the limit
+# 8192 against 4096 / 16384: L235k-34C step 25.5 / 26.2 / 25.6 ms, 8-scene batch 49.5 / 49.8 / 49.7, S100k 9.90 / 9.89 / 10.01), and --
 # without a row limit -- for the launches that write the fine side of a 2^3 stride-2 map, where every row has exactly one
 # pair and the result rows go straight to the output (100 k rows 96 -> 96: 32 us against 70; 48 k rows 128 -> 96: 20 / 62)
-WS_MAX_ROWS = int(os.environ.get("OSN_WS_MAX_ROWS", "4096"))
+WS_MAX_ROWS = int(os.environ.get("OSN_WS_MAX_ROWS", "8192"))
 
 
 def ws_kernel(K, c_src, c_dst, n_src, n_dst, fine_unique, dst_fine):
