@@ -54,12 +54,12 @@ def main():
         steps = ((cnt + 31) // 32).sum().item() * nchunk
         offs = (cnt > 0).sum().item()
         tot = p.sum(1)
-        print("stride %d %d->%d: %d tiles, %.1f offsets and %.1f steps per tile; %.0f ticks per tile (min %.0f max %.0f)" % (
-            stride, cin, cout, tl.n_tiles, offs / tl.n_tiles, steps / tl.n_tiles, tot.mean(), tot.min(), tot.max()))
-        p = p * (512.0 / tl.n_tiles)      # per-workgroup sums -> per-tile averages
+        print("stride %d %d->%d: %d tiles, %.1f offsets and %.1f steps per tile; %.0f ticks per workgroup (min %.0f max %.0f), %.0f per tile" % (
+            stride, cin, cout, tl.n_tiles, offs / tl.n_tiles, steps / tl.n_tiles, tot.mean(), tot.min(), tot.max(), tot.sum() / tl.n_tiles))
+        # p[w, i] = ticks workgroup w spent in phase i over ALL its tiles: per tile = sum / tiles, per step = sum / steps
         for i, name in enumerate(PHASES):
             print("   %-24s %9.0f ticks/tile  %5.1f %%   %8.0f per step" % (
-                name, p[:, i].mean(), 100 * p[:, i].sum() / tot.sum(), p[:, i].sum() / steps))
+                name, p[:, i].sum() / tl.n_tiles, 100 * p[:, i].sum() / tot.sum(), p[:, i].sum() / steps))
 
 
 if __name__ == "__main__":
