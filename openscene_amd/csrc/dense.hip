@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void dense_kernel(const float* __restrict__
                             af[pl] = *reinterpret_cast<const bf16x8*>(&stage[pl][16 * rb + (lane & 15)][ks * 32 + akq]);
 #define DN_MFMA(AP, BP)                                                                                         \
     _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                                            \
-        acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[AP], B[ks][nb][BP], acc[rb][nb], 0, 0, 0);
+        acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ks][nb][BP], af[AP], acc[rb][nb], 0, 0, 0);
                         DN_MFMA(2, 0) DN_MFMA(1, 1) DN_MFMA(0, 2) DN_MFMA(1, 0) DN_MFMA(0, 1) DN_MFMA(0, 0)
 #undef DN_MFMA
                     }
@@ -129,20 +129,23 @@ __global__ __launch_bounds__(256, 2) void dense_kernel(const float* __restrict__
             }
             if (!single && s0 + KS < ns) __syncthreads();   // every wave is done reading the stage before the next chunk lands
         }
-        // ---- accumulators -> output rows: C row = 4 (lane >> 4) + r, col = lane & 15 of each 16 x 16 block
+        // ---- accumulators -> output rows.  The weight fragment is the MFMA's FIRST operand (the staged rows the second), so a
+        // block comes out transposed: lane l holds columns 4 (l >> 4) .. + 3 of row l & 15 -- one 16-byte store per block
+        if (wave_on) {
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = r0 + 16 * rb + 4 * (lane >> 4) + r;
+            for (int rb = 0; rb < 4; ++rb) {
+                const int64_t row = r0 + 16 * rb + (lane & 15);
                 if (row < n) {
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
-                        const int col = cg * 128 + 32 * wave + 16 * nb + (lane & 15);
-                        if (col < cout) out[row * cout + col] = acc[rb][nb][r];
+                        const int col = cg * 128 + 32 * wave + 16 * nb + 4 * (lane >> 4);
+                        if (col < cout)          // (cout % 4 == 0: a quad is inside or outside as a whole)
+                            *reinterpret_cast<float4*>(out + row * cout + col) =
+                                make_float4(acc[rb][nb][0], acc[rb][nb][1], acc[rb][nb][2], acc[rb][nb][3]);
                     }
                 }
             }
+        }
     }
 }
 

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                         // order is still smallest terms first: a3b1, a2b2, a1b3, a2b1, a1b2, a1b1
 #define TL_MFMA(H0, H1, AP, BP)                                                                             \
     _Pragma("unroll") for (int h = H0; h < H1; ++h) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)          \
-        acc[h][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[h][AP], B[ks][nb][BP], acc[h][nb], 0, 0, 0);
+        acc[h][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ks][nb][BP], af[h][AP], acc[h][nb], 0, 0, 0);
                         if (half1) {
                             TL_MFMA(0, 2, 2, 0)
                             TL_MFMA(0, 2, 1, 1)
@@ -397,31 +397,31 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                     asm volatile("" ::"v"(sink));
                 }
                 TL_TICK(5)                                 // 5: B-load wait + fragment reads + MFMAs
-                // ---- add the result blocks into the output tile: C row = 4 (lane >> 4) + r, col = lane & 15
-                // (all reads first, then all writes: the 16 cells of a lane are distinct -- one output row per pair
-                // within an offset -- but the compiler cannot know, and a read-add-write chain per cell would
-                // serialise 16 LDS round trips)
-                const int pbase = __builtin_amdgcn_readfirstlane(lstart[it.a]) + 32 * it.g + 4 * (lane >> 4);
+                // ---- add the result blocks into the output tile.  The MFMAs above take the WEIGHT fragment as their first
+                // operand and the staged rows as the second (same registers either way round: both fragment layouts are
+                // [16 rows or columns][8 k per lane group]), i.e. they produce the block TRANSPOSED: lane l holds columns
+                // 4 (l >> 4) .. + 3 of pair l & 15 -- four CONSECUTIVE floats of one output row, one 16-byte LDS access instead
+                // of four 4-byte ones (round 3: the tile update was 13 % of a step).  All reads first, then all writes: a lane's
+                // cells are distinct -- one output row per pair within an offset -- but the compiler cannot know, and a
+                // read-add-write chain per cell would serialise the LDS round trips.
+                const int pbase = __builtin_amdgcn_readfirstlane(lstart[it.a]) + 32 * it.g + (lane & 15);
                 auto update = [&](auto nh) {                // nh halves: all reads, then all writes
                     constexpr int NH = decltype(nh)::value;
-                    int orow[NH][4];
+                    int ocell[NH];
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) ocell[h] = int(plist[pbase + 16 * h] >> 24) * S + 32 * wave + 4 * (lane >> 4);
+                    float4 cur[NH][2];
 #pragma unroll
                     for (int h = 0; h < NH; ++h)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) orow[h][r] = int(plist[pbase + 16 * h + r] >> 24) * S + 32 * wave + (lane & 15);
-                    float cur[NH][2][4];
-#pragma unroll
-                    for (int h = 0; h < NH; ++h)
-#pragma unroll
-                        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) cur[h][nb][r] = otile[orow[h][r] + 16 * nb];
+                        for (int nb = 0; nb < 2; ++nb) cur[h][nb] = *reinterpret_cast<const float4*>(&otile[ocell[h] + 16 * nb]);
 #pragma unroll
                     for (int h = 0; h < NH; ++h)
 #pragma unroll
                         for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) otile[orow[h][r] + 16 * nb] = cur[h][nb][r] + acc[h][nb][r];
+                            *reinterpret_cast<float4*>(&otile[ocell[h] + 16 * nb]) =
+                                make_float4(cur[h][nb].x + acc[h][nb][0], cur[h][nb].y + acc[h][nb][1], cur[h][nb].z + acc[h][nb][2],
+                                            cur[h][nb].w + acc[h][nb][3]);
                 };
                 if (half1) update(std::integral_constant<int, 2>{});
                 else update(std::integral_constant<int, 1>{});

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void spconv_ws_kernel(const float* __restrict_
                             // smallest terms first per accumulator, consecutive MFMAs on different accumulators
 #define WS_MFMA(H1, AP, BP)                                                                                   \
     _Pragma("unroll") for (int h = 0; h < H1; ++h) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)           \
-        acc[g][h][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[h][AP], B[ks][nb][BP], acc[g][h][nb], 0, 0, 0);
+        acc[g][h][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ks][nb][BP], af[h][AP], acc[g][h][nb], 0, 0, 0);
                             if (half1) {
                                 WS_MFMA(2, 2, 0) WS_MFMA(2, 1, 1) WS_MFMA(2, 0, 2) WS_MFMA(2, 1, 0) WS_MFMA(2, 0, 1) WS_MFMA(2, 0, 0)
                             } else {
@@ -169,26 +169,26 @@ __global__ __launch_bounds__(256) void spconv_ws_kernel(const float* __restrict_
         }
     }
     if (wave >= NW) return;
-    // ---- result rows -> partial[k][dst]: C row = 4 (lane >> 4) + r, col = lane & 15 of each 16 x 16 block
+    // ---- result rows -> partial[k][dst].  The weight fragment is the MFMA's FIRST operand (the staged rows the second), so a
+    // block comes out transposed: lane l holds columns 4 (l >> 4) .. + 3 of pair l & 15 -- one 16-byte store per block
 #pragma unroll
     for (int g = 0; g < WS_NG; ++g) {
         if (g < nsteps) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h) {
+                const int d = didx[32 * g + 16 * h + (lane & 15)];
+                if (d >= 0) {
+                    // direct: every destination row has exactly one pair in the whole map -- `partial` IS the output
+                    float* row = partial + ((direct ? int64_t(0) : int64_t(k) * n_dst) + d) * cout;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int lp = 32 * g + 16 * h + 4 * (lane >> 4) + r;
-                    const int d = didx[lp];
-                    if (d >= 0) {
-                        // direct: every destination row has exactly one pair in the whole map -- `partial` IS the output
-                        float* row = partial + ((direct ? int64_t(0) : int64_t(k) * n_dst) + d) * cout;
-#pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) {
-                            const int col = col0 + 32 * wave + 16 * nb + (lane & 15);
-                            if (col < cout) row[col] = acc[g][h][nb][r];
-                        }
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const int col = col0 + 32 * wave + 16 * nb + 4 * (lane >> 4);
+                        if (col < cout)
+                            *reinterpret_cast<float4*>(row + col) =
+                                make_float4(acc[g][h][nb][0], acc[g][h][nb][1], acc[g][h][nb][2], acc[g][h][nb][3]);
                     }
                 }
+            }
         }
     }
 }
