@@ -368,3 +368,45 @@ def test_conv_adversarial_operands(kind, mode, monkeypatch):
     # the weight gradient contracts over up to ~1e5 pairs in several partial sums: fp32 accumulation error grows
     # with the number of terms (sqrt-like for random signs); 2e-5 of the abs-sum covers the 100 k-term reductions
     within(wg.grad, w64.grad, b_gw, "weight gradient", 2e-5)
+
+
+@pytest.mark.parametrize("cin,cout", [(96, 768), (768, 96), (128, 96)])
+@pytest.mark.parametrize("kind", ["row_scales", "cancellation", "gradient_sized", "wide_elements"])
+def test_dense_1x1_adversarial_operands(kind, cin, cout):
+    """The 1x1-convolution kernel (csrc/dense.hip: head, shortcuts, their input gradients) on the same adversarial operands
+    and at the same bound as the gather kernels: every element within 2e-6 of sum_k |a_k| |b_k| of the float64 value."""
+    from openscene_amd import functional as F_
+    n = 20000
+    g = torch.Generator().manual_seed(23 + cin)
+    feats = _adversarial(kind, n, cin, g)
+    w = torch.randn(cin, cout, generator=g) / np.sqrt(cin)
+    if kind == "cancellation":
+        w[1::2, :] = w[0::2, :]
+    gout = _adversarial(kind if kind != "cancellation" else "row_scales", n, cout, g)
+    f64 = feats.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    ref = f64 @ w64
+    ref.backward(gout.double())
+    b_out = feats.double().abs() @ w.double().abs()
+    b_gin = gout.double().abs() @ w.double().abs().t()
+    d = dev()
+    fg = feats.to(d).requires_grad_(True)
+    wg = w.to(d).requires_grad_(True)
+    rec = _KindRecorder()
+    from openscene_amd import ops
+    ops.set_profiler(rec)
+    try:
+        out = F_.sparse_conv(fg, wg, (None, None, False), n)
+        out.backward(gout.to(d))
+    finally:
+        ops.set_profiler(None)
+    assert rec.kinds.count("dense_fwd") == 2, rec.kinds          # forward and input gradient
+
+    def within(got, want, bound, what):
+        err = (got.detach().double().cpu() - want.detach()).abs()
+        lim = 2e-6 * bound + 6e-8 * want.detach().abs() + 1e-37
+        bad = err > lim
+        assert not bool(bad.any()), "%s %s: %d elements beyond the bound, worst ratio %.2f" % (
+            kind, what, int(bad.sum()), float((err / lim).max()))
+    within(out, ref, b_out, "forward")
+    within(fg.grad, f64.grad, b_gin, "input gradient")
