@@ -1,0 +1,109 @@
+"""Host logic of openscene_amd.optim.FlatAdam on the CPU: the kernel behind osn_adam_step is replaced by a numpy restatement
+of its update rule (float32, operating on the pointers the wrapper passes), everything else is the product code -- parameter
+flattening, the executor-ordered layout, in-place use of a flat gradient buffer against the gathered fallback, version
+counters, torch.optim.Adam's checkpoint layout."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+
+class _FakeLib:
+    """osn_adam_step in numpy, same argument list as include/openscene_amd.h."""
+
+    def __init__(self):
+        self.calls = 0
+
+    @staticmethod
+    def _arr(ptr, n):
+        return np.ctypeslib.as_array((ctypes.c_float * n).from_address(ptr))
+
+    def osn_adam_step(self, p, g, m, v, n, step, lr, b1, b2, eps, wd, stream):
+        self.calls += 1
+        p, g, m, v = (self._arr(x, n) for x in (p, g, m, v))
+        f = np.float32
+        grad = g + f(wd) * p if wd else g.copy()
+        m += (f(1) - f(b1)) * (grad - m)
+        v[:] = f(b2) * v + (f(1) - f(b2)) * grad * grad
+        bc1 = 1.0 - float(b1) ** step
+        bc2 = 1.0 - float(b2) ** step
+        denom = np.sqrt(v) / f(np.sqrt(bc2)) + f(eps)
+        p -= f(lr / bc1) * m / denom
+        return 0
+
+
+@pytest.fixture()
+def fake_adam(monkeypatch):
+    from openscene_amd import ops
+    lib = _FakeLib()
+    monkeypatch.setattr(ops, "_prep", lambda dev: lib)
+    monkeypatch.setattr(ops, "_stream", lambda dev: None)
+
+    class NoDev:
+        def __init__(self, dev):
+            pass
+
+        def __enter__(self):
+            pass
+
+        def __exit__(self, *a):
+            pass
+    monkeypatch.setattr(ops, "_Dev", NoDev)
+    return lib
+
+
+@pytest.mark.parametrize("flat_grads", [False, True])
+def test_flat_adam_layout_versions_and_checkpoints(fake_adam, flat_grads):
+    from openscene_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(1)
+    shapes = [(8, 4, 4), (6,), (3, 5), (1,)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    ref_p = [torch.nn.Parameter(t.clone()) for t in init]
+    our_p = [torch.nn.Parameter(t.clone()) for t in init]
+    ref = torch.optim.Adam(ref_p, lr=2e-3, betas=(0.9, 0.98), weight_decay=0.01)
+    ours = FlatAdam(our_p, lr=2e-3, betas=(0.9, 0.98), weight_decay=0.01)
+    assert ours.offsets == [0, 128, 136, 152] and ours.total == 156          # every slice starts on a 16-byte boundary
+    assert all(p.data_ptr() == ours.flat.data_ptr() + 4 * o for p, o in zip(our_p, ours.offsets))
+    assert all(torch.equal(a.detach(), b.detach()) for a, b in zip(ref_p, our_p))
+    for step in range(4):
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        flat = torch.zeros(ours.total)
+        for p, q, gr, o in zip(ref_p, our_p, grads, ours.offsets):
+            p.grad = gr.clone()
+            q.grad = flat[o:o + gr.numel()].view(gr.shape).copy_(gr) if flat_grads else gr.clone()
+        got, in_place = ours._flat_grads()
+        assert in_place == flat_grads and (got.data_ptr() == flat.data_ptr()) == flat_grads
+        before = [q._version for q in our_p]
+        ref.step()
+        ours.step()
+        assert all(q._version > b for q, b in zip(our_p, before))
+        for p, q in zip(ref_p, our_p):
+            assert torch.allclose(q.detach(), p.detach(), rtol=1e-5, atol=1e-6)
+    assert fake_adam.calls == 4
+    # a parameter without a gradient contributes zeros through the gathered path
+    our_p[1].grad = None
+    assert ours._flat_grads()[1] is False
+    sd = ours.state_dict()
+    ref_sd = ref.state_dict()
+    assert set(sd["state"]) == set(ref_sd["state"]) and sd["param_groups"][0]["lr"] == 2e-3
+    for i in range(len(shapes)):
+        assert torch.allclose(sd["state"][i]["exp_avg"], ref_sd["state"][i]["exp_avg"], rtol=1e-5, atol=1e-6)
+        assert sd["state"][i]["exp_avg"].shape == torch.Size(shapes[i])
+    again = FlatAdam([torch.nn.Parameter(t.clone()) for t in init], lr=1.0)
+    again.load_state_dict(ref_sd)
+    assert again.steps == 4 and again.param_groups[0]["betas"] == (0.9, 0.98)
+
+
+def test_flat_adam_adopts_the_executor_order_for_a_model(fake_adam):
+    """Given a module, the optimizer lays its buffer out in the order of the network executor's gradient buffer (convolution
+    kernels first, then the batch-norm pairs), so that the executor's gradients can be read in place."""
+    from openscene_amd import executor as E
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.optim import FlatAdam
+    model = mink_unet(3, 20, 3, "MinkUNet14A")
+    ex = E.for_model(model)
+    opt = FlatAdam(model, lr=1e-3)
+    assert [id(p) for p in opt._params] == [id(p) for p in ex.program.params]
+    assert opt.offsets == ex.grad_off and opt.total == ex.grad_total
+    assert len(opt._params) == len(list(model.parameters()))
