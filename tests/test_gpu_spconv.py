@@ -69,6 +69,7 @@ CASES = [
     ("small", (1, 1, 1), 128, 256),
     ("small", (2, 1, 2), 256, 128),
     ("small", (4, 4, 3), 256, 256),
+    ("small", (1, 1, 5), 32, 64),    # 125 offsets on an MFMA kernel (the generic offset loops of the list / reduce kernels)
 ]
 
 
