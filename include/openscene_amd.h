@@ -423,6 +423,11 @@ int osn_cosine_query(const float* X, const int64_t* gather, const void* text_f16
  * Each source has its own (nullable) gather: the reference gathers the distilled
  * voxel features with inds_reverse while the fused features are already per point.
  * sel (nullable) uint8 [n] = 1 where the fusion feature was selected.            */
+/* labels[p] = argmax over the first c columns of row (gather ? gather[p] : p) of a float32 score matrix with row stride ld
+ * (first maximum wins): `torch.max(pred, 1)[1]` of run/evaluate.py:292 fused with the point -> voxel gather `[inds_reverse]`,
+ * for scores that exist per VOXEL (the fused-head query).  Indices outside [0, n_rows) read row 0.  */
+int osn_rows_argmax(const float* scores, int64_t ld, int c, const int64_t* gather, int64_t n_pts, int64_t n_rows,
+                    int64_t* labels, osn_stream_t stream);
 size_t osn_query_ensemble_ws_bytes(int64_t n);
 int osn_query_ensemble(const float* X_distill, const int64_t* gather_distill,
                        const float* X_fusion, const int64_t* gather_fusion,

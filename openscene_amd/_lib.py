@@ -61,6 +61,7 @@ PROTOTYPES = {
     "osn_stem_conv_wgrad_ws_bytes": (_sz, [_i32, _i32]),
     "osn_stem_conv_wgrad": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "osn_dense_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "osn_rows_argmax": (_i32, [_vp, _i64, _i32, _vp, _i64, _i64, _vp, _vp]),
     "osn_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _vp]),
     "osn_spconv_fwd_ws_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "osn_spconv_fwd_ws": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),

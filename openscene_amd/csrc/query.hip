@@ -239,6 +239,32 @@ __global__ void ensemble_select_kernel(const float* __restrict__ max_d, const fl
     if (p < n) sel[p] = max_d[p] < max_f[p] ? 1 : 0;
 }
 
+// labels[p] = argmax_c scores[g ? g[p] : p][0 .. c)   (first maximum wins, as torch.max / torch.argmax): one wave per point,
+// lanes over the row's columns (coalesced), butterfly reduction on (value, column)
+__global__ __launch_bounds__(256) void rows_argmax_kernel(const float* __restrict__ scores, int64_t ld, int c,
+                                                          const int64_t* __restrict__ g, int64_t n_pts, int64_t n_rows,
+                                                          int64_t* __restrict__ labels) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (p >= n_pts) return;
+    int64_t r = g ? g[p] : p;
+    if (r < 0 || r >= n_rows) r = 0;                          // (the wrapper validates the range of a gather index it is given)
+    const float* row = scores + r * ld;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int col = lane; col < c; col += 64) {
+        const float v = row[col];
+        if (v > bv || (v == bv && col < bi) || bi == 0x7fffffff) { bv = v; bi = col; }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const float ov = __shfl_xor(bv, m, 64);
+        const int oi = __shfl_xor(bi, m, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) labels[p] = bi == 0x7fffffff ? 0 : bi;
+}
+
 static int launch_query(hipStream_t st, const float* X0, const int64_t* g0, const float* X1, const int64_t* g1,
                         const uint8_t* sel, const float* rowdiv, const _Float16* T, _Float16* scores, int64_t* argmax,
                         float* rowmax, int64_t n, int d, int c) {
@@ -271,6 +297,18 @@ extern "C" int osn_cosine_query(const float* X, const int64_t* gather, const voi
     OSN_REQUIRE(aligned16(X) && aligned16(text_f16), OSN_E_ARG, "osn_cosine_query: X and text must be 16-byte aligned");
     return launch_query(st, X, gather, nullptr, nullptr, nullptr, nullptr, static_cast<const _Float16*>(text_f16),
                         static_cast<_Float16*>(scores_f16), argmax, nullptr, n, d, c);
+}
+
+extern "C" int osn_rows_argmax(const float* scores, int64_t ld, int c, const int64_t* gather, int64_t n_pts, int64_t n_rows,
+                               int64_t* labels, osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n_pts >= 0 && n_rows >= 1 && c >= 1 && ld >= c, OSN_E_ARG, "osn_rows_argmax: n_pts=%lld n_rows=%lld c=%d ld=%lld",
+                (long long)n_pts, (long long)n_rows, c, (long long)ld);
+    if (n_pts == 0) return OSN_OK;
+    OSN_REQUIRE(scores && labels, OSN_E_ARG, "osn_rows_argmax: null pointer");
+    hipLaunchKernelGGL(rows_argmax_kernel, dim3(unsigned(cdiv(n_pts, 4))), dim3(256), 0, st, scores, ld, c, gather, n_pts, n_rows, labels);
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
 }
 
 extern "C" size_t osn_query_ensemble_ws_bytes(int64_t n) {

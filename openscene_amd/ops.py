@@ -731,6 +731,26 @@ def spconv_wgrad_tl(feats, gout, tl, K, swap=False):
     return gw
 
 
+def rows_argmax(scores, gather=None):
+    """int64 labels [len(gather) or N] = argmax over the columns of float32 `scores` [N, c] (a column slice of a wider
+    contiguous matrix is fine), row gather[p] for point p: argmax + point -> voxel gather in one launch."""
+    dev = scores.device
+    lib = _prep(dev)
+    if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1:
+        raise ValueError("scores must be a float32 matrix with unit column stride")
+    n, c = scores.shape
+    ld = scores.stride(0) if n > 1 else max(c, scores.stride(0))
+    if gather is not None:
+        if gather.dtype != torch.int64 or gather.device != dev:
+            raise ValueError("gather must be an int64 vector on the scores' device")
+        gather = gather.contiguous()
+    n_pts = n if gather is None else gather.shape[0]
+    labels = torch.empty(n_pts, dtype=torch.int64, device=dev)
+    with _Dev(dev):
+        check(lib.osn_rows_argmax(_p(scores), ld, c, _p(gather), n_pts, n, _p(labels), _stream(dev)), "osn_rows_argmax")
+    return labels
+
+
 def dense_eligible(cin, cout):
     """Shapes the 1x1-convolution kernel takes (everything of the U-Net family; odd widths stay on the generic kernel)."""
     return cin % 4 == 0 and cin >= 8 and cout % 4 == 0

@@ -53,9 +53,7 @@ def query_distill_fused(features, final_kernel, text_features, inds_reverse=None
     agree wherever the reference's top-2 margin exceeds twice that.  Returns int64 labels [N_pts] (and float32 scores
     [N_vox, n_labels] per VOXEL if return_scores)."""
     scores = _rows_times(features, head_times_text(final_kernel, text_features))
-    labels = scores.argmax(1)
-    if inds_reverse is not None:
-        labels = labels[inds_reverse]
+    labels = ops.rows_argmax(scores, inds_reverse)          # argmax + point -> voxel gather, one launch
     return (labels, scores) if return_scores else labels
 
 

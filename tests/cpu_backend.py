@@ -264,6 +264,11 @@ def stem_conv_fwd(feats, weight, nbr, n_out):
     return spconv_fwd(feats, weight, nbr, n_out)
 
 
+def rows_argmax(scores, gather=None):
+    labels = scores.argmax(1)
+    return labels if gather is None else labels[gather]
+
+
 def dense_eligible(cin, cout):
     return cin % 4 == 0 and cin >= 8 and cout % 4 == 0
 
@@ -434,7 +439,7 @@ def cat2_bwd(gout, ca, cb):
     return gout[:, :ca].contiguous(), gout[:, ca:ca + cb].contiguous()
 
 
-_NAMES = ["relu_fwd", "relu_bwd", "add", "cat2", "cat2_bwd", "fusion_project", "fusion_accumulate", "fusion_finish", "weight_image", "stem_eligible", "stem_conv_fwd", "stem_conv_wgrad", "dense_eligible", "dense_fwd", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "spconv_fwd_ws", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "coords_pyramid", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
+_NAMES = ["relu_fwd", "relu_bwd", "add", "cat2", "cat2_bwd", "fusion_project", "fusion_accumulate", "fusion_finish", "weight_image", "stem_eligible", "stem_conv_fwd", "stem_conv_wgrad", "dense_eligible", "dense_fwd", "rows_argmax", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "spconv_fwd_ws", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "coords_pyramid", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
           "spconv_wgrad", "bn_stats", "bn_forward_train", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
           "fnv_hash", "ravel_hash", "feature_remap", "batch_coords"]
 

@@ -190,6 +190,26 @@ def _query_inputs(n_vox, n_pts, d, c, seed):
     return x, t, gather
 
 
+@pytest.mark.parametrize("n,c,n_pts", [(5000, 20, 12000), (300, 160, 0), (1, 21, 7), (4000, 3, 4000)])
+def test_rows_argmax_with_gather_equals_torch(n, c, n_pts):
+    """ops.rows_argmax = torch's argmax (first maximum) + the point -> voxel gather of run/evaluate.py:290-292, on a column
+    slice of a wider matrix (the fused-head scores are padded to a multiple of four columns), ties and -inf rows included."""
+    from openscene_amd import ops
+    dv = dev()
+    g = torch.Generator().manual_seed(n + c)
+    wide = torch.randn(n, c + 3, generator=g)
+    wide[::7, : c] = wide[::7, : c].round()                 # ties
+    if n > 10:
+        wide[3, :c] = float("-inf")
+        wide[5, :c] = 1.25                                   # a constant row: label 0
+    scores = wide.to(dv)[:, :c]
+    inds = torch.randint(0, n, (n_pts,), generator=g).to(dv) if n_pts else None
+    got = ops.rows_argmax(scores, inds)
+    want = scores.argmax(1)
+    want = want if inds is None else want[inds]
+    assert got.dtype == torch.int64 and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("flat_grads", [False, True])
 @pytest.mark.parametrize("weight_decay", [0.0, 0.01])
 def test_flat_adam_equals_torch_adam(flat_grads, weight_decay):
