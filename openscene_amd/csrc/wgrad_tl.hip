@@ -19,6 +19,7 @@
 //   * 4 waves as 2 x 2 over the (input channel, output channel) block, MB x NB accumulator blocks of 16 x 16
 //     per wave, six MFMAs per block and step (a3g1 + a2g2 + a1g3 + a2g1 + a1g2 + a1g1, fp32 accumulate).
 #include "common.h"
+#include <cstdlib>
 #include "pairlist.h"
 
 namespace osn {
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(const int32_t* __restric
 // Work items: every offset's pairs cut into ranges of `quota` pairs (quota: whole 32-pair steps, at least
 // PL_MIN_QUOTA, such that at most PL_ITEMS items exist).  One workgroup.
 __global__ __launch_bounds__(256) void pair_plan_kernel(const int32_t* __restrict__ total, int K, int4* __restrict__ items,
-                                                        int2* __restrict__ range) {
+                                                        int2* __restrict__ range, int items_max) {
     __shared__ int nk[PL_KMAX];
     __shared__ int start[PL_KMAX + 1];
     __shared__ int quota_s;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void pair_plan_kernel(const int32_t* __restric
     if (tid == 0) {
         long long P = 0;
         for (int k = 0; k < K; ++k) P += total[k];
-        long long q = (P + (PL_ITEMS - K) - 1) / (PL_ITEMS - K);
+        long long q = (P + (items_max - K) - 1) / (items_max - K);
         q = (q + 31) / 32 * 32;
         if (q < PL_MIN_QUOTA) q = PL_MIN_QUOTA;
         quota_s = int(q);
@@ -404,7 +405,11 @@ extern "C" int osn_pair_lists_build(const void* tl, const int32_t* out_rows, int
     const int32_t* cnt = static_cast<const int32_t*>(tl);
     const int2* lst = reinterpret_cast<const int2*>(static_cast<const char*>(tl) + align_up(size_t(nt) * K * 4, 256));
     hipLaunchKernelGGL(pair_prefix_kernel, dim3(K), dim3(256), 0, st, cnt, int(nt), K, v.pref, v.total);
-    hipLaunchKernelGGL(pair_plan_kernel, dim3(1), dim3(256), 0, st, v.total, K, v.items, v.range);
+    // items per map: PL_ITEMS (one round of two workgroups per CU); OSN_PL_ITEMS lowers it (fewer, longer items: less
+    // partial-sum traffic for the reduction, less parallelism for the kernel; measured per step: 256 +0.13 ms, 384 equal)
+    static const int items_env = [] { const char* e = getenv("OSN_PL_ITEMS"); return e ? atoi(e) : 0; }();
+    const int items_max = (items_env > K + 32 && items_env <= PL_ITEMS) ? items_env : PL_ITEMS;
+    hipLaunchKernelGGL(pair_plan_kernel, dim3(1), dim3(256), 0, st, v.total, K, v.items, v.range, items_max);
     hipLaunchKernelGGL(pair_fill_kernel, dim3(unsigned(nt)), dim3(256), 0, st, cnt, lst, out_rows, v.pref, v.total, int(nt), K,
                        bm, v.pin, v.pout, v.poff);
     OSN_LAUNCH_CHECK();
