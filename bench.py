@@ -22,14 +22,12 @@ import os
 import sys
 import time
 
-# (before the HIP runtime initialises; openscene_amd sets the same default on import, see openscene_amd/__init__.py)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
-
 import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+HW_QUEUES = None               # GPU_MAX_HW_QUEUES in force (main() sets it before the first device call; OSN_HW_QUEUES overrides)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3       # f32 MFMA / vector peak, same guide
@@ -460,6 +458,129 @@ def cpu_baseline(seed, arch, out_dim):
                         "what": "numpy restatement of dataset/voxelizer.py:97-140 + sparse_quantize (oracle/voxelize.py)"}
     return res
 
+METRIC = "active voxels/sec MinkUNet18A fwd+bwd @2cm ScanNet; per-point query ms"
+MAX_LINE_BYTES = 6000          # the driver keeps ~8 KB of stdout tail: the headline must fit with room to spare
+
+
+def write_detail(detail, path=None):
+    """Everything the run measured (per-stage launch table, per-kernel survey, every side phase with its prose) goes to a
+    side file; only the short headline goes to stdout (the driver parses the LAST stdout line out of an ~8 KB tail)."""
+    paths = [path] if path else [os.path.join(ROOT, "bench_detail.json")]
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if not path and os.path.isdir(out_dir):
+        paths.append(os.path.join(out_dir, "bench_detail.json"))
+    written = None
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(detail, f, indent=1)
+            written = written or p
+        except OSError:
+            pass
+    return written
+
+
+def _num(x, nd=4):
+    if isinstance(x, float):
+        return float("%.*g" % (nd + 2, x))
+    return x
+
+
+def headline(detail, detail_path=None):
+    """The ONE stdout line of the contract: numbers only, no prose beyond the workload name; < MAX_LINE_BYTES."""
+    cfg = detail["config"]
+    line = {k: detail[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                   "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg[k] for k in ("workload", "arch", "feature_dim", "voxels_rank0", "parallelism",
+                                          "step_algorithmic_GB", "step_GFLOP") if k in cfg}
+    rf = detail.get("roofline")
+    if rf:
+        keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "shape", "avg_launch_us", "launches_per_step",
+                "bytes_per_launch", "flops_per_launch", "hbm_frac", "mfma_frac", "step_hbm_frac", "step_mfma_frac", "evidence")
+        line["roofline"] = {k: _num(rf[k]) for k in keep if k in rf}
+    else:
+        line["roofline"] = None
+    cb = detail.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: _num(cb.get(k)) for k in ("value", "unit", "cores", "kind")}
+        line["cpu_baseline"]["sample"] = str(cb.get("sample"))[:240]
+    else:
+        line["cpu_baseline"] = None
+    q = detail.get("query")
+    if q:
+        line["query"] = {"ms": _num(q["ms"]), "n_points": q["n_points"], "dim": q["dim"], "labels": q["labels"],
+                         "hbm_frac": _num(q["hbm_frac"])}
+        for k in ("matterport160", "q1m_labels", "q1m_scores"):
+            if k in q:
+                line["query"][k] = {"ms": _num(q[k]["ms"]), "hbm_frac": _num(q[k]["hbm_frac"])}
+    if detail.get("voxelizer"):
+        line["voxelizer_ms"] = _num(detail["voxelizer"]["ms"])
+    ph = detail.get("phases")
+    if ph:
+        line["phases_ms"] = {k: _num(v.get("ms", v.get("project_ms"))) for k, v in ph.items() if isinstance(v, dict)}
+    cm = detail.get("comm")
+    if cm:
+        line["comm"] = {k: _num(cm[k]) for k in ("backend", "ranks", "allreduce_MB", "allreduce_ms_standalone",
+                                                 "share_of_step_if_exposed", "ms_per_step_by_rank", "hw_queues") if k in cm}
+    line["loss"] = detail.get("loss")
+    line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+    s = json.dumps(line, separators=(",", ":"))
+    for drop in ("phases_ms", "comm", "query", "voxelizer_ms"):         # never let the line outgrow the driver's tail
+        if len(s) <= MAX_LINE_BYTES:
+            break
+        line.pop(drop, None)
+        s = json.dumps(line, separators=(",", ":"))
+    return line
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_command(n, argv, port=None):
+    """`python bench.py --gpus N ...` without a launcher: the command this process replaces itself with -- one rank per GPU
+    under torch.distributed.run, exactly the line the driver uses for N > 1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port or _free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def self_spawn(n):
+    cmd = spawn_command(n, sys.argv[1:])
+    print("[bench] --gpus %d without a launcher: re-executing under torch.distributed.run" % n, file=sys.stderr, flush=True)
+    os.execv(cmd[0], cmd)
+
+
+def spawn_self_test(rank, world, args):
+    """CPU check of the N > 1 harness (tests/test_bench_line.py): gloo group, barrier-bracketed timing, MAX over ranks, rank 0
+    prints ONE schema-complete line.  No GPU, no model: the step is a fixed amount of host arithmetic."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    n_units = 1000 + rank
+    dist.barrier()
+    t0 = time.perf_counter()
+    acc = torch.zeros(64, 64)
+    for _ in range(args.steps):
+        acc = acc + torch.ones(64, 64) @ torch.ones(64, 64)
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt, float(n_units)], dtype=torch.float64)
+    tmax, tsum = tt.clone(), tt.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        detail = {"metric": METRIC, "value": float(tsum[1]) * args.steps / float(tmax[0]), "unit": "voxels/s", "n_gpus": world,
+                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(tmax[0]) * 1e3 / args.steps,
+                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                  "config": {"workload": "spawn self-test (no GPU work)", "parallelism": "dp%d" % world},
+                  "roofline": None, "cpu_baseline": None, "loss": float(acc.sum())}
+        print(json.dumps(headline(detail, None), separators=(",", ":")))
+    dist.destroy_process_group()
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -493,6 +614,9 @@ def main():
     ap.add_argument("--train-only", action="store_true", help="skip the query / inference / voxeliser / loader phases "
                     "(for rocprofv3 runs: every traced kernel then belongs to the training steps)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--spawn-self-test", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--detail", default=None, help="where the full record goes (default: bench_detail.json next to bench.py, "
+                    "and gpurun_out/ when present); stdout carries only the < 6 KB headline line")
     args = ap.parse_args()
     global LOSS_HIP
     LOSS_HIP = not args.torch_loss
@@ -504,10 +628,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the application's choice, made before the HIP runtime starts and reported in `comm` (the library does not touch it)
+    global HW_QUEUES
+    import openscene_amd
+    HW_QUEUES = openscene_amd.configure_hw_queues(log=(rank == 0 and not args.spawn_self_test))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # called the way N = 1 is called: start the ranks ourselves (the reference spawns its own, run/distill.py:113-116)
+            self_spawn(args.gpus)
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if args.spawn_self_test:
+        return spawn_self_test(rank, world, args)
     if os.environ.get("OSN_BENCH_ONE_DEVICE") == "1":
         local_rank = 0              # functional test of the N > 1 control flow on a 1-GPU box (with OSN_DIST_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
@@ -1014,7 +1145,7 @@ def main():
                             "openscene_amd.distributed.FlatGradAllReduce (one collective after backward)",
                 "allreduce_MB": flat.numel() * 4 / 1e6,
                 "allreduce_ms_standalone": ar_ms, "share_of_step_if_exposed": ar_ms / (dt_max * 1e3 / args.steps),
-                "ms_per_step_by_rank": per_rank_ms,
+                "ms_per_step_by_rank": per_rank_ms, "hw_queues": HW_QUEUES if HW_QUEUES is not None else "default",
                 "note": "the all-reduce runs after the backward pass, not overlapped: its stand-alone time is the exposed share"}
 
     if rank != 0:
@@ -1097,8 +1228,8 @@ def main():
 
     from openscene_amd import functional as _F
     conv_dtype = "f32 (bf16x6 split-precision MFMA, fp32 accumulate)" if _F.CONV_MODE in ("bf16x6", "tl") else "f32"
-    line = {
-        "metric": "active voxels/sec MinkUNet18A fwd+bwd @2cm ScanNet; per-point query ms",
+    detail = {
+        "metric": METRIC,
         "value": vox_total * args.steps / dt_max, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": conv_dtype, "data": "synthetic",
@@ -1118,7 +1249,9 @@ def main():
                            "coordinate pyramid (+ mask rows) of step i+1 queued on a side stream during step i; kernel maps inside the step"
                            if prefetch else "pyramid and maps inside the step"),
     }
-    print(json.dumps(line))
+    detail_path = write_detail(detail, args.detail)
+    line = headline(detail, detail_path)
+    print(json.dumps(line, separators=(",", ":")))
     if dist_on:
         dist.destroy_process_group()
 

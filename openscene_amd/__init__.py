@@ -20,18 +20,53 @@ import types
 
 __version__ = "0.1.0"
 
-# HIP maps streams to at most this many hardware queues per process (read once, when the runtime initialises).  The training
-# step uses three streams (main, weight gradients, next batch's maps); a fourth ACTIVE hardware queue -- RCCL's stream in a
-# multi-GPU run -- slows every launch on this part: 13.4 ms per step against 10.1 ms with the cap at 3 (and 20 ms with 8),
-# measured with a one-rank RCCL group (profiles/r03_s12_hw_queues.txt).  Streams beyond the cap share a queue.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
+HW_QUEUES_TUNED = 3
 
 
-def install_minkowski_alias(force=False):
+def configure_hw_queues(n=HW_QUEUES_TUNED, log=True):
+    """Cap the HIP hardware queues of THIS PROCESS (``GPU_MAX_HW_QUEUES``; read once, when the HIP runtime initialises -- call
+    this before the first device call).  Opt-in: importing openscene_amd no longer touches the environment (it used to).
+
+    Why 3: the training step runs on three streams (main, weight gradients, next batch's maps); a fourth ACTIVE hardware
+    queue -- RCCL's stream in a multi-GPU run -- slowed every launch on this part: 13.4 ms per step against 10.1 ms with the
+    cap at 3 and 20 ms with 8, measured with a ONE-rank RCCL group (profiles/r03_s12_hw_queues.txt).  Streams beyond the cap
+    share a queue.  Its effect on an 8-rank all-reduce is unmeasured; `OSN_HW_QUEUES=default` (or any number) overrides.
+    -> the value in force (None = the runtime's default)."""
+    want = os.environ.get("OSN_HW_QUEUES")
+    if want is not None:
+        n = None if want.strip().lower() in ("default", "", "0") else int(want)
+    if "GPU_MAX_HW_QUEUES" in os.environ:               # an explicit setting of the user's wins
+        val = os.environ["GPU_MAX_HW_QUEUES"]
+        src = "environment"
+    elif n is None:
+        val, src = None, "runtime default"
+    else:
+        val = os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
+        src = "openscene_amd.configure_hw_queues"
+    if log:
+        print("[openscene_amd] GPU_MAX_HW_QUEUES=%s (%s)" % (val if val is not None else "unset", src), file=sys.stderr, flush=True)
+    return None if val is None else int(val)
+
+
+def accelerate(target):
+    """Route a MinkUNet's passes through the network executor: `target` is a MinkUNet class, an instance of one -- e.g. of the
+    reference's own models/mink_unet.py:28 class built on the alias -- or a module containing one (DisNet).  See drop_in.py."""
+    from .drop_in import accelerate as f
+    return f(target)
+
+
+def install_minkowski_alias(force=False, accelerate=True):
     """Register ``MinkowskiEngine`` (+ ``.modules.resnet_block``, ``.utils``) in
     ``sys.modules`` so the reference's imports (models/mink_unet.py:25-26,
     models/resnet_base.py:27-28, run/distill.py:18, run/evaluate.py:18) resolve to
-    the HIP implementation without editing the reference."""
+    the HIP implementation without editing the reference.
+
+    accelerate (default): also arrange for the reference's ``models/mink_unet.py`` -- whenever it gets imported -- to run its
+    forward / backward passes through the network executor (``openscene_amd.drop_in``: the class's ``forward`` becomes a
+    dispatcher that falls back to the original, module-by-module code for every pass the executor does not compile)."""
+    if accelerate:
+        from .drop_in import install_import_hook
+        install_import_hook()
     if "MinkowskiEngine" in sys.modules and not force:
         mod = sys.modules["MinkowskiEngine"]
         if getattr(mod, "__openscene_amd__", False):

@@ -12,6 +12,7 @@ device pointers over, allocate the activation arena and the flat gradient buffer
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -197,7 +198,7 @@ class UNetExecutor:
         self.grad_total = off
 
     # -------------------------------------------------------------------------------------------- eligibility
-    def usable(self, x):
+    def usable(self, x, model=None):
         from . import functional as F_
         if not ENABLED or F_.CONV_MODE != "tl":
             return False
@@ -207,8 +208,13 @@ class UNetExecutor:
         p = self.program
         if f.shape[1] != p.convs[0].in_channels:
             return False
+        if f.requires_grad and torch.is_grad_enabled():
+            return False                    # the node has no input-feature gradient (op 0 is planned without one): module path
+        training = bool(model.training) if model is not None else None
         for m in p.bns:
             b = m.bn
+            if training is not None and (bool(b.training) != training or bool(m.training) != training):
+                return False                # per-BN flags (frozen statistics): the executor applies ONE flag to every BN
             if b.momentum is None or not b.affine or not b.track_running_stats or b.weight.device != f.device:
                 return False
         return all(c.kernel.device == f.device and c.kernel.dtype == torch.float32 for c in p.convs)
@@ -409,18 +415,28 @@ class _UNetFunction(Function):
     @staticmethod
     def backward(ctx, gout):
         _ = ctx.saved_tensors                    # raises if a parameter was modified in place since the forward pass
+        if ctx.st is None:
+            raise RuntimeError("the network executor's node was backpropagated a second time: its activation arena is released "
+                               "after the first backward pass (retain_graph is not supported here; set OSN_EXECUTOR=0 for the "
+                               "module-by-module path)")
         grads = ctx.ex._run_backward(ctx.st, gout)
         ctx.st = None
         return (None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:]))
 
 
+_EXECUTORS = weakref.WeakKeyDictionary()       # model -> UNetExecutor | None.  NOT stored on the module: the executor holds ctypes
+                                                # structures with pointer fields and raw event handles, which would break
+                                                # copy.deepcopy(model), pickling and torch.save(model) (EMA copies, mp.spawn)
+
+
 def for_model(model):
-    """The (cached) executor of a MinkUNetBase instance, or None when its tree is not compilable."""
-    ex = model.__dict__.get("_osn_executor", False)
+    """The (cached) executor of a MinkUNet module tree -- openscene_amd.mink_unet's or the reference's own
+    models/mink_unet.py class built on the MinkowskiEngine alias -- or None when the tree is not compilable."""
+    ex = _EXECUTORS.get(model, False)
     if ex is False:
         try:
             ex = UNetExecutor(model)
-        except NotImplementedError:
+        except (NotImplementedError, AttributeError, TypeError):
             ex = None
-        model.__dict__["_osn_executor"] = ex
+        _EXECUTORS[model] = ex
     return ex

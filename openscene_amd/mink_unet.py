@@ -89,7 +89,7 @@ class MinkUNetBase(nn.Module):
         # one C call per pass (openscene_amd/executor.py) when the configuration allows it; otherwise -- and for the
         # reference's own models/mink_unet.py running through the MinkowskiEngine alias -- module by module
         ex = executor.for_model(self)
-        if ex is not None and ex.usable(x):
+        if ex is not None and ex.usable(x, self):
             return ex.forward(self, x)
         with F_.deferred_bn_counters():
             return self.final(self._forward(x)).F
@@ -98,7 +98,7 @@ class MinkUNetBase(nn.Module):
         """The input of the final 1x1 convolution (float32 [N_0, PLANES[7]], input row order): what
         ``openscene_amd.query.query_distill_fused`` folds the head into."""
         ex = executor.for_model(self)
-        if ex is not None and ex.usable(x):
+        if ex is not None and ex.usable(x, self):
             out = ex.forward(self, x, features_only=True)
             if out is not None:
                 return out

@@ -8,7 +8,8 @@ multi-tensor Adam (5 launches, 236 us per step for MinkUNet18A; this: ~60 us).
     loss.backward(); optim.step()
 
 Update rule, hyper-parameters and state semantics are torch.optim.Adam's (amsgrad=False, maximize=False, L2 weight decay);
-`state_dict()` / `load_state_dict()` use torch's layout (`exp_avg`, `exp_avg_sq`, `step` per parameter), so checkpoints
+`state_dict()` / `load_state_dict()` use torch's layout (`exp_avg`, `exp_avg_sq`, `step` per parameter, keyed by the
+parameter's position in `model.parameters()` order whatever the flat layout is), so checkpoints
 written by the reference's save_checkpoint (run/distill.py:232-239) load here and vice versa."""
 import torch
 
@@ -19,6 +20,12 @@ from ._lib import check
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, model_or_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         params = self._ordered(model_or_params)
+        # checkpoint index of every parameter = its position in `model.parameters()` order (what torch.optim.Adam, built the
+        # way run/distill.py:141 builds it, keys its state by) -- NOT its position in the flat layout, which follows the
+        # executor's gradient buffer (all conv kernels first, then the BN weight / bias pairs)
+        given = (list(model_or_params.parameters()) if isinstance(model_or_params, torch.nn.Module) else list(model_or_params))
+        torch_pos = {id(q): i for i, q in enumerate(q for q in given if q.requires_grad)}
+        self._ckpt_index = [torch_pos[id(q)] for q in params]
         if not params:
             raise ValueError("FlatAdam got no parameters")
         if not all(p.dtype == torch.float32 and p.device == params[0].device for p in params):
@@ -49,10 +56,10 @@ class FlatAdam(torch.optim.Optimizer):
         as one flat array with the optimizer's own layout), else in the order given."""
         if isinstance(model_or_params, torch.nn.Module):
             from . import executor as E
-            from .mink_unet import MinkUNetBase
+            from .drop_in import is_unet
             seen, out = set(), []
             for m in model_or_params.modules():
-                if isinstance(m, MinkUNetBase):
+                if is_unet(m):
                     ex = E.for_model(m) if E.ENABLED else None
                     if ex is not None:
                         for p in ex.program.params:
@@ -110,7 +117,7 @@ class FlatAdam(torch.optim.Optimizer):
     # ---- torch.optim.Adam's checkpoint layout
     def state_dict(self):
         state = {}
-        for i, (p, o) in enumerate(zip(self._params, self.offsets)):
+        for i, p, o in sorted(zip(self._ckpt_index, self._params, self.offsets), key=lambda t: t[0]):
             n = p.numel()
             state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": self.exp_avg[o:o + n].view_as(p).clone(),
                         "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).clone()}
@@ -122,11 +129,16 @@ class FlatAdam(torch.optim.Optimizer):
             if k != "params":
                 self.param_groups[0][k] = v
         steps = 0
-        for i, (p, o) in enumerate(zip(self._params, self.offsets)):
+        if len(sd["param_groups"][0]["params"]) != len(self._params):
+            raise ValueError("loaded state dict holds %d parameters, this optimizer %d"
+                             % (len(sd["param_groups"][0]["params"]), len(self._params)))
+        for i, p, o in zip(self._ckpt_index, self._params, self.offsets):
             st = sd["state"].get(i)
             if st is None:
                 continue
             n = p.numel()
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("state of parameter %d has shape %s, the parameter %s" % (i, tuple(st["exp_avg"].shape), tuple(p.shape)))
             self.exp_avg[o:o + n].view_as(p).copy_(st["exp_avg"])
             self.exp_avg_sq[o:o + n].view_as(p).copy_(st["exp_avg_sq"])
             steps = max(steps, int(float(st["step"])))

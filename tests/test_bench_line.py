@@ -1,0 +1,76 @@
+"""The bench contract the driver depends on: the LAST stdout line is one JSON object that fits the driver's ~8 KB stdout
+tail (round 3's 31.8 KB line left BENCH_r03.json unparsed), and `python bench.py --gpus N` starts its own ranks."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("osn_bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("record", ["r03_s17_bench_final.json", "r03_s20_bench_head.json"])
+def test_headline_of_a_full_record_fits_the_drivers_tail(record):
+    """Round 3's archived full records (31.8 KB each: 147 per-stage dicts, per-kernel survey, prose) through `headline()`."""
+    b = _bench()
+    detail = json.loads(open(os.path.join(ROOT, "profiles", record)).read().strip().splitlines()[-1])
+    line = json.dumps(b.headline(detail, os.path.join(ROOT, "bench_detail.json")), separators=(",", ":"))
+    assert len(line) < 8192 and len(line) <= b.MAX_LINE_BYTES
+    back = json.loads(line)
+    for k in REQUIRED:
+        assert k in back, k
+    assert back["value"] == detail["value"] and back["ms_per_step"] == detail["ms_per_step"]
+    rf = back["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in back["cpu_baseline"]
+    assert "workload" in back["config"] and "model" not in back["config"]
+    assert "stages" not in back and "kernels" not in back
+    assert back["detail"] == "bench_detail.json"
+
+
+def test_headline_drops_side_blocks_rather_than_outgrow_the_limit():
+    b = _bench()
+    detail = json.loads(open(os.path.join(ROOT, "profiles", "r03_s20_bench_head.json")).read().strip().splitlines()[-1])
+    detail["phases"] = {"phase_%04d" % i: {"ms": 1.0 / (i + 1)} for i in range(600)}
+    line = json.dumps(b.headline(detail, None), separators=(",", ":"))
+    assert len(line) <= b.MAX_LINE_BYTES
+    back = json.loads(line)
+    assert "phases_ms" not in back and all(k in back for k in REQUIRED)
+
+
+def test_gpus_n_without_a_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun, no RANK in the environment) re-executes under torch.distributed.run; the
+    hidden self-test mode runs the N > 1 harness (barrier-bracketed timing, MAX over ranks, rank-0 line) on gloo / CPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--spawn-self-test"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["value"] > 0 and d["config"]["parallelism"] == "dp2"
+    assert "re-executing under torch.distributed.run" in r.stderr
+
+
+def test_spawn_command_is_the_drivers_launch_line():
+    b = _bench()
+    cmd = b.spawn_command(4, ["--gpus", "4", "--steps", "20"], port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "20"]

@@ -107,3 +107,43 @@ def test_flat_adam_adopts_the_executor_order_for_a_model(fake_adam):
     assert [id(p) for p in opt._params] == [id(p) for p in ex.program.params]
     assert opt.offsets == ex.grad_off and opt.total == ex.grad_total
     assert len(opt._params) == len(list(model.parameters()))
+
+
+def test_flat_adam_checkpoints_round_trip_with_torch_adam_on_a_model(fake_adam):
+    """the flat layout follows the executor (kernels first, BN pairs after), the CHECKPOINT follows
+    model.parameters() order -- a torch.optim.Adam state dict loads into FlatAdam and back with every moment on its own
+    parameter (same-shaped parameters would otherwise be silently swapped)."""
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.optim import FlatAdam
+    torch.manual_seed(3)
+    model_a = mink_unet(3, 20, 3, "MinkUNet14A")
+    model_b = mink_unet(3, 20, 3, "MinkUNet14A")
+    model_b.load_state_dict(model_a.state_dict())
+    ref = torch.optim.Adam(model_a.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(9)
+    for _ in range(2):
+        for p in model_a.parameters():
+            p.grad = torch.randn(p.shape, generator=g)
+        ref.step()
+    ref_sd = ref.state_dict()
+    ours = FlatAdam(model_b, lr=1.0)
+    assert [id(p) for p in ours._params] != [id(p) for p in model_b.parameters()]       # the layouts really differ
+    ours.load_state_dict(ref_sd)
+    assert ours.steps == 2 and ours.param_groups[0]["lr"] == 1e-3
+    names = [n for n, _ in model_b.named_parameters()]
+    by_id = {id(p): (o, p) for p, o in zip(ours._params, ours.offsets)}
+    for i, p in enumerate(model_b.parameters()):
+        o, _ = by_id[id(p)]
+        assert torch.equal(ours.exp_avg[o:o + p.numel()].view_as(p), ref_sd["state"][i]["exp_avg"]), names[i]
+        assert torch.equal(ours.exp_avg_sq[o:o + p.numel()].view_as(p), ref_sd["state"][i]["exp_avg_sq"]), names[i]
+    back = ours.state_dict()
+    assert list(back["state"]) == list(ref_sd["state"]) and back["param_groups"][0]["params"] == ref_sd["param_groups"][0]["params"]
+    fresh = torch.optim.Adam(model_b.parameters(), lr=1.0)
+    fresh.load_state_dict(back)                                     # torch does not check shapes: compare the values
+    for i, p in enumerate(model_b.parameters()):
+        assert torch.equal(fresh.state[p]["exp_avg"], ref_sd["state"][i]["exp_avg"]), names[i]
+        assert float(fresh.state[p]["step"]) == 2.0
+    # a state dict of a different model is refused instead of mis-assigned
+    other = torch.optim.Adam(mink_unet(3, 20, 3, "MinkUNet18A").parameters(), lr=1e-3).state_dict()
+    with pytest.raises(ValueError):
+        ours.load_state_dict(other)

@@ -74,14 +74,14 @@ def bn_launches(log):
     return [l for l in log.split("\n") if re.search(r"col_reduce|bn_", l)]
 
 
-def step_logs(lib, arch="MinkUNet18A", points=20000, out_dim=64, tl_min_rows=6000, setattr_=setattr):
+def step_logs(lib, arch="MinkUNet18A", points=20000, out_dim=64, tl_min_rows=6000, setattr_=setattr, make_model=None):
     """{'modules': log, 'executor': log} of one training step (forward + backward) of `arch` on a synthetic room."""
     from openscene_amd import executor, functional as F_, synthetic as syn
     from openscene_amd.mink_unet import mink_unet
     from openscene_amd.sparse import CoordinateManager, SparseTensor
     setattr_(F_, "TL_FWD_MIN_ROWS", tl_min_rows)    # small scene: still send level 0 through the tile-list kernels
     torch.manual_seed(0)
-    model = mink_unet(3, out_dim, 3, arch).train()
+    model = (make_model or mink_unet)(3, out_dim, 3, arch).train()       # make_model: e.g. the reference's own factory (drop-in test)
     vox = syn.shuffled(syn.grid_voxels(syn.room_points(0, n_pts=points), 0.04), 0)
     coords = torch.from_numpy(syn.batch_coords([vox]))
     feats = torch.ones(coords.shape[0], 3)
