@@ -385,6 +385,65 @@ def variant_step_ms(device, arch, feature, coords, conv_mode=None, steps=5, warm
         F_.CONV_MODE = old
 
 
+def drop_in_step_ms(device, arch, out_dim, coords0, executor_on, steps=5, warmup=3, n_sup=20000):
+    """ms per step with the call sites of run/distill.py:141,315-333 UNCHANGED: a U-Net class written against
+    `import MinkowskiEngine` (tests/foreign/mink_unet.py stands in for the reference's models/mink_unet.py, which does not
+    exist on the GPU box: same attribute names, same un-fused conv / BN / ReLU / ME.cat forward) reached through
+    openscene_amd.install_minkowski_alias(); torch.optim.Adam(model.parameters()); maps built inside the step by
+    SparseTensor(feat, coords); `output_3d[mask]` with a bool mask; torch's cosine chain; loss.item() every step.
+    executor_on: the alias's import hook has given the class the network executor (what a maintainer gets by default);
+    off: its own module-by-module forward (OSN_EXECUTOR=0)."""
+    import openscene_amd
+    from openscene_amd import executor as E
+    openscene_amd.install_minkowski_alias()
+    tests_dir = os.path.join(ROOT, "tests")
+    if tests_dir not in sys.path:
+        sys.path.insert(0, tests_dir)
+    import foreign.mink_unet as fm
+    from MinkowskiEngine import SparseTensor
+    old = E.ENABLED
+    E.ENABLED = bool(executor_on)
+    try:
+        torch.manual_seed(1463)
+        model = getattr(fm, arch)(3, out_dim, 3)
+        optimizer = torch.optim.Adam(model.parameters(), lr=1e-4)            # run/distill.py:141 (before .cuda(), as there)
+        model = model.to(device)
+        model.train()
+        n = coords0.shape[0]
+        feat = torch.ones(n, 3, device=device)
+        g = torch.Generator().manual_seed(7)
+        mask = torch.zeros(n, dtype=torch.bool)
+        mask[torch.randperm(n, generator=g)[:min(n_sup, n)]] = True
+        mask = mask.to(device)
+        feat_3d = torch.nn.functional.normalize(torch.randn(int(mask.sum()), out_dim, generator=g), dim=1).half().float().to(device)
+        rng = np.random.default_rng(0)
+
+        def one():
+            coords = coords0.clone()
+            coords[:, 1:4] += torch.from_numpy((rng.random(3) * 100).astype(np.int32)).to(device)
+            sinput = SparseTensor(feat, coords)
+            output_3d = model(sinput)
+            output_3d = output_3d[mask]
+            loss = (1 - torch.nn.CosineSimilarity()(output_3d, feat_3d)).mean()
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            return loss.item()
+
+        for _ in range(warmup):
+            one()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = one()
+        torch.cuda.synchronize(device)
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        from openscene_amd import drop_in
+        return ms, last, (E.for_model(model) is not None and drop_in.accelerated(model) and bool(executor_on))
+    finally:
+        E.ENABLED = old
+
+
 def _cpu_step(seed, n_pts, arch, out_dim):
     from oracle import coords as oc
     from oracle import sparse_ops as so
@@ -1106,6 +1165,16 @@ def main():
                                      "what": "8 scenes per batch: maps + eval-mode forward"}
         del coords8
         extra["conv_mode"] = F_.CONV_MODE
+        # what the reference's call sites get UNCHANGED (foreign class through the alias, torch Adam, bool-mask
+        # loss, no prefetch, loss.item() per step) -- with the executor the import hook attaches, and without it
+        di_ms, di_loss, di_ex = drop_in_step_ms(device, args.arch, out_dim, coords0, executor_on=True)
+        dm_ms, dm_loss, _ = drop_in_step_ms(device, args.arch, out_dim, coords0, executor_on=False)
+        extra["drop_in_step"] = {"ms": di_ms, "voxels_per_s": n_vox / (di_ms * 1e-3), "executor": di_ex, "loss": di_loss,
+                                 "what": "run/distill.py:141,315-333 call sites unchanged (MinkowskiEngine alias + import hook: the foreign "
+                                         "MinkUNet class plays the executor's stage program; torch.optim.Adam, maps inside the step, "
+                                         "output_3d[mask], torch cosine chain, loss.item() per step)"}
+        extra["drop_in_step_modules"] = {"ms": dm_ms, "voxels_per_s": n_vox / (dm_ms * 1e-3), "loss": dm_loss,
+                                         "what": "the same with OSN_EXECUTOR=0: the class's own un-fused conv / BN / ReLU / ME.cat chain"}
         # multi-view feature fusion: one 320 x 240 view of a 200 k-point scene, 768-d pixel features
         from openscene_amd.fusion import FeatureFusion, PointCloudToImageMapper, adjust_intrinsic, make_intrinsic
         intr = adjust_intrinsic(make_intrinsic(577.870605, 577.870605, 319.5, 239.5), [640, 480], (320, 240))

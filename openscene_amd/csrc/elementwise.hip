@@ -8,8 +8,9 @@ namespace osn {
 
 __device__ inline float4 ew_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ inline void ew_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ inline float relu_nan(float x) { return x > 0.f ? x : (x != x ? x : 0.f); }
 
-// MODE 0: y = max(x, 0)      MODE 1: gx = y > 0 ? gy : 0  (a = y, b = gy)      MODE 2: out = a + b
+// MODE 0: y = x > 0 ? x : (x != x ? x : 0)  (NaN propagates, as torch.relu does)      MODE 1: gx = y > 0 ? gy : 0  (a = y, b = gy)      MODE 2: out = a + b
 template <int MODE>
 __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                  float* __restrict__ out, int64_t total) {
@@ -19,7 +20,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
         const float4 x = ew_ld4(a + 4 * e);
         float4 o;
         if (MODE == 0) {
-            o = make_float4(fmaxf(x.x, 0.f), fmaxf(x.y, 0.f), fmaxf(x.z, 0.f), fmaxf(x.w, 0.f));
+            o = make_float4(relu_nan(x.x), relu_nan(x.y), relu_nan(x.z), relu_nan(x.w));
         } else {
             const float4 y = ew_ld4(b + 4 * e);
             if (MODE == 1) o = make_float4(x.x > 0.f ? y.x : 0.f, x.y > 0.f ? y.y : 0.f, x.z > 0.f ? y.z : 0.f, x.w > 0.f ? y.w : 0.f);
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
     if (blockIdx.x == 0 && threadIdx.x < (total & 3)) {
         const int64_t e = (total4 << 2) + threadIdx.x;
         const float x = a[e];
-        out[e] = MODE == 0 ? fmaxf(x, 0.f) : (MODE == 1 ? (x > 0.f ? b[e] : 0.f) : x + b[e]);
+        out[e] = MODE == 0 ? relu_nan(x) : (MODE == 1 ? (x > 0.f ? b[e] : 0.f) : x + b[e]);
     }
 }
 

@@ -256,17 +256,37 @@ class Cat2Function(Function):
         return ops.cat2_bwd(g, ca, cb)
 
 
+def _hip_eligible(*ts):
+    """The elementwise HIP kernels take contiguous float32 device matrices on 16-byte boundaries.  Anything else ON A DEVICE
+    (another dtype, a strided view, an odd storage offset) goes to the torch operator of the same name -- MinkowskiEngine
+    accepts those too; host tensors are refused by the ops like everywhere else (no CPU fallback)."""
+    for t in ts:
+        if not t.is_cuda:
+            return True                 # -> ops.* raises its usual error
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16 != 0:
+            return False
+    return True
+
+
 def relu(x):
+    if not _hip_eligible(x):
+        return torch.relu(x)
     return ReluFunction.apply(x)
 
 
 def add(a, b):
+    if not _hip_eligible(a, b) or a.shape != b.shape:
+        if a.is_cuda and b.is_cuda:
+            return a + b
     return AddFunction.apply(a, b)
 
 
 def cat(ts):
     """Column concat of feature matrices on one coordinate map, left to right: one HIP launch per pair (the
-    reference only ever concatenates two tensors; widths must be multiples of 4, as every MinkUNet width is)."""
+    reference only ever concatenates two tensors).  Widths that are not multiples of 4, other dtypes and unaligned views
+    take torch.cat on the device."""
+    if all(t.is_cuda for t in ts) and (not _hip_eligible(*ts) or any(t.dim() != 2 or t.shape[1] % 4 or t.shape[1] < 4 for t in ts)):
+        return torch.cat(list(ts), dim=1)
     out = ts[0]
     for t in ts[1:]:
         out = Cat2Function.apply(out, t)

@@ -116,6 +116,34 @@ def test_sparse_tensor_cat_and_iadd_run_on_the_hip_kernels():
     assert calls == ["cat2", "add"]
 
 
+
+def test_elementwise_inputs_the_hip_kernels_do_not_take_go_to_torch_on_the_device():
+    """MinkowskiEngine's `+`, ME.cat and MinkowskiReLU accept any dtype / width; the HIP kernels take contiguous
+    16-byte-aligned fp32 (cat: widths in multiples of 4).  Everything else stays on the device through torch's operators
+    instead of raising; NaN propagates through the HIP ReLU as through torch.relu; host tensors are still refused."""
+    from openscene_amd import _lib, functional as F_
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(50, 6, generator=g).to(dev())
+    b = torch.randn(50, 3, generator=g).to(dev())
+    assert torch.equal(F_.cat([a, b]), torch.cat([a, b], 1))                       # widths 6 and 3
+    h = torch.randn(50, 8, generator=g).half().to(dev())
+    assert torch.equal(F_.relu(h), torch.relu(h)) and F_.relu(h).dtype == torch.float16
+    assert torch.equal(F_.add(h, h), h + h)
+    wide = torch.randn(50, 9, generator=g).to(dev())
+    view = wide[:, 1:]                                                           # strided, 4-byte-aligned view
+    assert torch.equal(F_.relu(view), torch.relu(view)) and torch.equal(F_.add(view, view), view + view)
+    x = torch.tensor([[float("nan"), -1.0, 2.0, float("inf")]], device=dev())
+    y = F_.relu(x)
+    assert torch.isnan(y[0, 0]) and y[0, 1] == 0 and y[0, 2] == 2 and torch.isinf(y[0, 3])
+    xr = x.clone().requires_grad_(True)
+    F_.relu(xr).backward(torch.ones_like(x))
+    assert xr.grad.tolist() == [[0.0, 0.0, 1.0, 1.0]]
+    with pytest.raises(_lib.OpenSceneAmdError):
+        F_.relu(torch.ones(4, 4))
+    with pytest.raises(_lib.OpenSceneAmdError):
+        F_.add(torch.ones(4, 4), torch.ones(4, 4))
+
+
 # ------------------------------------------------------------------ batch norm
 @pytest.mark.parametrize("n,c", [(1, 32), (7, 64), (700, 256), (3052, 128), (47618, 96), (100999, 32), (5000, 768)])
 @pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])

@@ -334,3 +334,70 @@ def test_wgrad_on_the_auxiliary_stream_and_cached_weight_images_change_nothing(m
         for a, b in zip(ref, got):
             assert torch.equal(a, b)
     ops.clear_weight_cache()
+
+
+def test_foreign_class_through_the_alias_runs_the_executor_on_the_gpu(monkeypatch):
+    """a U-Net class written against `import MinkowskiEngine` (tests/foreign/mink_unet.py: the
+    reference's attribute names and un-fused forward) reached through install_minkowski_alias() gets the network executor on
+    the HIP path -- output bitwise equal to the mirror's executor, gradients equal -- and with OSN_EXECUTOR=0 its OWN un-fused
+    conv / BN / ReLU / ME.cat chain runs on the HIP kernels and agrees to fp32 round-off.  One optimizer step with
+    torch.optim.Adam created before .to(device), as run/distill.py:141-152 does."""
+    import os
+    import sys
+    import openscene_amd
+    from openscene_amd import drop_in, executor as E
+    from openscene_amd.mink_unet import mink_unet
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in [m for m in sys.modules if m == "MinkowskiEngine" or m.startswith("MinkowskiEngine.") or m.startswith("foreign")]:
+        monkeypatch.delitem(sys.modules, name)
+    openscene_amd.install_minkowski_alias()
+    monkeypatch.syspath_prepend(here)
+    try:
+        import foreign.mink_unet as fm
+        import MinkowskiEngine as ME
+        d = dev()
+        coords = torch.from_numpy(scene_coords(77, 30000, 0.03)).to(d)
+        feats = torch.rand(coords.shape[0], 3, device=d)
+        torch.manual_seed(3)
+        theirs = fm.MinkUNet18A(3, 48, 3)
+        optimizer = torch.optim.Adam(theirs.parameters(), lr=1e-3)
+        theirs = theirs.to(d).train()
+        ours = mink_unet(3, 48, 3, "MinkUNet18A").to(d).train()
+        ours.load_state_dict(theirs.state_dict())
+        assert drop_in.accelerated(theirs) and E.for_model(theirs) is not None
+        launches = []
+        real = E.UNetExecutor._run_forward
+        monkeypatch.setattr(E.UNetExecutor, "_run_forward", lambda self, *a, **k: (launches.append(self), real(self, *a, **k))[1])
+        mask = torch.rand(coords.shape[0], device=d) < 0.3
+        tgt = torch.nn.functional.normalize(torch.randn(int(mask.sum()), 48, device=d), dim=1)
+
+        def step(model, x):
+            out = model(x)
+            loss = (1 - torch.nn.CosineSimilarity()(out[mask], tgt)).mean()
+            model.zero_grad(set_to_none=True)
+            loss.backward()
+            return out.detach().clone(), [p.grad.detach().clone() for p in model.parameters()]
+
+        a_out, a_g = step(theirs, ME.SparseTensor(feats, coords))
+        assert len(launches) == 1 and launches[0] is E.for_model(theirs)          # the foreign class ran the executor
+        b_out, b_g = step(ours, ME.SparseTensor(feats, coords))
+        assert torch.equal(a_out, b_out)
+        for (n, _), ga, gb in zip(theirs.named_parameters(), a_g, b_g):
+            assert torch.equal(ga, gb), n
+        # its own forward (executor off): un-fused modules on the HIP kernels, same numbers to round-off
+        monkeypatch.setattr(E, "ENABLED", False)
+        for m in theirs.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.reset_running_stats()
+        c_out, c_g = step(theirs, ME.SparseTensor(feats, coords))
+        assert len(launches) == 2                                          # (the mirror's step was the second executor pass; none since)
+        assert rel_l2(c_out, a_out) <= 2e-5
+        for (n, _), ga, gc in zip(theirs.named_parameters(), a_g, c_g):
+            assert rel_l2(gc, ga) <= 3e-3, n                                 # ReLU sign flips at round-off (see the module docstring)
+        monkeypatch.setattr(E, "ENABLED", True)
+        before = [p.detach().clone() for p in theirs.parameters()]
+        step(theirs, ME.SparseTensor(feats, coords))
+        optimizer.step()
+        assert all(not torch.equal(p, q) for p, q in zip(theirs.parameters(), before))
+    finally:
+        drop_in.remove_import_hook()
