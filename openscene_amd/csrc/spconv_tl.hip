@@ -573,13 +573,24 @@ __host__ __device__ inline size_t tl2_lds_bytes(int nw, int ks, int ring, int bm
            64 + 16;
 }
 
-template <int NW, int KS, int RING>
+// PROF (tools only): wave 0 accumulates s_memtime deltas into prof[workgroup][10]: 0 tile prologue, 1 list load, 2 counted
+// wait at the top of a step, 3 barrier, 4 tail-fragment issue, 5 accumulator / fragment reads + k-step 0, 6 DMA + prefetch
+// issue, 7 remaining k-steps + write-back, 8 epilogue
+#define TL2_TICK(slot)                                             \
+    if (PROF) {                                                    \
+        __builtin_amdgcn_sched_barrier(0);                         \
+        const long long now_ = __builtin_amdgcn_s_memtime();       \
+        tacc[slot] += now_ - tlast;                                \
+        tlast = now_;                                              \
+        __builtin_amdgcn_sched_barrier(0);                         \
+    }
+template <int NW, int KS, int RING, bool PROF = false>
 __global__ __launch_bounds__(256, 2) void spconv_tl2_kernel(const float* __restrict__ in, const bf16x8* __restrict__ Wp,
                                                                 const int32_t* __restrict__ cnt, const int2* __restrict__ lst,
                                                                 const int32_t* __restrict__ out_rows, float* __restrict__ out,
                                                                 double* __restrict__ bn_partial, int32_t* __restrict__ counter,
                                                                 float* __restrict__ partial, int nz, int n_out, int K, int cin,
-                                                                int cout, int bm, int n_tiles, int ns, int ncb, int self_reset) {
+                                                                int cout, int bm, int n_tiles, int ns, int ncb, int self_reset, long long* __restrict__ prof) {
     constexpr int NT = 256;
     constexpr int CW = 32 * NW;               // output columns of the workgroup
     constexpr int S = CW + 4;                 // fp32 row stride of the output tile
@@ -626,7 +637,12 @@ __global__ __launch_bounds__(256, 2) void spconv_tl2_kernel(const float* __restr
         a_z4[h] = 4 * tl2_swz<KS>(r);
     }
 
-    bf16x8 B[KS][2][3];
+    // B fragments: k-step 0 of the current and of the NEXT (offset, chunk) in two alternating sets, k-steps >= 1 in one tail
+    // set filled at the top of a unit (needed 400+ clocks later): 96 registers for 96 input channels instead of 144
+    bf16x8 B0[2][3], B1[2][3], Bt[KS > 1 ? KS - 1 : 1][2][3];
+    const bool dbg_nob = (self_reset & 2) != 0, dbg_nodma = (self_reset & 4) != 0;      // tools only (osn_dbg_set_tl2 bits 1, 2)
+    long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = PROF ? __builtin_amdgcn_s_memtime() : 0;
 
     for (;;) {
         if (tid == 0) scal[2] = atomicAdd(&counter[blockIdx.y], 1);
@@ -665,6 +681,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tl2_kernel(const float* __restr
         __syncthreads();
         const int nact_all = __builtin_amdgcn_readfirstlane(scal[0]);
         const int nact = nact_all * (zpart + 1) / nz;
+        TL2_TICK(0)
 
         int a0 = nact_all * zpart / nz;
         while (a0 < nact) {
@@ -708,6 +725,11 @@ __global__ __launch_bounds__(256, 2) void spconv_tl2_kernel(const float* __restr
                     plist[e] = e < rows ? ((uint32_t(e) << 24) | uint32_t(row0 + e)) : (uint32_t(bm) << 24);
             }
             __syncthreads();                               // lists ready; no DMA is in flight here (the pipeline below drains)
+            // (an S_WAITCNT the compiler's scoreboard sees: without it its model carries the list loads above into the loop as
+            // "possibly pending" and guards their registers with vmcnt(1) / vmcnt(0) on every step -- which, at run time, drains
+            // the DMA groups and fragment loads it does not know about)
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0), expcnt / lgkmcnt untouched
+            TL2_TICK(1)
 
             auto first = [&](int a) {
                 TlIter it;
@@ -736,136 +758,178 @@ __global__ __launch_bounds__(256, 2) void spconv_tl2_kernel(const float* __restr
                 for (int j = 0; j < IPW; ++j) {
                     const unsigned row = plist[base + d_row[j]] & 0xFFFFFFu;
                     const float* src = in + (uint64_t(row) * unsigned(cin) + unsigned(32 * it.s0 + d_col[j]));
-                    tl2_dma16(src, dst + j * 1024);
+                    if (!dbg_nodma) tl2_dma16(src, dst + j * 1024);
                 }
             };
 
-            TlIter cur = first(a0);
-            TlIter nf = cur;                   // the step whose rows are fetched next
-            int inflight = 0;                  // slots issued and not yet consumed
-            int cslot = 0, fslot = 0;
+            // ---- the batch as a sequence of UNITS (offset, channel chunk), each a run of 32-pair steps.  The B fragments of
+            // unit u + 1 are loaded into the OTHER register set in the middle of unit u's first step: the 54 KB a workgroup pulls
+            // per unit (a burst the CU's load path needs ~900 clocks for, 2 500 with the other workgroup's burst beside it: round
+            // 3's "B issue" timer) travel while unit u multiplies.  They are ordinary loads -- the compiler orders their first
+            // use (its wait sits in the peeled first step of a unit only; hiding them in inline asm as well let the register
+            // allocator copy a fragment that had not landed yet) -- and, being vector-memory operations, they count in the
+            // hand-placed waits of the DMA groups.
+            struct Unit { int a, s0, np, niter; };
+            auto unit_at = [&](int a, int s0) {
+                Unit u;
+                u.a = a; u.s0 = s0;
+                u.np = a < a1 ? __builtin_amdgcn_readfirstlane(kcnt[a]) : 0;
+                u.niter = (u.np + 31) >> 5;
+                return u;
+            };
+            auto unit_next = [&](const Unit& u) { return u.s0 + KS >= ns ? unit_at(u.a + 1, 0) : unit_at(u.a, u.s0 + KS); };
+            // fragments of k-step ks of unit u (2 column blocks x 3 planes, one coalesced 1 KB load each)
+            auto load_b = [&](bf16x8 (&Bk)[2][3], const Unit& u, int ks) {
+                const int k = __builtin_amdgcn_readfirstlane(klist[u.a]);
 #pragma unroll
-            for (int d = 0; d < RING - 1; ++d) {
+                for (int nb = 0; nb < 2; ++nb) {
+                    const unsigned cb = cb0 + nb < ncb ? unsigned(cb0 + nb) : 0u;         // (columns past the weight are never stored)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const unsigned blk = (unsigned(pl * K + k) * unsigned(ns) + unsigned(u.s0 + ks)) * unsigned(ncb) + cb;
+                        Bk[nb][pl] = (Wp + (size_t(dbg_nob ? 0u : blk) << 6))[lane];
+                    }
+                }
+            };
+
+            TlIter nf = first(a0);             // the step whose rows are fetched next
+            int inflight = 0;                  // ring slots issued and not yet consumed
+            int cslot = 0, fslot = 0;
+            bool pend_b = false;               // a fragment prefetch was issued during the previous step (younger than that step's DMA group)
+            auto fetch_next = [&]() {
                 if (nf.a < a1) {
                     fetch(nf, fslot);
                     fslot = fslot + 1 == RING ? 0 : fslot + 1;
                     ++inflight;
                     advance(nf);
                 }
-            }
-            while (cur.a < a1) {
-                const bool newb = cur.g == 0 && wave < NW;
-                if (newb) {
-                    const int k = __builtin_amdgcn_readfirstlane(klist[cur.a]);
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) {
-                            const bool on = cb0 + nb < ncb;
-                            const unsigned cb = on ? unsigned(cb0 + nb) : 0u;
-#pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) {
-                                const unsigned blk = (unsigned(pl * K + k) * unsigned(ns) + unsigned(cur.s0 + ks)) * unsigned(ncb) + cb;
-                                B[ks][nb][pl] = (Wp + (size_t(blk) << 6))[lane];
-                            }
-                        }
-                }
-                // this wave's share of slot `cslot` has landed (younger DMA groups and the B loads above stay in flight)
-                if (RING == 3 && inflight > 1) {
-                    if (newb) tl_wait_vm<IPW + NBL>();
+            };
+            // one step of unit u on register set `Bs`; FIRST: the unit's first step, which also starts the prefetch into `Bn`
+            auto step = [&](auto first_c, bf16x8 (&Bs)[2][3], bf16x8 (&Bn)[2][3], const Unit& u, const Unit& un, int g) {
+                constexpr bool FIRST = decltype(first_c)::value;
+                // this wave's share of slot `cslot` has landed (and every older load); the youngest DMA group and a fragment
+                // prefetch issued during the previous step stay in flight
+                const bool young = RING == 3 && inflight > 1;
+                if (young) {
+                    if (pend_b) tl_wait_vm<IPW + NBL>();
                     else tl_wait_vm<IPW>();
                 } else {
-                    if (newb) tl_wait_vm<NBL>();
+                    if (pend_b) tl_wait_vm<NBL>();
                     else tl_wait_vm<0>();
                 }
-                __builtin_amdgcn_s_barrier();              // every wave's share has; every wave is done with the previous step
+                pend_b = false;
+                TL2_TICK(2)
+                __builtin_amdgcn_s_barrier();              // every wave's share has landed; every wave is done with the previous step
                 asm volatile("" ::: "memory");
+                TL2_TICK(3)
+                if (FIRST && KS > 1 && wave < NW) {
+                    // the unit's fragments of k-steps >= 1 into the single tail set (the previous unit is done with it): they are
+                    // first needed after the 12 - 24 MFMAs of k-step 0
+#pragma unroll
+                    for (int ks = 1; ks < KS; ++ks) load_b(Bt[ks - 1], u, ks);
+                    pend_b = true;
+                }
+                TL2_TICK(4)
                 const float* slotp = ring + cslot * SLOT;
-                const bool half1 = cur.np - 32 * cur.g > 16;
+                const bool half1 = u.np - 32 * g > 16;
                 if (wave < NW) {
-                    // NH = 16-pair halves of this step that hold real pairs (the last step of an offset often has <= 16: the
-                    // average (tile, offset) of a 100 k-row map holds 36 pairs); branch-free inside, so that the compiler can
-                    // place the split of k-step ks + 1 between the MFMAs of k-step ks
+                    // NH = 16-pair halves of this step that hold real pairs (the last step of an offset often has <= 16)
                     auto body = [&](auto nh) {
                         constexpr int NH = decltype(nh)::value;
+                        // accumulators start from the output tile's cells (read now: the latency hides under the fragment reads and
+                        // the split) and are stored back after the last MFMA: no separate read-add-write phase
+                        const int pbase = __builtin_amdgcn_readfirstlane(lstart[u.a]) + 32 * g + (lane & 15);
+                        int ocell[NH];
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) ocell[h] = int(plist[pbase + 16 * h] >> 24) * S + 32 * wave + 4 * (lane >> 4);
+                        float4 raw[NH][2];
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+                            raw[h][0] = *reinterpret_cast<const float4*>(slotp + a_row[h] + (a_g8 ^ a_z4[h]));
+                            raw[h][1] = *reinterpret_cast<const float4*>(slotp + a_row[h] + ((a_g8 + 4) ^ a_z4[h]));
+                        }
                         f32x4 acc[NH][2];
 #pragma unroll
                         for (int h = 0; h < NH; ++h)
 #pragma unroll
-                            for (int nb = 0; nb < 2; ++nb) acc[h][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        float4 raw[2][NH][2];
-#pragma unroll
-                        for (int h = 0; h < NH; ++h) {
-                            raw[0][h][0] = *reinterpret_cast<const float4*>(slotp + a_row[h] + (a_g8 ^ a_z4[h]));
-                            raw[0][h][1] = *reinterpret_cast<const float4*>(slotp + a_row[h] + ((a_g8 + 4) ^ a_z4[h]));
-                        }
+                            for (int nb = 0; nb < 2; ++nb) acc[h][nb] = *reinterpret_cast<const f32x4*>(&otile[ocell[h] + 16 * nb]);
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks) {
-                            bf16x8 af[NH][3];
+                            // one 16-pair half at a time: split its eight channels, then its 12 MFMAs (2 column blocks x 6 products;
+                            // per accumulator smallest terms first: a3b1, a2b2, a1b3, a2b1, a1b2, a1b1, as in spconv_tl_kernel).  The
+                            // second half's split runs beside the first half's MFMAs, and only one half's fragments are live.
 #pragma unroll
-                            for (int h = 0; h < NH; ++h) tl2_split8(raw[ks & 1][h][0], raw[ks & 1][h][1], af[h][0], af[h][1], af[h][2]);
-                            if (ks + 1 < KS) {
-#pragma unroll
-                                for (int h = 0; h < NH; ++h) {
-                                    raw[(ks + 1) & 1][h][0] = *reinterpret_cast<const float4*>(slotp + a_row[h] + ((32 * (ks + 1) + a_g8) ^ a_z4[h]));
-                                    raw[(ks + 1) & 1][h][1] = *reinterpret_cast<const float4*>(slotp + a_row[h] + ((32 * (ks + 1) + a_g8 + 4) ^ a_z4[h]));
+                            for (int h = 0; h < NH; ++h) {
+                                bf16x8 af[3];
+                                tl2_split8(raw[h][0], raw[h][1], af[0], af[1], af[2]);
+                                if (ks + 1 < KS) {
+                                    raw[h][0] = *reinterpret_cast<const float4*>(slotp + a_row[h] + ((32 * (ks + 1) + a_g8) ^ a_z4[h]));
+                                    raw[h][1] = *reinterpret_cast<const float4*>(slotp + a_row[h] + ((32 * (ks + 1) + a_g8 + 4) ^ a_z4[h]));
                                 }
-                            }
-                            // product-major order: consecutive MFMAs go to DIFFERENT accumulators; per accumulator the order is
-                            // smallest terms first: a3b1, a2b2, a1b3, a2b1, a1b2, a1b1 (as in spconv_tl_kernel)
 #define TL2_MFMA(AP, BP)                                                                                     \
-    _Pragma("unroll") for (int h = 0; h < NH; ++h) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)            \
-        acc[h][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ks][nb][BP], af[h][AP], acc[h][nb], 0, 0, 0);
-                            TL2_MFMA(2, 0)
-                            TL2_MFMA(1, 1)
-                            TL2_MFMA(0, 2)
-                            TL2_MFMA(1, 0)
-                            TL2_MFMA(0, 1)
-                            TL2_MFMA(0, 0)
+    _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                                         \
+        acc[h][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ks == 0 ? Bs[nb][BP] : Bt[ks > 0 ? ks - 1 : 0][nb][BP], af[AP], acc[h][nb], 0, 0, 0);
+                                TL2_MFMA(2, 0)
+                                TL2_MFMA(1, 1)
+                                TL2_MFMA(0, 2)
+                                TL2_MFMA(1, 0)
+                                TL2_MFMA(0, 1)
+                                TL2_MFMA(0, 0)
 #undef TL2_MFMA
+                            }
                             if (ks == 0) {
-                                // the rows of step t + RING - 1 (slot of step t - 1: free since the barrier above).  Issued AFTER
-                                // the first use of freshly loaded B fragments: the compiler's wait there covers every
-                                // vector-memory operation it knows to be outstanding
-                                if (nf.a < a1) {
-                                    fetch(nf, fslot);
-                                    fslot = fslot + 1 == RING ? 0 : fslot + 1;
-                                    ++inflight;
-                                    advance(nf);
+                                // after the first use of this unit's fragments (the compiler's wait for them covers every load it
+                                // knows to be outstanding): the rows of step t + RING - 1 into the slot of step t - 1 (free since the
+                                // barrier), then the next unit's fragments
+                                if (PROF) {
+                                    float sink = 0.f;
+#pragma unroll
+                                    for (int h = 0; h < NH; ++h) sink += acc[h][0][0] + acc[h][1][0];
+                                    asm volatile("" ::"v"(sink));
                                 }
+                                TL2_TICK(5)
+                                __builtin_amdgcn_sched_barrier(0);
+                                fetch_next();
+                                if (FIRST && un.a < a1) {
+                                    load_b(Bn, un, 0);
+                                    pend_b = true;
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                TL2_TICK(6)
                             }
                         }
-                        const int pbase = __builtin_amdgcn_readfirstlane(lstart[cur.a]) + 32 * cur.g + (lane & 15);
-                        int ocell[NH];
-#pragma unroll
-                        for (int h = 0; h < NH; ++h) ocell[h] = int(plist[pbase + 16 * h] >> 24) * S + 32 * wave + 4 * (lane >> 4);
-                        float4 curv[NH][2];
 #pragma unroll
                         for (int h = 0; h < NH; ++h)
 #pragma unroll
-                            for (int nb = 0; nb < 2; ++nb) curv[h][nb] = *reinterpret_cast<const float4*>(&otile[ocell[h] + 16 * nb]);
-#pragma unroll
-                        for (int h = 0; h < NH; ++h)
-#pragma unroll
-                            for (int nb = 0; nb < 2; ++nb)
-                                *reinterpret_cast<float4*>(&otile[ocell[h] + 16 * nb]) =
-                                    make_float4(curv[h][nb].x + acc[h][nb][0], curv[h][nb].y + acc[h][nb][1],
-                                                curv[h][nb].z + acc[h][nb][2], curv[h][nb].w + acc[h][nb][3]);
+                            for (int nb = 0; nb < 2; ++nb) *reinterpret_cast<f32x4*>(&otile[ocell[h] + 16 * nb]) = acc[h][nb];
+                        TL2_TICK(7)
                     };
                     if (half1) body(std::integral_constant<int, 2>{});
                     else body(std::integral_constant<int, 1>{});
                 } else {
-                    // staging-only wave (output narrower than 128 columns): its share of the next rows
-                    if (nf.a < a1) {
-                        fetch(nf, fslot);
-                        fslot = fslot + 1 == RING ? 0 : fslot + 1;
-                        ++inflight;
-                        advance(nf);
-                    }
+                    fetch_next();                          // staging-only wave (output narrower than 128 columns)
                 }
                 --inflight;
                 cslot = cslot + 1 == RING ? 0 : cslot + 1;
-                advance(cur);
+            };
+            auto run_unit = [&](bf16x8 (&Bs)[2][3], bf16x8 (&Bn)[2][3], const Unit& u, const Unit& un) {
+                step(std::true_type{}, Bs, Bn, u, un, 0);
+                for (int g = 1; g < u.niter; ++g) step(std::false_type{}, Bs, Bn, u, un, g);
+            };
+
+            Unit u = unit_at(a0, 0);
+            if (wave < NW) load_b(B0, u, 0);               // the batch's first unit: nothing to hide it behind
+#pragma unroll
+            for (int d = 0; d < RING - 1; ++d) fetch_next();
+            for (;;) {
+                if (u.a >= a1) break;
+                Unit un = unit_next(u);
+                run_unit(B0, B1, u, un);
+                u = un;
+                if (u.a >= a1) break;
+                un = unit_next(u);
+                run_unit(B1, B0, u, un);
+                u = un;
             }
             a0 = a1;
             __syncthreads();                               // (drains nothing: every issued slot was consumed) tile / lists reusable
@@ -900,8 +964,11 @@ __global__ __launch_bounds__(256, 2) void spconv_tl2_kernel(const float* __restr
             }
         }
         __syncthreads();
+        TL2_TICK(8)
     }
-    if (self_reset && tid == 0) {
+    if (PROF && tid == 0 && blockIdx.y == 0)
+        for (int i = 0; i < 10; ++i) prof[int64_t(blockIdx.x) * 10 + i] = tacc[i];
+    if ((self_reset & 1) && tid == 0) {
         const int done = atomicAdd(&counter[64 + blockIdx.y], 1);
         if (done == int(gridDim.x) - 1) {
             counter[blockIdx.y] = 0;
@@ -1012,12 +1079,13 @@ static int g_tl2 = -1;
 static bool tl2_on() {
     if (g_tl2 < 0) {
         const char* e = getenv("OSN_TL2");
-        g_tl2 = (e && e[0] == '0') ? 0 : 1;
+        g_tl2 = (e && e[0] == '1') ? 1 : 0;         // experimental (round 4): measured SLOWER than spconv_tl_kernel, off by default
     }
     return g_tl2 == 1;
 }
 // Tools only: 1 = LDS-DMA kernel where eligible (default), 0 = round-2 kernel
-extern "C" void osn_dbg_set_tl2(int on) { g_tl2 = on ? 1 : 0; }
+static int g_tl2_dbg = 0;
+extern "C" void osn_dbg_set_tl2(int on) { g_tl2 = (on & 1) ? 1 : 0; g_tl2_dbg = on & 6; }
 
 static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
                               float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm, void* ws,
@@ -1060,7 +1128,7 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
     const bf16x8* wp = static_cast<const bf16x8*>(Wp);
     // round 4: the LDS-DMA kernel for input channels in multiples of 32 (every MinkUNet width); OSN_TL2=0 / osn_dbg_set_tl2(0)
     // keep the round-2 kernel
-    if (tl2_on() && !prof && (cin & 31) == 0) {
+    if (tl2_on() && (cin & 31) == 0 && (!prof || (nw == 3 && ns == 3 && tl2_lds_bytes(3, 3, 3, bm) <= 80 * 1024 - 640))) {
         const int ks2 = ns % 3 == 0 ? 3 : (ns % 2 == 0 ? 2 : (ns == 1 ? 1 : 0));
         if (ks2 > 0) {
             int ring = 3;
@@ -1079,7 +1147,7 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
             attr_bytes = lds;                                                                                                \
         }                                                                                                                    \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, wp, cnt, lst, out_rows, out, bn_partial, counter, partial, nz, \
-                           int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset);                                 \
+                           int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset | g_tl2_dbg, prof);               \
     } while (0)
 #define OSN_TL2R(NW_, KS_)                                                                                                   \
     do {                                                                                                                     \
@@ -1092,6 +1160,14 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
         else if (ks2 == 2) OSN_TL2R(NW_, 2);                                                                                 \
         else OSN_TL2R(NW_, 1);                                                                                               \
     } while (0)
+            if (prof) {
+                auto kern = spconv_tl2_kernel<3, 3, 3, true>;
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
+                    rc2 = OSN_E_HIP;
+                else
+                    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, wp, cnt, lst, out_rows, out, bn_partial, counter, partial, nz,
+                                       int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof);
+            } else
             switch (nw) {
                 case 4: OSN_TL2W(4); break;
                 case 3: OSN_TL2W(3); break;

@@ -14,6 +14,8 @@ from openscene_amd.sparse import CoordinateManager  # noqa: E402
 
 PHASES = ["prologue", "list load", "gather wait+split", "barrier A", "barrier B",
           "B wait+frags+MFMA", "tile RMW", "epilogue", "B issue", "stage write+gather issue"]
+PHASES2 = ["prologue", "list load", "counted wait (DMA landed)", "barrier", "tail-fragment issue", "acc/frag reads + k-step 0",
+           "DMA + prefetch issue", "k-steps 1.. + write-back", "epilogue", "-"]
 
 
 def main():
@@ -25,7 +27,12 @@ def main():
     fn.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, ctypes.c_size_t, vp, vp]
     vox = syn.shuffled(syn.grid_voxels(syn.room_points(0), 0.02), 0)
     cm = CoordinateManager(torch.from_numpy(syn.batch_coords([vox])).to(dev))
-    for stride, cin, cout in ((1, 96, 96), (1, 128, 96), (2, 96, 96), (2, 32, 32)):
+    import ctypes as _c
+    set_tl2 = _c.CDLL(_lib.LIB_PATH).osn_dbg_set_tl2
+    variant = int(os.environ.get("TL2", "1"))
+    set_tl2(variant)
+    shapes = ((1, 96, 96), (2, 96, 96)) if variant else ((1, 96, 96), (1, 128, 96), (2, 96, 96), (2, 32, 32))
+    for stride, cin, cout in shapes:
         n = cm.size(stride)
         tiles = cm.kmap_tiles(stride, stride, 3)[0]
         tl = ops.tile_lists(tiles[1], out_rows=tiles[0])
@@ -50,14 +57,14 @@ def main():
         print("kernel with timers: %.1f us" % (e0.elapsed_time(e1) * 1e3))
         p = prof.double().cpu()
         cnt = tl.counts().cpu()
-        nchunk = -(-cin // 128)
+        nchunk = 1 if variant else -(-cin // 128)
         steps = ((cnt + 31) // 32).sum().item() * nchunk
         offs = (cnt > 0).sum().item()
         tot = p.sum(1)
         print("stride %d %d->%d: %d tiles, %.1f offsets and %.1f steps per tile; %.0f ticks per workgroup (min %.0f max %.0f), %.0f per tile" % (
             stride, cin, cout, tl.n_tiles, offs / tl.n_tiles, steps / tl.n_tiles, tot.mean(), tot.min(), tot.max(), tot.sum() / tl.n_tiles))
         # p[w, i] = ticks workgroup w spent in phase i over ALL its tiles: per tile = sum / tiles, per step = sum / steps
-        for i, name in enumerate(PHASES):
+        for i, name in enumerate(PHASES2 if variant else PHASES):
             print("   %-24s %9.0f ticks/tile  %5.1f %%   %8.0f per step" % (
                 name, p[:, i].sum() / tl.n_tiles, 100 * p[:, i].sum() / tot.sum(), p[:, i].sum() / steps))
 
