@@ -384,6 +384,10 @@ int osn_distill_loss_fwd(const float* out, const int64_t* sel, const float* targ
                          float* loss, void* state, size_t state_bytes, osn_stream_t stream);
 int osn_distill_loss_bwd(const float* out, const float* target, const float* gloss, int64_t n, int64_t n_sel, int d, int kind,
                          float* gout, const void* state, size_t state_bytes, osn_stream_t stream);
+/* the same pass; additionally grows[j, :] = gout[sel[j], :] (nullable): the non-zero rows of the gradient once more, compacted,
+ * for osn_net_run.goutput_rows (the first n int32 of `state` are osn_net_run.grows_pos)                                  */
+int osn_distill_loss_bwd_rows(const float* out, const float* target, const float* gloss, int64_t n, int64_t n_sel, int d, int kind,
+                              float* gout, float* grows, const void* state, size_t state_bytes, osn_stream_t stream);
 int osn_distill_loss_check(const void* state, int64_t n, int64_t n_sel, osn_stream_t stream);
 
 /* ---- optimizer step over one flat buffer ------------------------------------------------------------ *
@@ -589,8 +593,22 @@ typedef struct osn_net_run {
     osn_stream_t side_stream;
     void* ws_side; uint64_t ws_side_bytes;     /* scratch of the side stream's launches (same size rule as ws)       */
     osn_events_t* events;        /* osn_events_create(2 * n_ops + 2)                                              */
+    /* backward, all nullable: `goutput` is zero outside `n_grows` rows (the distillation loss supervises ~20 % of the
+     * voxels: run/distill.py:321-326 indexes the output with a mask before the loss, so autograd's gradient of the full
+     * output has zero rows everywhere else).  grows_pos[r] = j for the j-th such row, -1 otherwise (osn_distill_loss_* keeps
+     * it); grows_idx[j] = r; goutput_rows [n_grows, cout] = goutput[grows_idx].  Given all three, the input and weight
+     * gradients of the op that produced `output` run on the n_grows rows only (same values: the other rows contribute
+     * exact zeros).                                                                                                */
+    const int32_t* grows_pos;
+    const int64_t* grows_idx;
+    const float* goutput_rows;
+    int64_t n_grows;
 } osn_net_run;
 int osn_net_plan_query(const osn_net_desc* net, const int64_t* level_rows, int training, osn_net_plan* plan);
+/* out[j, :] = in[idx[j], :] (c % 4 == 0) and its inverse out[r, :] = pos[r] >= 0 ? in[pos[r], :] : 0 over all n rows: the row
+ * compaction around the head's gradients (`output_3d[mask]`, run/distill.py:322, and torch's index backward)        */
+int osn_rows_gather(const float* in, const int64_t* idx, int64_t n_idx, int c, float* out, osn_stream_t stream);
+int osn_rows_scatter_zero(const float* in, const int32_t* pos, int64_t n, int c, float* out, osn_stream_t stream);
 int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, osn_stream_t stream);
 int osn_net_backward(const osn_net_desc* net, const osn_net_run* run, osn_stream_t stream);
 osn_events_t* osn_events_create(int n);       /* n timing-free HIP events on the current device; null on failure   */

@@ -57,6 +57,9 @@ PROTOTYPES = {
     "osn_distill_loss_state_bytes": (_sz, [_i64, _i64]),
     "osn_distill_loss_fwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "osn_distill_loss_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "osn_distill_loss_bwd_rows": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "osn_rows_gather": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "osn_rows_scatter_zero": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "osn_distill_loss_check": (_i32, [_vp, _i64, _i64, _vp]),
     "osn_stem_conv_wgrad_ws_bytes": (_sz, [_i32, _i32]),
     "osn_stem_conv_wgrad": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),

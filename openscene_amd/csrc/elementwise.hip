@@ -52,6 +52,29 @@ __global__ __launch_bounds__(256) void cat2_kernel(float* __restrict__ a, int ca
     }
 }
 
+// out[j, :] = in[idx[j], :]
+__global__ __launch_bounds__(256) void rows_gather_kernel(const float* __restrict__ in, const int64_t* __restrict__ idx, int64_t n_idx,
+                                                          int c4, float* __restrict__ out) {
+    const int64_t total = n_idx * c4;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t j = e / c4;
+        const int c = int(e - j * c4);
+        ew_st4(out + e * 4, ew_ld4(in + (idx[j] * c4 + c) * 4));
+    }
+}
+
+// out[r, :] = pos[r] >= 0 ? in[pos[r], :] : 0
+__global__ __launch_bounds__(256) void rows_scatter_zero_kernel(const float* __restrict__ in, const int32_t* __restrict__ pos, int64_t n,
+                                                                int c4, float* __restrict__ out) {
+    const int64_t total = n * c4;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t r = e / c4;
+        const int c = int(e - r * c4);
+        const int j = pos[r];
+        ew_st4(out + e * 4, j >= 0 ? ew_ld4(in + (int64_t(j) * c4 + c) * 4) : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
+
 static int ew_blocks(int64_t work) {
     int64_t g = cdiv(work, 256);
     if (g > 4096) g = 4096;
@@ -113,6 +136,26 @@ extern "C" int osn_cat2_bwd(const float* gout, float* ga, int ca, float* gb, int
     OSN_REQUIRE(gout && ga && gb && aligned16(gout) && aligned16(ga) && aligned16(gb), OSN_E_ARG, "osn_cat2_bwd: null or unaligned pointer");
     hipLaunchKernelGGL((cat2_kernel<true>), dim3(ew_blocks(n * ((ca + cb) / 4))), dim3(256), 0, st, ga, ca / 4, gb, cb / 4,
                        const_cast<float*>(gout), n);
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}
+
+extern "C" int osn_rows_gather(const float* in, const int64_t* idx, int64_t n_idx, int c, float* out, osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n_idx >= 0 && c >= 4 && (c & 3) == 0, OSN_E_ARG, "osn_rows_gather: needs c %% 4 == 0 (n_idx=%lld c=%d)", (long long)n_idx, c);
+    if (n_idx == 0) return OSN_OK;
+    OSN_REQUIRE(in && idx && out && aligned16(in) && aligned16(out), OSN_E_ARG, "osn_rows_gather: null or unaligned pointer");
+    hipLaunchKernelGGL(rows_gather_kernel, dim3(ew_blocks(n_idx * (c / 4))), dim3(256), 0, st, in, idx, n_idx, c / 4, out);
+    OSN_LAUNCH_CHECK();
+    return OSN_OK;
+}
+
+extern "C" int osn_rows_scatter_zero(const float* in, const int32_t* pos, int64_t n, int c, float* out, osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n >= 0 && c >= 4 && (c & 3) == 0, OSN_E_ARG, "osn_rows_scatter_zero: needs c %% 4 == 0 (n=%lld c=%d)", (long long)n, c);
+    if (n == 0) return OSN_OK;
+    OSN_REQUIRE(in && pos && out && aligned16(in) && aligned16(out), OSN_E_ARG, "osn_rows_scatter_zero: null or unaligned pointer");
+    hipLaunchKernelGGL(rows_scatter_zero_kernel, dim3(ew_blocks(n * (c / 4))), dim3(256), 0, st, in, pos, n, c / 4, out);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
 }

@@ -90,7 +90,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ out, const float* __restrict__ target,
                                                         const int32_t* __restrict__ pos, const float* __restrict__ stats,
                                                         const float* __restrict__ gloss, int64_t n, int64_t n_sel, int d,
-                                                        float* __restrict__ gout) {
+                                                        float* __restrict__ gout, float* __restrict__ grows) {
     const int lane = threadIdx.x & 63;
     const int64_t r = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (r >= n) return;
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
     }
     const float* a = out + r * d;
     const float* b = target + int64_t(j) * d;
+    float* g2 = grows ? grows + int64_t(j) * d : nullptr;      // the same row once more, compacted: [n_sel, d]
     const float up = gloss ? *gloss : 1.f;
     if (KIND == 0) {
         const float dot = stats[3 * j + 0], a2 = stats[3 * j + 1], b2 = stats[3 * j + 2];
@@ -114,7 +115,9 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
         for (int c = 4 * lane; c < d; c += 256) {
             const float4 x = *reinterpret_cast<const float4*>(a + c);
             const float4 y = *reinterpret_cast<const float4*>(b + c);
-            *reinterpret_cast<float4*>(g + c) = make_float4(kb * y.x + ka * x.x, kb * y.y + ka * x.y, kb * y.z + ka * x.z, kb * y.w + ka * x.w);
+            const float4 v = make_float4(kb * y.x + ka * x.x, kb * y.y + ka * x.y, kb * y.z + ka * x.z, kb * y.w + ka * x.w);
+            *reinterpret_cast<float4*>(g + c) = v;
+            if (g2) *reinterpret_cast<float4*>(g2 + c) = v;
         }
     } else {
         const float s = up / (float(n_sel) * float(d));
@@ -122,7 +125,9 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
         for (int c = 4 * lane; c < d; c += 256) {
             const float4 x = *reinterpret_cast<const float4*>(a + c);
             const float4 y = *reinterpret_cast<const float4*>(b + c);
-            *reinterpret_cast<float4*>(g + c) = make_float4(sg(x.x - y.x), sg(x.y - y.y), sg(x.z - y.z), sg(x.w - y.w));
+            const float4 v = make_float4(sg(x.x - y.x), sg(x.y - y.y), sg(x.z - y.z), sg(x.w - y.w));
+            *reinterpret_cast<float4*>(g + c) = v;
+            if (g2) *reinterpret_cast<float4*>(g2 + c) = v;
         }
     }
 }
@@ -179,20 +184,27 @@ extern "C" int osn_distill_loss_fwd(const float* out, const int64_t* sel, const 
     return OSN_OK;
 }
 
-extern "C" int osn_distill_loss_bwd(const float* out, const float* target, const float* gloss, int64_t n, int64_t n_sel, int d,
-                                    int kind, float* gout, const void* state, size_t state_bytes, osn_stream_t stream) {
+extern "C" int osn_distill_loss_bwd_rows(const float* out, const float* target, const float* gloss, int64_t n, int64_t n_sel, int d,
+                                         int kind, float* gout, float* grows, const void* state, size_t state_bytes,
+                                         osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n >= 1 && n_sel >= 1 && n_sel <= n && d >= 4 && (d & 3) == 0 && (kind == 0 || kind == 1), OSN_E_ARG,
                 "osn_distill_loss_bwd: n=%lld n_sel=%lld d=%d kind=%d", (long long)n, (long long)n_sel, d, kind);
     OSN_REQUIRE(out && target && gout && state && state_bytes >= osn_distill_loss_state_bytes(n, n_sel), OSN_E_ARG,
                 "osn_distill_loss_bwd: null pointer or state buffer too small");
-    OSN_REQUIRE(aligned16(out) && aligned16(target) && aligned16(gout), OSN_E_ARG, "osn_distill_loss_bwd: pointers must be 16-byte aligned");
+    OSN_REQUIRE(aligned16(out) && aligned16(target) && aligned16(gout) && (!grows || aligned16(grows)), OSN_E_ARG,
+                "osn_distill_loss_bwd: pointers must be 16-byte aligned");
     LossState s = loss_state(const_cast<void*>(state), n, n_sel);
     const dim3 grid(unsigned(cdiv(n, 4)));
-    if (kind == 0) hipLaunchKernelGGL(loss_grad_kernel<0>, grid, dim3(256), 0, st, out, target, s.pos, s.stats, gloss, n, n_sel, d, gout);
-    else hipLaunchKernelGGL(loss_grad_kernel<1>, grid, dim3(256), 0, st, out, target, s.pos, s.stats, gloss, n, n_sel, d, gout);
+    if (kind == 0) hipLaunchKernelGGL(loss_grad_kernel<0>, grid, dim3(256), 0, st, out, target, s.pos, s.stats, gloss, n, n_sel, d, gout, grows);
+    else hipLaunchKernelGGL(loss_grad_kernel<1>, grid, dim3(256), 0, st, out, target, s.pos, s.stats, gloss, n, n_sel, d, gout, grows);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
+}
+
+extern "C" int osn_distill_loss_bwd(const float* out, const float* target, const float* gloss, int64_t n, int64_t n_sel, int d,
+                                    int kind, float* gout, const void* state, size_t state_bytes, osn_stream_t stream) {
+    return osn_distill_loss_bwd_rows(out, target, gloss, n, n_sel, d, kind, gout, nullptr, state, state_bytes, stream);
 }
 
 // 0 = fine; bit 0: an index outside [0, n); bit 1: a row selected twice  (blocks until the forward pass has run)

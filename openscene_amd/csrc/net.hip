@@ -63,6 +63,7 @@ static bool x6_eligible(int K, int cin, int cout, int64_t n_out) {
 // Everything the passes derive from (program, level sizes): kernel per stage, arena offsets, scratch size.
 struct Layout {
     std::vector<uint64_t> x_off, stat_off, y_off, gx_off, gres_off, gin_off, gpart_off;
+    uint64_t rows_in_off = NO_OFF, rows_gin_off = NO_OFF;   // output op only: gathered input rows / their input gradients (row-sparse goutput)
     std::vector<int32_t> fwd_k, dgrad_k, wgrad_k, images;
     std::vector<int32_t> producer;       // buffer -> op with dst == buffer
     std::vector<uint8_t> side;           // stage may run beside the main chain: a block's 1x1 shortcut (conv + BN), see below
@@ -128,6 +129,10 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
         }
         if (o.res >= 0) { L.gres_off[i] = b; b += up256(uint64_t(n_out) * o.cout * 4); }
         if (o.need_dgrad) { L.gin_off[i] = b; b += up256(uint64_t(n_in) * o.cin * 4); }
+        if (o.dst < 0 && o.K == 1 && training) {          // room for osn_net_run.goutput_rows (at most every row)
+            L.rows_in_off = b; b += up256(uint64_t(n_in) * o.cin * 4);
+            L.rows_gin_off = b; b += up256(uint64_t(n_in) * o.cin * 4);
+        }
         // ---- forward kernel
         if (stem_eligible(o.K, o.cin, o.cout)) {
             OSN_REQUIRE(!o.transposed, OSN_E_ARG, "osn_net: op %d: transposed stem", i);
@@ -512,6 +517,12 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
         MapView v{};
         const osn_net_map* m = o.map >= 0 ? &run->maps[o.map] : nullptr;
         if (m) v = view_of(*m, o.transposed != 0);
+        // the network output's gradient with known zero rows (the loss saw n_grows of the n_out rows): both gradients of the
+        // head run on the compacted rows -- in[idx]^T @ g[idx] and scatter(g[idx] @ W^T) -- instead of all n_out
+        const bool sparse_rows = o.dst < 0 && o.K == 1 && o.bn < 0 && run->goutput_rows && run->grows_pos && run->grows_idx &&
+                                 run->n_grows > 0 && run->n_grows < n_out && L.rows_in_off != NO_OFF &&
+                                 (L.wgrad_k[i] == OSN_NET_K_WGRAD || L.wgrad_k[i] == OSN_NET_K_WGRAD_TL) &&
+                                 (!o.need_dgrad || L.dgrad_k[i] == OSN_NET_K_DENSE);
         // ---- weight gradient (fork: the side stream sees everything the main stream has queued up to gx)
         OSN_REQUIRE(w.gW, OSN_E_ARG, "osn_net_backward: op %d: null weight-gradient pointer", i);
         if (forked && !on_side) {
@@ -520,7 +531,13 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
         }
         {
             Bracket br(run->prof, i, 2, forked ? side : st);
-            if (L.wgrad_k[i] == OSN_NET_K_WGRAD_TL) {
+            if (sparse_rows) {
+                float* in_rows = reinterpret_cast<float*>(B + L.rows_in_off);
+                rc = osn_rows_gather(in, run->grows_idx, run->n_grows, o.cin, in_rows, wstream);
+                if (!rc)
+                    rc = osn_spconv_wgrad(in_rows, run->goutput_rows, nullptr, nullptr, nullptr, w.gW, run->n_grows, 1, o.cin, o.cout, wws,
+                                          wws_bytes, wstream);
+            } else if (L.wgrad_k[i] == OSN_NET_K_WGRAD_TL) {
                 // pair arrays of the map's forward table; a transposed conv uses the strided conv's arrays, roles swapped
                 OSN_REQUIRE(o.K == 1 || (m && m->pl_fwd), OSN_E_ARG, "osn_net_backward: op %d: pair lists missing", i);
                 osn_wgrad_job job;
@@ -550,6 +567,11 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
                 // a self map (flip) is its own mirror: same direction of the pair arrays with the mirrored weight image;
                 // otherwise the input gradient walks them the other way round
                 const int swap_f = o.transposed ? 1 : 0;
+                if (sparse_rows) {
+                    float* gin_rows = reinterpret_cast<float*>(B + L.rows_gin_off);
+                    rc = osn_dense_fwd(run->goutput_rows, w.tl_dgrad, gin_rows, run->n_grows, o.cout, o.cin, sstream);
+                    if (!rc) rc = osn_rows_scatter_zero(gin_rows, run->grows_pos, n_in, o.cin, gin, sstream);
+                } else
                 rc = run_conv(L.dgrad_k[i], gx, n_out, gin, n_in, o.K, o.cout, o.cin, nullptr, w.x6_dgrad, w.tl_dgrad, v.nbr_b, v.tb_rows,
                               v.tb_tbl, v.tb_g, v.tl_b, v.tl_b_rows, v.tl_b_bm, m ? m->pl_fwd : nullptr, o.transposed ? n_in : n_out,
                               (m && m->flip) ? swap_f : 1 - swap_f, r, sstream, i);

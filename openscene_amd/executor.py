@@ -26,6 +26,9 @@ ENABLED = os.environ.get("OSN_EXECUTOR", "1") != "0"
 # only at its end) and the BasicBlock shortcut stages of both passes.  Bitwise the same results; the GPU is the bottleneck
 # since the executor took the host out of the way, and most launches leave compute units idle (measured: -0.86 ms / step)
 SIDE_STREAM = os.environ.get("OSN_SIDE_STREAM", "1") != "0"
+# the head's input / weight gradients on the supervised rows only when the loss says which rows of the output gradient are
+# non-zero (losses.distill_loss does): 20 k of 101 k rows in the reference's configuration.  Exactly the same values.
+ROW_SPARSE_HEAD = os.environ.get("OSN_ROW_SPARSE_HEAD", "1") != "0"
 _DRY_RUN = False        # tools/dryrun only: accept host tensors (a null HIP runtime logs the launches instead of running them)
 
 _OP = np.dtype([(n, "<i4") for n in ("K", "cin", "cout", "lvl_in", "lvl_out", "map", "transposed", "src", "dst", "bn", "relu",
@@ -68,7 +71,9 @@ class _Run(ctypes.Structure):
                 ("tl_counters", ctypes.c_void_p), ("training", ctypes.c_int32), ("first_op", ctypes.c_int32),
                 ("end_op", ctypes.c_int32), ("reserved", ctypes.c_int32), ("prof", ctypes.c_void_p),
                 ("side_stream", ctypes.c_void_p), ("ws_side", ctypes.c_void_p), ("ws_side_bytes", ctypes.c_uint64),
-                ("events", ctypes.c_void_p)]
+                ("events", ctypes.c_void_p),
+                ("grows_pos", ctypes.c_void_p), ("grows_idx", ctypes.c_void_p), ("goutput_rows", ctypes.c_void_p),
+                ("n_grows", ctypes.c_int64)]
 
 
 def _ptr(a):
@@ -334,7 +339,7 @@ class UNetExecutor:
                    out.data_ptr() if out is not None else None, None, st.arena.data_ptr(), st.arena.numel(), None, 0,
                    ws.data_ptr(), ws.numel(), ops.tl_counters(dev).data_ptr(), int(training), 0, end, 0, self.prof,
                    side if events else None, ws2.data_ptr() if (events and ws2 is not None) else None,
-                   ws2.numel() if (events and ws2 is not None) else 0, events)
+                   ws2.numel() if (events and ws2 is not None) else 0, events, None, None, None, 0)
         with ops._Dev(dev):
             check(lib.osn_net_forward(ctypes.addressof(self.desc), ctypes.addressof(run), ops._stream(dev)), "osn_net_forward")
         if training:
@@ -372,6 +377,7 @@ class UNetExecutor:
         p = self.program
         dev = gout.device
         lib = ops._prep(dev)
+        gout_in = gout
         gout = ops._f32c(gout, "grad_output")
         self._plan_query(lib, st.rows, True)
         if int(self._plan.fwd_arena_bytes) != st.plan_fwd_bytes:
@@ -387,11 +393,22 @@ class UNetExecutor:
         ws = ops._ws(int(self._plan.ws_bytes), dev)
         self._rows[:len(st.rows)] = st.rows
         side, ws2, events = self._side(lib, dev)
+        # a gradient whose producer knows its non-zero rows (openscene_amd.losses.distill_loss: the loss sees `output[sel]`
+        # only): the head's two gradients run on those rows.  The hint travels as an attribute of the gradient tensor and is
+        # honoured only when it describes exactly this tensor.
+        rows_pos = rows_idx = rows_g = None
+        n_rows = 0
+        hint = getattr(gout_in, "_osn_rows", None)
+        if (ROW_SPARSE_HEAD and hint is not None and hint["ptr"] == gout.data_ptr() and hint["shape"] == tuple(gout.shape)
+                and 0 < hint["idx"].shape[0] < gout.shape[0] and hint["rows"].device == dev):
+            rows_pos, rows_idx, rows_g = hint["pos_ptr"], hint["idx"].data_ptr(), hint["rows"].data_ptr()
+            n_rows = int(hint["idx"].shape[0])
+            keep_hint = hint                      # (the tensors stay referenced until the launches are queued)
         run = _Run(_ptr(self._rows), _ptr(st.maps), _ptr(st.weights), _ptr(st.bns), st.feats.data_ptr(), None, gout.data_ptr(),
                    st.arena.data_ptr(), st.arena.numel(), barena.data_ptr(), barena.numel(), ws.data_ptr(), ws.numel(),
                    ops.tl_counters(dev).data_ptr(), int(st.training), 0, len(p.ops), 0, self.prof,
                    side if events else None, ws2.data_ptr() if (events and ws2 is not None) else None,
-                   ws2.numel() if (events and ws2 is not None) else 0, events)
+                   ws2.numel() if (events and ws2 is not None) else 0, events, rows_pos, rows_idx, rows_g, n_rows)
         with ops._Dev(dev):
             check(lib.osn_net_backward(ctypes.addressof(self.desc), ctypes.addressof(run), ops._stream(dev)), "osn_net_backward")
         return [grads[o:o + q.numel()].view_as(q) for o, q in zip(self.grad_off, p.params)]

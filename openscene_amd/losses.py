@@ -13,6 +13,7 @@ from . import ops
 from ._lib import check
 
 KINDS = {"cosine": 0, "l1": 1}
+ROWS_HINT = True          # attach the compacted non-zero rows to the output gradient (see _DistillLoss.backward)
 
 
 class _DistillLoss(Function):
@@ -39,6 +40,7 @@ class _DistillLoss(Function):
             if validate:
                 check(lib.osn_distill_loss_check(ops._p(state), n, n_sel, ops._stream(dev)), "osn_distill_loss_check")
         ctx.save_for_backward(out, target, state)
+        ctx.sel = sel
         ctx.cfg = (n, n_sel, d, kind)
         return loss
 
@@ -50,9 +52,17 @@ class _DistillLoss(Function):
         lib = ops._prep(dev)
         gloss = gloss.to(torch.float32).contiguous()
         gout = torch.empty_like(out)
+        # the gradient of the full output is zero outside the n_sel supervised rows: hand those rows out once more, compacted,
+        # with the row <-> position tables of the forward pass.  A consumer that understands the hint (the network executor's
+        # head) works on n_sel rows instead of n; everyone else sees the ordinary dense gradient.
+        grows = torch.empty((n_sel, d), dtype=torch.float32, device=dev) if ROWS_HINT and n_sel < n else None
         with ops._Dev(dev):
-            check(lib.osn_distill_loss_bwd(ops._p(out), ops._p(target), ops._p(gloss), n, n_sel, d, kind, ops._p(gout), ops._p(state),
-                                           state.numel(), ops._stream(dev)), "osn_distill_loss_bwd")
+            check(lib.osn_distill_loss_bwd_rows(ops._p(out), ops._p(target), ops._p(gloss), n, n_sel, d, kind, ops._p(gout),
+                                                ops._p(grows), ops._p(state), state.numel(), ops._stream(dev)),
+                  "osn_distill_loss_bwd_rows")
+        if grows is not None:
+            gout._osn_rows = {"ptr": gout.data_ptr(), "shape": tuple(gout.shape), "idx": ctx.sel, "rows": grows,
+                              "pos_ptr": state.data_ptr(), "state": state}
         return gout, None, None, None, None
 
 

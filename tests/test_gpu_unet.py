@@ -147,6 +147,63 @@ def test_disnet_distill_step_and_row_order():
     assert sum(float(g.abs().sum()) for g in grads) > 0
 
 
+@pytest.mark.parametrize("kind", ["cosine", "l1"])
+def test_row_sparse_head_gradients_equal_the_dense_path(kind, monkeypatch):
+    """Round 4: distill_loss hands the executor the non-zero rows of the output gradient (the loss sees `output[sel]`,
+    run/distill.py:322) and the head's weight / input gradients run on those rows only.  Against the dense head backward
+    (OSN_ROW_SPARSE_HEAD=0) and against torch's own `out[mask]` + CosineSimilarity / L1Loss chain: the input gradient rows
+    are computed by the same kernel row by row (=> everything upstream is BITWISE equal), the head's weight gradient sums
+    the same products without the zero rows (fp32 round-off)."""
+    from openscene_amd import executor as E, losses
+    from openscene_amd.disnet import DisNet
+    from openscene_amd.sparse import SparseTensor
+
+    class Cfg:
+        arch_3d = "MinkUNet18A"
+        feature_2d_extractor = "lseg"
+
+    torch.manual_seed(11)
+    net = DisNet(Cfg()).to(dev()).train()
+    coords = torch.from_numpy(scene_coords(5, 12000, 0.04)).to(dev())
+    n = coords.shape[0]
+    feats = torch.rand(n, 3, device=dev())
+    g = torch.Generator().manual_seed(2)
+    sel = torch.randperm(n, generator=g)[:n // 5].sort()[0].to(dev())
+    target = torch.nn.functional.normalize(torch.randn(sel.shape[0], 512, generator=g), dim=1).to(dev())
+    used = []
+    real = E.UNetExecutor._run_backward
+    monkeypatch.setattr(E.UNetExecutor, "_run_backward",
+                        lambda self, st, gout: (used.append(getattr(gout, "_osn_rows", None) is not None), real(self, st, gout))[1])
+
+    def step(sparse, torch_loss=False):
+        monkeypatch.setattr(E, "ROW_SPARSE_HEAD", sparse)
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.reset_running_stats()
+        net.zero_grad(set_to_none=True)
+        out = net(SparseTensor(feats, coords))
+        if torch_loss:
+            o = out.index_select(0, sel)
+            loss = (1 - torch.nn.CosineSimilarity()(o, target)).mean() if kind == "cosine" else torch.nn.L1Loss()(o, target)
+        else:
+            loss = losses.distill_loss(out, sel, target, kind)
+        loss.backward()
+        return loss.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+    l_sparse, g_sparse = step(True)
+    l_dense, g_dense = step(False)
+    l_torch, g_torch = step(True, torch_loss=True)
+    assert used == [True, True, False]                       # the hint travels with the HIP loss's gradient only
+    assert torch.equal(l_sparse, l_dense)
+    head = "net3d.final.kernel"
+    for k in g_dense:
+        if k == head:
+            assert rel_l2(g_sparse[k], g_dense[k]) <= 2e-6, k
+        else:
+            assert torch.equal(g_sparse[k], g_dense[k]), k
+        assert rel_l2(g_sparse[k], g_torch[k]) <= (2e-5 if kind == "cosine" else 2e-4), k
+
+
 def test_executor_equals_the_module_path(monkeypatch):
     """The executor plays the same kernels in the same order as the per-module path: forward outputs, feature taps and
     running statistics are BITWISE equal, in training and in evaluation mode; parameter gradients agree to fp32
