@@ -363,6 +363,12 @@ int osn_bn_backward_multi(const float* x, const float* y, const float* const* gy
                           int n_gy, const float* mean, const float* var, const float* gamma, float eps, int relu,
                           int training, float* gx, float* gres, float* ggamma, float* gbeta,
                           int64_t n, int c, void* ws, size_t ws_bytes, osn_stream_t stream);
+/* the same with `beta`: for a batch norm + ReLU WITHOUT a residual, y may be null -- the mask (y > 0) is recomputed from x
+ * with the forward pass's own expression, so neither backward pass reads y (models/resnet_base.py:98: bn -> relu)       */
+int osn_bn_backward_multi2(const float* x, const float* y, const float* const* gy_host, const int64_t* gy_ld_host, int n_gy,
+                           const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
+                           int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c, void* ws,
+                           size_t ws_bytes, osn_stream_t stream);
 
 /* ---- distillation loss on the supervised rows ------------------------------- *
  * Replaces run/distill.py:322-328 and its autograd chain:

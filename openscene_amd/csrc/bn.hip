@@ -35,6 +35,9 @@ __device__ inline float4 gy_load(const GySrc& s, int64_t r, int col) {
     return g;
 }
 
+__device__ inline float bn_val(float x, float mu, float is, float ga, float be);
+__device__ inline float bn_is(float var, float eps);
+
 struct ColReducePlan {
     int n_rb;            // row blocks
     int n_cg;            // column groups
@@ -58,7 +61,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const GySrc gy, const float* __restrict__ mean,
                                                          const float* __restrict__ var, float eps, int relu, int64_t n,
-                                                         int c, int rows_per_block, double* __restrict__ partial) {
+                                                         int c, int rows_per_block, double* __restrict__ partial,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta) {
     __shared__ double red[2][CR_RL][CR_COLS];
     const int tid = threadIdx.x;
     const int cl = tid & 15, rl = tid >> 4;
@@ -68,10 +72,16 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
     const int64_t r1 = min(n, r0 + rows_per_block);
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     float4 mu = make_float4(0, 0, 0, 0), is = make_float4(0, 0, 0, 0);
+    float4 ga = make_float4(0, 0, 0, 0), be = make_float4(0, 0, 0, 0);
+    const bool from_x = MODE == 1 && relu && !y;             // the ReLU mask recomputed from x (no residual): y is not read
     if (MODE == 1 && on) {
         mu = *reinterpret_cast<const float4*>(mean + col);
         const float4 v = *reinterpret_cast<const float4*>(var + col);
-        is = make_float4(1.f / sqrtf(v.x + eps), 1.f / sqrtf(v.y + eps), 1.f / sqrtf(v.z + eps), 1.f / sqrtf(v.w + eps));
+        is = make_float4(bn_is(v.x, eps), bn_is(v.y, eps), bn_is(v.z, eps), bn_is(v.w, eps));
+        if (from_x) {
+            ga = *reinterpret_cast<const float4*>(gamma + col);
+            be = *reinterpret_cast<const float4*>(beta + col);
+        }
     }
     if (on) {
         for (int64_t r = r0 + rl; r < r1; r += CR_RL) {
@@ -82,7 +92,12 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
                 s2[2] += double(xv.z) * xv.z; s2[3] += double(xv.w) * xv.w;
             } else {
                 float4 g = gy_load(gy, r, col);
-                if (relu) {
+                if (from_x) {
+                    g.x = bn_val(xv.x, mu.x, is.x, ga.x, be.x) > 0.f ? g.x : 0.f;
+                    g.y = bn_val(xv.y, mu.y, is.y, ga.y, be.y) > 0.f ? g.y : 0.f;
+                    g.z = bn_val(xv.z, mu.z, is.z, ga.z, be.z) > 0.f ? g.z : 0.f;
+                    g.w = bn_val(xv.w, mu.w, is.w, ga.w, be.w) > 0.f ? g.w : 0.f;
+                } else if (relu) {
                     const float4 yv = *reinterpret_cast<const float4*>(y + r * c + col);
                     g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
                     g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
@@ -194,6 +209,11 @@ __global__ __launch_bounds__(FIN_COLS * FIN_PARTS) void bn_bwd_finalize_kernel(c
 
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// The normalised value, ONE definition for the forward kernels and for the backward kernels that recompute the ReLU mask
+// from x instead of reading y (round 4): explicit fma so that both sides round identically whatever the surrounding code.
+__device__ inline float bn_val(float x, float mu, float is, float ga, float be) { return __fmaf_rn((x - mu) * is, ga, be); }
+__device__ inline float bn_is(float var, float eps) { return 1.f / sqrtf(var + eps); }
+
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ var, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps,
@@ -205,10 +225,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         const float4 xv = ld4(x + e * 4), mu = ld4(mean + col), vv = ld4(var + col), ga = ld4(gamma + col),
                      be = ld4(beta + col);
         float4 o;
-        o.x = (xv.x - mu.x) * (1.f / sqrtf(vv.x + eps)) * ga.x + be.x;
-        o.y = (xv.y - mu.y) * (1.f / sqrtf(vv.y + eps)) * ga.y + be.y;
-        o.z = (xv.z - mu.z) * (1.f / sqrtf(vv.z + eps)) * ga.z + be.z;
-        o.w = (xv.w - mu.w) * (1.f / sqrtf(vv.w + eps)) * ga.w + be.w;
+        o.x = bn_val(xv.x, mu.x, bn_is(vv.x, eps), ga.x, be.x);
+        o.y = bn_val(xv.y, mu.y, bn_is(vv.y, eps), ga.y, be.y);
+        o.z = bn_val(xv.z, mu.z, bn_is(vv.z, eps), ga.z, be.z);
+        o.w = bn_val(xv.w, mu.w, bn_is(vv.w, eps), ga.w, be.w);
         if (residual) {
             const float4 rv = ld4(residual + e * 4);
             o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
@@ -229,22 +249,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ sum_g,
                                                            const float* __restrict__ sum_gx, float inv_n,
                                                            float* __restrict__ gx, float* __restrict__ gres,
-                                                           int64_t total4, int c4) {
+                                                           int64_t total4, int c4, const float* __restrict__ beta) {
+    const bool from_x = relu && !y;                          // ReLU mask recomputed from x: one tensor less to read
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total4; e += int64_t(gridDim.x) * blockDim.x) {
         const int col = int(e % c4) * 4;
         float4 g = gy_load(gy, e / c4, col);
-        if (relu) {
+        const float4 vv = ld4(var + col), ga = ld4(gamma + col);
+        const float4 is = make_float4(bn_is(vv.x, eps), bn_is(vv.y, eps), bn_is(vv.z, eps), bn_is(vv.w, eps));
+        float4 xv = make_float4(0, 0, 0, 0), mu = make_float4(0, 0, 0, 0);
+        if (training || from_x) { xv = ld4(x + e * 4); mu = ld4(mean + col); }
+        if (from_x) {
+            const float4 be = ld4(beta + col);
+            g.x = bn_val(xv.x, mu.x, is.x, ga.x, be.x) > 0.f ? g.x : 0.f;
+            g.y = bn_val(xv.y, mu.y, is.y, ga.y, be.y) > 0.f ? g.y : 0.f;
+            g.z = bn_val(xv.z, mu.z, is.z, ga.z, be.z) > 0.f ? g.z : 0.f;
+            g.w = bn_val(xv.w, mu.w, is.w, ga.w, be.w) > 0.f ? g.w : 0.f;
+        } else if (relu) {
             const float4 yv = ld4(y + e * 4);
             g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
             g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
         }
         if (gres) *reinterpret_cast<float4*>(gres + e * 4) = g;
-        const float4 vv = ld4(var + col), ga = ld4(gamma + col);
-        const float4 is = make_float4(1.f / sqrtf(vv.x + eps), 1.f / sqrtf(vv.y + eps), 1.f / sqrtf(vv.z + eps),
-                                      1.f / sqrtf(vv.w + eps));
         float4 o;
         if (training) {
-            const float4 xv = ld4(x + e * 4), mu = ld4(mean + col), sg = ld4(sum_g + col), sx = ld4(sum_gx + col);
+            const float4 sg = ld4(sum_g + col), sx = ld4(sum_gx + col);
             o.x = ga.x * is.x * (g.x - sg.x * inv_n - (xv.x - mu.x) * is.x * sx.x * inv_n);
             o.y = ga.y * is.y * (g.y - sg.y * inv_n - (xv.y - mu.y) * is.y * sx.y * inv_n);
             o.z = ga.z * is.z * (g.z - sg.z * inv_n - (xv.z - mu.z) * is.z * sx.z * inv_n);
@@ -344,17 +372,16 @@ __global__ __launch_bounds__(SB_THREADS) void bn_small_fwd_kernel(const float* _
     }
     if (!con) return;
     const float4 ga = ld4(gamma + col), be = ld4(beta + col);
-    const float is0 = 1.f / sqrtf(vr[0] + eps), is1 = 1.f / sqrtf(vr[1] + eps), is2 = 1.f / sqrtf(vr[2] + eps),
-                is3 = 1.f / sqrtf(vr[3] + eps);
+    const float is0 = bn_is(vr[0], eps), is1 = bn_is(vr[1], eps), is2 = bn_is(vr[2], eps), is3 = bn_is(vr[3], eps);
 #pragma unroll
     for (int j = 0; j < SB_PER; ++j) {
         const int r = rl + SB_RL * j;
         if (r >= n) continue;
         float4 o;
-        o.x = (v[j].x - mu[0]) * is0 * ga.x + be.x;
-        o.y = (v[j].y - mu[1]) * is1 * ga.y + be.y;
-        o.z = (v[j].z - mu[2]) * is2 * ga.z + be.z;
-        o.w = (v[j].w - mu[3]) * is3 * ga.w + be.w;
+        o.x = bn_val(v[j].x, mu[0], is0, ga.x, be.x);
+        o.y = bn_val(v[j].y, mu[1], is1, ga.y, be.y);
+        o.z = bn_val(v[j].z, mu[2], is2, ga.z, be.z);
+        o.w = bn_val(v[j].w, mu[3], is3, ga.w, be.w);
         if (residual) {
             const float4 rv = ld4(residual + int64_t(r) * c + col);
             o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
@@ -394,7 +421,7 @@ extern "C" int osn_bn_stats(const float* x, int64_t n, int c, float* mean, float
     double* partial = static_cast<double*>(ws);
     hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(p.n_rb, p.n_cg), dim3(256), 0, st, x, (const float*)nullptr,
                        GySrc{}, (const float*)nullptr, (const float*)nullptr, 0.f, 0, n, c,
-                       p.rows_per_block, partial);
+                       p.rows_per_block, partial, (const float*)nullptr, (const float*)nullptr);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(c, FIN_COLS)), dim3(FIN_COLS * FIN_PARTS), 0, st, partial, p.n_rb, n, c, mean, var,
                        running_mean, running_var, momentum);
     OSN_LAUNCH_CHECK();
@@ -458,16 +485,20 @@ extern "C" int osn_bn_forward_train(const float* x, int64_t n, int c, const floa
                                  nullptr, 0, ws, ws_bytes, stream);
 }
 
-extern "C" int osn_bn_backward_multi(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,
-                                     const float* mean, const float* var, const float* gamma, float eps, int relu,
+extern "C" int osn_bn_backward_multi2(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,
+                                      const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
                                      int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c,
                                      void* ws, size_t ws_bytes, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n >= 1 && c >= 4 && (c & 3) == 0, OSN_E_ARG, "osn_bn_backward: need n >= 1 and c %% 4 == 0");
     OSN_REQUIRE(gy && gy_ld && n_gy >= 1 && n_gy <= BN_MAX_SRC, OSN_E_ARG,
                 "osn_bn_backward: %d gradient sources (1 .. %d are supported)", n_gy, BN_MAX_SRC);
-    OSN_REQUIRE(x && mean && var && gamma && gx && ggamma && gbeta && (!relu || y), OSN_E_ARG,
+    // y == null with relu: the mask is recomputed from x (the forward expression, bit for bit) -- needs beta, and a batch
+    // norm WITHOUT a residual (with one, y = relu(bn(x) + residual) cannot be rebuilt from x alone)
+    OSN_REQUIRE(x && mean && var && gamma && gx && ggamma && gbeta && (!relu || y || beta), OSN_E_ARG,
                 "osn_bn_backward: null pointer");
+    OSN_REQUIRE(!(relu && !y) || !gres, OSN_E_ARG, "osn_bn_backward: the ReLU mask can be recomputed from x only without a residual");
+    OSN_REQUIRE(!beta || aligned16(beta), OSN_E_ARG, "osn_bn_backward: beta must be 16-byte aligned");
     OSN_REQUIRE(aligned16(x) && aligned16(gx) && aligned16(mean) && aligned16(var) && aligned16(gamma) &&
                     aligned16(ggamma) && aligned16(gbeta) && (!y || aligned16(y)) && (!gres || aligned16(gres)),
                 OSN_E_ARG, "osn_bn_backward: pointers must be 16-byte aligned");
@@ -485,14 +516,23 @@ extern "C" int osn_bn_backward_multi(const float* x, const float* y, const float
     OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_bn_backward: workspace %zu < %zu", ws_bytes, need);
     double* partial = static_cast<double*>(ws);
     hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(p.n_rb, p.n_cg), dim3(256), 0, st, x, y, src, mean, var, eps, relu, n,
-                       c, p.rows_per_block, partial);
+                       c, p.rows_per_block, partial, gamma, beta);
     // ggamma = sum g*xhat, gbeta = sum g  (also the two column sums the apply pass needs)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, FIN_COLS)), dim3(FIN_COLS * FIN_PARTS), 0, st, partial, p.n_rb, c, gbeta, ggamma);
     const int64_t total4 = n * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, y, src, mean, var, gamma, eps,
-                       relu, training, gbeta, ggamma, 1.f / float(n), gx, gres, total4, c / 4);
+                       relu, training, gbeta, ggamma, 1.f / float(n), gx, gres, total4, c / 4, beta);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
+}
+
+extern "C" int osn_bn_backward_multi(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,
+                                     const float* mean, const float* var, const float* gamma, float eps, int relu,
+                                     int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c,
+                                     void* ws, size_t ws_bytes, osn_stream_t stream) {
+    OSN_REQUIRE(!relu || y, OSN_E_ARG, "osn_bn_backward_multi: relu needs y (or osn_bn_backward_multi2 with beta)");
+    return osn_bn_backward_multi2(x, y, gy, gy_ld, n_gy, mean, var, gamma, nullptr, eps, relu, training, gx, gres, ggamma, gbeta, n, c,
+                                  ws, ws_bytes, stream);
 }
 
 extern "C" int osn_bn_backward(const float* x, const float* y, const float* gy, const float* mean, const float* var,

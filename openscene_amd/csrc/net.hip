@@ -465,7 +465,10 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
             OSN_REQUIRE(run->goutput, OSN_E_ARG, "osn_net_backward: null output gradient");
             gsrc[ng] = run->goutput; gld[ng] = o.cout; ++ng;
         } else {
-            for (int j = i + 1; j < run->end_op && ng < 4; ++j) {
+            // (every later op, not only those of this call's range: a backward pass may be played in segments, highest ops
+            // first -- executor.py does when a gradient exchange wants the finished slices early -- and the consumers of an
+            // earlier segment left their input gradients in the arena)
+            for (int j = i + 1; j < net->n_ops && ng < 4; ++j) {
                 const osn_net_op& c = net->ops[j];
                 bool from_j = false;
                 if (c.src == o.dst && c.need_dgrad) { gsrc[ng] = reinterpret_cast<const float*>(B + L.gin_off[j]); gld[ng] = c.cin; ++ng; from_j = true; }
@@ -505,8 +508,11 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
             float* gxw = reinterpret_cast<float*>(B + L.gx_off[i]);
             float* gres = o.res >= 0 ? reinterpret_cast<float*>(B + L.gres_off[i]) : nullptr;
             OSN_REQUIRE(bn.ggamma && bn.gbeta, OSN_E_ARG, "osn_net_backward: op %d: null batch-norm gradient pointers", i);
-            rc = osn_bn_backward_multi(x, y, gsrc, gld, ng, mean, var, bn.gamma, bn.eps, o.relu, run->training, gxw, gres,
-                                       bn.ggamma, bn.gbeta, n_out, o.cout, r->ws, size_t(r->ws_bytes), sstream);
+            // bn -> relu without a residual: the mask is recomputed from x, y is not read (one tensor less per backward kernel)
+            const bool from_x = o.relu && o.res < 0 && bn.beta;
+            rc = osn_bn_backward_multi2(x, from_x ? nullptr : y, gsrc, gld, ng, mean, var, bn.gamma, from_x ? bn.beta : nullptr, bn.eps,
+                                        o.relu, run->training, gxw, gres, bn.ggamma, bn.gbeta, n_out, o.cout, r->ws, size_t(r->ws_bytes),
+                                        sstream);
             if (rc) return rc;
             gx = gxw;
         } else {

@@ -38,6 +38,7 @@ class FlatGradAllReduce(object):
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self._pending, self._sliced = [], None
         self.buffers = [b for b in module.buffers() if b.is_floating_point()] if broadcast_buffers else []
         self.int_buffers = [b for b in module.buffers() if not b.is_floating_point()] if broadcast_buffers else []
         # rank 0's parameters (ALL of them, frozen ones included: DDP syncs the whole module state) and buffers
@@ -87,6 +88,38 @@ class FlatGradAllReduce(object):
             base = b
         return base
 
+    # ---- overlapped exchange of the executor's flat gradient buffer --------------------------------------------
+    def attach(self, executor, segments=4):
+        """Exchange the executor's convolution weight gradients in `segments` pieces WHILE the backward pass runs: the pass
+        is played in that many segments (highest ops first) and each finished slice is all-reduced asynchronously; what is
+        left for reduce_gradients() is the batch-norm region and the wait.  Same values as the one-collective exchange
+        (mean over ranks; a sum's chunking does not change its elements)."""
+        executor.grad_segments = max(1, int(segments))
+        executor._cuts = None
+        executor.grad_ready_hook = self._on_slice
+        self._pending = []
+        self._sliced = None
+
+    def _avg(self, t, async_op):
+        """t <- mean over ranks.  RCCL averages inside the collective (no separate division launch); gloo gets div + sum."""
+        if not self.collectives:
+            return None
+        backend = dist.get_backend(self.group)
+        if backend == "nccl":
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+        if self.world > 1:
+            t.div_(self.world)
+        return dist.all_reduce(t, group=self.group, async_op=async_op)
+
+    def _on_slice(self, flat, lo, hi, last):
+        if self._sliced is None or self._sliced[0] is not flat:
+            self._sliced = [flat, hi, hi]              # [buffer, lowest float exchanged so far, end of the kernels' region]
+        if hi > lo:
+            w = self._avg(flat[lo:hi], async_op=True)
+            if w is not None:
+                self._pending.append(w)
+        self._sliced[1] = min(self._sliced[1], lo)
+
     def reduce_gradients(self):
         """After backward: p.grad <- mean over ranks, as views of the flat buffer (no copy back).
         A parameter without a gradient on this rank contributes zeros (DDP with find_unused_parameters) and, like
@@ -97,10 +130,20 @@ class FlatGradAllReduce(object):
         # in place: exchange that buffer itself -- no gather copy, the optimizer keeps reading the same views
         base = self._common_base()
         if base is not None:
-            if self.collectives:
-                if self.world > 1:
-                    base.div_(self.world)
-                dist.all_reduce(base, group=self.group)
+            sl = getattr(self, "_sliced", None)
+            if sl is not None and sl[0] is base:
+                # slices [sl[1], sl[2]) went out during the backward pass: what is left is the head of the kernels' region
+                # (nothing, normally) and the batch-norm region behind it
+                if sl[1] > 0:
+                    self._avg(base[:sl[1]], async_op=False)
+                if sl[2] < base.numel():
+                    self._avg(base[sl[2]:], async_op=False)
+                for w in self._pending:
+                    w.wait()
+                self._pending = []
+                self._sliced = None
+                return
+            self._avg(base, async_op=False)
             return
         grads = []
         for p, v in zip(self.params, self.views):
@@ -114,9 +157,6 @@ class FlatGradAllReduce(object):
         same = all(g.data_ptr() == v.data_ptr() for g, v in zip(src, dst))
         if not same:
             torch._foreach_copy_(dst, src)          # one multi-tensor copy into the flat buffer
-        if self.collectives:
-            if self.world > 1:
-                self.flat.div_(self.world)
-            dist.all_reduce(self.flat, group=self.group)
+        self._avg(self.flat, async_op=False)
         for p, v in zip(self.params, self.views):
             p.grad = v

@@ -194,6 +194,11 @@ class UNetExecutor:
                            _ptr(self._kw), _ptr(self._img))
         self._rows = np.zeros(8, np.int64)
         self.prof = None                  # osn_prof_t* (bench.py), or None
+        # gradient exchange (openscene_amd.distributed): hook(flat_gradients, first_float, end_float, last) is called after each
+        # of `grad_segments` segments of the backward pass with the slice of convolution weight gradients that segment finished
+        self.grad_ready_hook = None
+        self.grad_segments = 4
+        self._cuts = None
         self._events = {}                 # device index -> osn_events_t* (fork / join of the backward pass)
         # gradient layout: one flat fp32 buffer, every parameter's slice starts on a 16-byte boundary
         self.grad_off, off = [], 0
@@ -201,6 +206,7 @@ class UNetExecutor:
             self.grad_off.append(off)
             off += (prm.numel() + 3) // 4 * 4
         self.grad_total = off
+        self.conv_grad_end = self.grad_off[len(p.convs)] if len(self.grad_off) > len(p.convs) else off   # end of the kernels' region
 
     # -------------------------------------------------------------------------------------------- eligibility
     def usable(self, x, model=None):
@@ -409,9 +415,36 @@ class UNetExecutor:
                    ops.tl_counters(dev).data_ptr(), int(st.training), 0, len(p.ops), 0, self.prof,
                    side if events else None, ws2.data_ptr() if (events and ws2 is not None) else None,
                    ws2.numel() if (events and ws2 is not None) else 0, events, rows_pos, rows_idx, rows_g, n_rows)
+        hook = self.grad_ready_hook
         with ops._Dev(dev):
-            check(lib.osn_net_backward(ctypes.addressof(self.desc), ctypes.addressof(run), ops._stream(dev)), "osn_net_backward")
+            if hook is None:
+                check(lib.osn_net_backward(ctypes.addressof(self.desc), ctypes.addressof(run), ops._stream(dev)), "osn_net_backward")
+            else:
+                # the pass in segments, highest ops first; after each, the weight-gradient slices of its convolutions are final
+                # (every segment ends with the join of the weight-gradient stream) and the hook may start exchanging them
+                hi = len(p.ops)
+                for lo in self.backward_cuts():
+                    run.first_op, run.end_op = lo, hi
+                    check(lib.osn_net_backward(ctypes.addressof(self.desc), ctypes.addressof(run), ops._stream(dev)), "osn_net_backward")
+                    hook(grads, self.grad_off[lo], self.grad_off[hi] if hi < nc else self.conv_grad_end, lo == 0)
+                    hi = lo
         return [grads[o:o + q.numel()].view_as(q) for o, q in zip(self.grad_off, p.params)]
+
+    def backward_cuts(self):
+        """First ops of the backward segments (descending, ending with 0): about equal shares of the convolution weights."""
+        if self._cuts is None:
+            p = self.program
+            nc = len(p.convs)
+            sizes = [c.kernel.numel() for c in p.convs]
+            total, target = float(sum(sizes)), float(sum(sizes)) / max(1, self.grad_segments)
+            cuts, acc = [], 0.0
+            for i in range(nc - 1, 0, -1):
+                acc += sizes[i]
+                if acc >= target and len(cuts) < self.grad_segments - 1:
+                    cuts.append(i)
+                    acc = 0.0
+            self._cuts = cuts + [0]
+        return self._cuts
 
     def kernels(self, rows, training=True):
         """[(op index, forward kernel, input-gradient kernel, weight-gradient kernel)] names for the given level sizes."""

@@ -197,17 +197,18 @@ class BatchNormActFunction(Function):
         else:
             mean, var = running_mean, running_var
             y = ops.bn_apply(x, mean, var, gamma, beta, eps, residual, relu)
-        ctx.save_for_backward(x, y if relu else None, mean, var, gamma)
+        # bn -> relu without a residual: the backward pass recomputes the mask (y > 0) from x instead of reading y
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, var, gamma, beta if relu else None)
         ctx.cfg = (bool(training), float(eps), bool(relu), residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, y, mean, var, gamma = ctx.saved_tensors
+        x, y, mean, var, gamma, beta = ctx.saved_tensors
         training, eps, relu, has_res = ctx.cfg
         want_gres = has_res and ctx.needs_input_grad[5]
         gx, gres, ggamma, gbeta = ops.bn_backward(x, y, gy.contiguous(), mean, var, gamma, eps, relu, training,
-                                                  want_gres)
+                                                  want_gres, beta=beta if (relu and not has_res) else None)
         return gx, ggamma, gbeta, None, None, gres, None, None, None, None
 
 

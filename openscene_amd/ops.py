@@ -984,22 +984,9 @@ def bn_forward_train(x, gamma, beta, eps, residual, relu, running_mean, running_
     return y, mv[0], mv[1]
 
 
-def bn_backward(x, y, gy, mean, var, gamma, eps, relu, training, want_gres):
-    dev = x.device
-    lib = _prep(dev)
-    gy = _f32c(gy, "grad_output")
-    n, c = x.shape
-    gx = torch.empty_like(x)
-    gres = torch.empty_like(x) if want_gres else None
-    ggamma = torch.empty(c, dtype=torch.float32, device=dev)
-    gbeta = torch.empty(c, dtype=torch.float32, device=dev)
-    wsb = _cached("osn_bn_ws_bytes", n, c)
-    ws = _ws(wsb, dev)
-    with _Dev(dev):
-        check(lib.osn_bn_backward(_p(x), _p(y), _p(gy), _p(mean), _p(var), _p(gamma), float(eps), int(bool(relu)),
-                                  int(bool(training)), _p(gx), _p(gres), _p(ggamma), _p(gbeta), n, c, _p(ws),
-                                  ws.numel(), _stream(dev)), "osn_bn_backward")
-    return gx, gres, ggamma, gbeta
+def bn_backward(x, y, gy, mean, var, gamma, eps, relu, training, want_gres, beta=None):
+    """beta given and y None (batch norm + ReLU without a residual): the ReLU mask is recomputed from x, y is not read."""
+    return bn_backward_multi(x, y, [_f32c(gy, "grad_output")], mean, var, gamma, eps, relu, training, want_gres, beta=beta)
 
 
 def _row_view(t, c, name):
@@ -1032,12 +1019,14 @@ def bn_forward_train2(x, gamma, beta, eps, residual, relu, running_mean, running
     return y, mv[0], mv[1]
 
 
-def bn_backward_multi(x, y, gys, mean, var, gamma, eps, relu, training, want_gres):
+def bn_backward_multi(x, y, gys, mean, var, gamma, eps, relu, training, want_gres, beta=None):
     """bn_backward whose incoming gradient is the SUM of the matrices in `gys` (1 .. 3, each possibly a column window of a
-    wider matrix): the sum is formed while reading."""
+    wider matrix): the sum is formed while reading.  y None with relu needs beta (mask recomputed from x; no residual)."""
     dev = x.device
     lib = _prep(dev)
     n, c = x.shape
+    if relu and y is None and (beta is None or want_gres):
+        raise ValueError("batch-norm backward with ReLU needs y, or beta and no residual")
     views = [_row_view(g, c, "grad_output[%d]" % i) for i, g in enumerate(gys)]
     ptrs = (ctypes.c_void_p * len(views))(*[v[0] for v in views])
     lds = (ctypes.c_int64 * len(views))(*[v[1] for v in views])
@@ -1047,9 +1036,10 @@ def bn_backward_multi(x, y, gys, mean, var, gamma, eps, relu, training, want_gre
     gbeta = torch.empty(c, dtype=torch.float32, device=dev)
     ws = _ws(_cached("osn_bn_ws_bytes", n, c), dev)
     with _Dev(dev):
-        check(lib.osn_bn_backward_multi(_p(x), _p(y), ptrs, lds, len(views), _p(mean), _p(var), _p(gamma), float(eps),
-                                        int(bool(relu)), int(bool(training)), _p(gx), _p(gres), _p(ggamma), _p(gbeta), n, c,
-                                        _p(ws), ws.numel(), _stream(dev)), "osn_bn_backward_multi")
+        check(lib.osn_bn_backward_multi2(_p(x), _p(y), ptrs, lds, len(views), _p(mean), _p(var), _p(gamma),
+                                         _p(beta) if (relu and y is None) else None, float(eps),
+                                         int(bool(relu)), int(bool(training)), _p(gx), _p(gres), _p(ggamma), _p(gbeta), n, c,
+                                         _p(ws), ws.numel(), _stream(dev)), "osn_bn_backward_multi2")
     return gx, gres, ggamma, gbeta
 
 

@@ -330,7 +330,9 @@ def bn_apply(x, mean, var, gamma, beta, eps, residual=None, relu=False):
     return F.relu(y) if relu else y
 
 
-def bn_backward(x, y, gy, mean, var, gamma, eps, relu, training, want_gres):
+def bn_backward(x, y, gy, mean, var, gamma, eps, relu, training, want_gres, beta=None):
+    if relu and y is None:          # mask recomputed from x (bn -> relu without a residual), as the HIP kernels do
+        y = (x - mean) * torch.rsqrt(var + eps) * gamma + beta
     g = gy * (y > 0).to(gy.dtype) if relu else gy
     invstd = torch.rsqrt(var + eps)
     xhat = (x - mean) * invstd

@@ -279,3 +279,55 @@ def test_flat_exchange_reduces_the_executors_gradient_buffer_in_place(tmp_path):
     b = torch.load(os.path.join(tmp_path, "v1.pt"))
     for ga, gb, o in zip(a["g"], b["g"], a["offs"]):
         assert torch.equal(ga, gb) and torch.equal(ga, torch.full_like(ga, 1.5 * (o + 1)))
+
+
+def _worker_sliced(rank, world, port, out_dir):
+    """The overlapped exchange on a stand-in for the executor: a backward pass played in segments calls the hook with the
+    slice of kernel gradients each segment finished (highest ops first); reduce_gradients() sends what is left."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    from openscene_amd.distributed import FlatGradAllReduce
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(*[torch.nn.Linear(7, 7) for _ in range(6)])
+    ex = FlatGradAllReduce(net)
+
+    class FakeExecutor:
+        grad_ready_hook = None
+        grad_segments = 1
+        _cuts = None
+    fake = FakeExecutor()
+    ex.attach(fake, segments=3)
+    assert fake.grad_ready_hook is not None and fake.grad_segments == 3
+    # the executor's layout: every weight first ("kernels"), then the biases ("batch-norm region"), 4-float aligned slices
+    params = [m.weight for m in net] + [m.bias for m in net]
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + 3) // 4 * 4
+    kernels_end = offs[6]
+    for step in range(2):                                   # two steps: the state of the exchange resets between them
+        flat = torch.full((off,), float("nan"))
+        for p, o in zip(params, offs):
+            v = flat[o:o + p.numel()].view_as(p)
+            v.copy_(torch.full_like(p, float(rank + 1 + step)) * (o + 1))
+            p.grad = v
+        for lo_i, hi_i in ((4, 6), (2, 4), (0, 2)):          # segments, highest "ops" first
+            fake.grad_ready_hook(flat, offs[lo_i], offs[hi_i] if hi_i < 6 else kernels_end, lo_i == 0)
+        ex.reduce_gradients()
+        assert all(p.grad._base is flat for p in params), "gradients were copied"
+        assert ex._pending == [] and ex._sliced is None
+    torch.save({"g": [p.grad.clone() for p in params], "offs": offs}, os.path.join(out_dir, "s%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sliced_exchange_during_a_segmented_backward_pass(tmp_path):
+    """the all-reduce goes out in pieces as the backward pass finishes them; every element ends up as the
+    mean over ranks exactly as with the one-collective exchange."""
+    mp.spawn(_worker_sliced, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(tmp_path, "s0.pt"))
+    b = torch.load(os.path.join(tmp_path, "s1.pt"))
+    for ga, gb, o in zip(a["g"], b["g"], a["offs"]):
+        assert torch.equal(ga, gb) and torch.equal(ga, torch.full_like(ga, 2.5 * (o + 1)))     # step 1: mean of 2 and 3

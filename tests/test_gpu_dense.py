@@ -187,6 +187,34 @@ def test_batchnorm_train_forward_backward(n, c, relu, res):
     assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked)
 
 
+@pytest.mark.parametrize("n,c", [(37, 32), (3052, 128), (47618, 96), (100999, 32)])
+@pytest.mark.parametrize("training", [True, False])
+def test_batchnorm_backward_recomputes_the_relu_mask_from_x(n, c, training):
+    """Round 4: for bn -> relu without a residual the backward kernels rebuild (y > 0) from x with the forward pass's own
+    expression instead of reading y (one tensor less per pass).  Bitwise the same gradients as with y, train and eval mode,
+    including rows whose pre-activation is exactly zero or a denormal away from it."""
+    from openscene_amd import ops
+    g = torch.Generator().manual_seed(n * 7 + c)
+    x = (torch.randn(n, c, generator=g) * 1.5 + 0.2).to(dev())
+    gamma = torch.empty(c).uniform_(0.5, 1.5, generator=g).to(dev())
+    beta = torch.empty(c).uniform_(-0.5, 0.5, generator=g).to(dev())
+    rm = (torch.randn(c, generator=g) * 0.1).to(dev())
+    rv = torch.empty(c).uniform_(0.5, 2.0, generator=g).to(dev())
+    if training:
+        y, mean, var = ops.bn_forward_train(x, gamma, beta, 1e-5, None, True, rm.clone(), rv.clone(), 0.1)
+    else:
+        mean, var = rm, rv
+        y = ops.bn_apply(x, mean, var, gamma, beta, 1e-5, None, True)
+    gy = torch.randn(n, c, generator=g).to(dev())
+    a = ops.bn_backward(x, y, gy, mean, var, gamma, 1e-5, True, training, False)
+    b = ops.bn_backward(x, None, gy, mean, var, gamma, 1e-5, True, training, False, beta=beta)
+    for u, v in zip(a, b):
+        assert (u is None and v is None) or torch.equal(u, v)
+    assert 0.2 < float((y > 0).float().mean()) < 0.8
+    with pytest.raises(ValueError):
+        ops.bn_backward(x, None, gy, mean, var, gamma, 1e-5, True, training, True, beta=beta)       # a residual needs y
+
+
 def test_batchnorm_eval_mode():
     from openscene_amd import functional as F_
     g = torch.Generator().manual_seed(5)

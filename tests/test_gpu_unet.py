@@ -204,6 +204,42 @@ def test_row_sparse_head_gradients_equal_the_dense_path(kind, monkeypatch):
         assert rel_l2(g_sparse[k], g_torch[k]) <= (2e-5 if kind == "cosine" else 2e-4), k
 
 
+def test_segmented_backward_pass_is_bitwise_the_single_call(monkeypatch):
+    """The backward pass played in 4 segments (what an attached gradient exchange does, distributed.FlatGradAllReduce.attach):
+    the hook sees disjoint slices that tile the kernels' region of the flat gradient buffer, highest ops first, and every
+    gradient is bitwise the one-call pass's."""
+    from openscene_amd import executor as E
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import SparseTensor
+    torch.manual_seed(21)
+    model = mink_unet(3, 64, 3, "MinkUNet18A").to(dev()).train()
+    coords = torch.from_numpy(scene_coords(3, 20000, 0.04)).to(dev())
+    feats = torch.rand(coords.shape[0], 3, device=dev())
+    ex = E.for_model(model)
+
+    def grads(hook, segments=4):
+        ex.grad_ready_hook, ex.grad_segments, ex._cuts = hook, segments, None
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.reset_running_stats()
+        model.zero_grad(set_to_none=True)
+        out = model(SparseTensor(feats, coords))
+        out.square().mean().backward()
+        return [p.grad.detach().clone() for p in model.parameters()]
+
+    try:
+        ref = grads(None)
+        seen = []
+        got = grads(lambda flat, lo, hi, last: seen.append((lo, hi, last, flat.data_ptr())))
+    finally:
+        ex.grad_ready_hook = None
+    assert len(seen) == 4 and [s[2] for s in seen] == [False, False, False, True]
+    assert seen[0][1] == ex.conv_grad_end and seen[-1][0] == 0 and all(a[0] == b[1] for a, b in zip(seen[:-1], seen[1:]))
+    assert len({s[3] for s in seen}) == 1
+    for (n, _), a, b in zip(model.named_parameters(), ref, got):
+        assert torch.equal(a, b), n
+
+
 def test_executor_equals_the_module_path(monkeypatch):
     """The executor plays the same kernels in the same order as the per-module path: forward outputs, feature taps and
     running statistics are BITWISE equal, in training and in evaluation mode; parameter gradients agree to fp32
