@@ -34,7 +34,7 @@ static inline uint64_t up256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
 
 static bool stem_eligible(int K, int cin, int cout) { return cin <= 4 && cout == 32 && K > 1 && K <= 125; }
 static bool tl_eligible(int K, int cin, int cout, int64_t n_in) {
-    return (cin & 3) == 0 && cin >= 8 && (cout & 3) == 0 && K <= 128 && n_in <= (int64_t(1) << 24);
+    return (cin & 3) == 0 && cin >= 8 && cin <= 512 && (cout & 3) == 0 && K <= 128 && n_in <= (int64_t(1) << 24);
 }
 // functional.tl_rows_ok: a table big enough for the tile-list kernel (always from tl_min_rows rows on; from tl_mid_rows on
 // when both channel counts are at least 96)

@@ -41,7 +41,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TL_BMAX = 88;       // rows per tile at most (LDS budget of the 128-column instance, 2 workgroups / CU)
 constexpr int TL_BMIN = 32;       // rows per tile of small tables
-constexpr int TL_LCAP = 1536;     // packed list entries resident in LDS per batch of offsets
+constexpr int TL_LCAP = 1024;     // packed list entries resident in LDS per batch of offsets
+constexpr int TL_STEPS = TL_LCAP / 32 * 4;   // step-table entries: 32-pair steps of a batch x channel chunks (<= 4: 512 channels)
 constexpr int TL_KMAX = 128;      // kernel offsets a list-mode launch can take (5^3 = 125)
 constexpr int TL_SLOTS = 512;     // persistent workgroups per column group (2 per CU)
 
@@ -99,6 +100,29 @@ __global__ void weight_prep_tl_kernel(const float* __restrict__ W, int K, int ci
     }
 }
 
+// fp32 x 4 -> the three bf16 pieces of every element (x = h1 + h2 + h3 exactly; round to nearest), two elements per instruction
+__device__ __forceinline__ void tl_split4(const float4 x, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const f2 v[2] = {f2{x.x, x.y}, f2{x.z, x.w}};
+    u2 q1, q2, q3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const b2 h1 = __builtin_convertvector(v[j], b2);
+        const uint32_t u1 = __builtin_bit_cast(uint32_t, h1);
+        const f2 r1 = v[j] - f2{__builtin_bit_cast(float, u1 << 16), __builtin_bit_cast(float, u1 & 0xFFFF0000u)};
+        const b2 h2 = __builtin_convertvector(r1, b2);
+        const uint32_t u2_ = __builtin_bit_cast(uint32_t, h2);
+        const f2 r2 = r1 - f2{__builtin_bit_cast(float, u2_ << 16), __builtin_bit_cast(float, u2_ & 0xFFFF0000u)};
+        const b2 h3 = __builtin_convertvector(r2, b2);
+        q1[j] = u1; q2[j] = u2_; q3[j] = __builtin_bit_cast(uint32_t, h3);
+    }
+    p1 = __builtin_bit_cast(bf16x4, q1);
+    p2 = __builtin_bit_cast(bf16x4, q2);
+    p3 = __builtin_bit_cast(bf16x4, q3);
+}
+
 // ------------------------------------------------------------------------------------------ conv
 struct TlIter {
     int a;        // offset index in klist
@@ -123,7 +147,7 @@ struct TlIter {
 // (B fragments of a chunk: KS k-steps x 2 column blocks x 3 planes = 24 KS VGPRs).  KS is the k-step count that
 // tiles the input channels without a remainder where one exists (96 channels: KS = 3 -- with the fixed 128-channel
 // chunk of round 2 a quarter of the weight-fragment loads and of the gather lanes of every 96-channel conv was padding).
-template <int NW, int KS, bool PROF = false>
+template <int NW, int KS, bool RAGGED, bool PROF = false>
 __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restrict__ in, const bf16x8* __restrict__ Wp,
                                                                const int32_t* __restrict__ cnt, const int2* __restrict__ lst,
                                                                const int32_t* __restrict__ out_rows, float* __restrict__ out,
@@ -146,6 +170,14 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
     __shared__ int kcnt[TL_KMAX];
     __shared__ int lstart[TL_KMAX + 1];       // first plist slot of each offset of the current batch
     __shared__ unsigned char gowner[TL_LCAP / 32];
+    // Round 4: the batch's (offset, chunk, step) sequence as a TABLE, written once per batch by one thread per offset:
+    //   x = first plist slot of the step   y = pairs of the step (1 .. 32) | first step of its (offset, chunk) << 8 | first
+    //   k-step of the chunk << 16          z = 1 KB weight block of (offset, chunk): (k ns + s0) ncb
+    // Round 3's loop advanced three iterators per step through LDS look-ups (pairs, list start and offset of the current
+    // list entry, each a dependent read + readfirstlane) and rebuilt every weight-fragment address from scalars: 220 scalar
+    // and 35 wait instructions per 72 MFMAs.  The kernel is bound by instruction issue (with every byte of memory traffic
+    // removed it runs 149 instead of 173 us, profiles/r04_s2_*), so the control path is what there is to cut.
+    __shared__ uint4 stab[TL_STEPS];
     __shared__ int nact_s, bend_s, tile_s;
 
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -167,6 +199,16 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
 
     bf16x8 B[KS][2][3];
     float4 P0[NQ], P1[NQ];
+    // RAGGED = false: every channel chunk is full (every MinkUNet width) -- no channel masks, no fragment selects in the loop
+    constexpr bool ragged = RAGGED;
+    // a fragment load is ONE instruction: scalar base of (offset, chunk, k-step, plane) + this lane's byte offset inside the
+    // column block (two registers: one per column block of the wave).  Column blocks past the weight are never stored: they
+    // read block 0 instead (valid memory).
+    uint32_t boff[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) boff[nb] = (cb0 + nb < ncb ? unsigned(cb0 + nb) : 0u) * 1024u + 16u * unsigned(lane);
+    const uint32_t plane_bytes = unsigned(K) * unsigned(ns) * unsigned(ncb) * 1024u;      // one bf16 piece of the whole weight
+    const uint32_t kstep_bytes = unsigned(ncb) * 1024u;
 
     for (;;) {
         // ---- draw the next tile (densest first: a tile-ordered table has the rows with most neighbours last)
@@ -257,76 +299,75 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                 for (int e = tid; e < E; e += NT)
                     plist[e] = e < rows ? ((uint32_t(e) << 24) | uint32_t(row0 + e)) : (uint32_t(TL_BMAX) << 24);
             }
+            // step table of the batch: offset a owns entries [nchunk (lstart[a] / 32), + nchunk niter(a)), chunk-major
+            const int nchunk = (ns + KS - 1) / KS;
+            for (int a = a0 + tid; a < a1; a += NT) {
+                const int np = kcnt[a], niter = (np + 31) >> 5, l0 = lstart[a];
+                const int kk = cnt ? klist[a] : 0;
+                int t = nchunk * (l0 >> 5);
+                for (int c = 0; c < nchunk; ++c)
+                    for (int g = 0; g < niter; ++g, ++t)
+                        stab[t] = make_uint4(uint32_t(l0 + 32 * g), uint32_t(min(32, np - 32 * g)) | (g == 0 ? 0x100u : 0u) | (uint32_t(c * KS) << 16),
+                                             uint32_t((kk * ns + c * KS) * ncb), 0u);
+            }
+            const int T = nchunk * (E >> 5);
             __syncthreads();
             TL_TICK(1)                                     // 1: batch list load
 
-            // ---- flat pipeline over the (offset, chunk, step) sequence of the batch
-            auto first = [&](int a) {
-                TlIter it;
-                it.a = a; it.s0 = 0; it.g = 0;
-                it.np = a < a1 ? __builtin_amdgcn_readfirstlane(kcnt[a]) : 0;
-                it.niter = (it.np + 31) >> 5;
-                return it;
+            // ---- flat pipeline over the step table of the batch
+            struct Step {
+                int base, fl, blk0;           // stab entry (scalars); base < 0: past the end
+                __device__ bool valid() const { return base >= 0; }
+                __device__ int np() const { return fl & 0xFF; }
+                __device__ bool first() const { return (fl & 0x100) != 0; }
+                __device__ int s0() const { return fl >> 16; }
             };
-            auto advance = [&](TlIter& it) {
-                if (++it.g == it.niter) {
-                    it.g = 0;
-                    it.s0 += KS;
-                    if (it.s0 >= ns) {
-                        it.s0 = 0;
-                        ++it.a;
-                        it.np = it.a < a1 ? __builtin_amdgcn_readfirstlane(kcnt[it.a]) : 0;
-                        it.niter = (it.np + 31) >> 5;
-                    }
+            auto entry = [&](int t) {
+                Step e;
+                if (t < T) {
+                    const uint4 v = stab[t];
+                    e.base = __builtin_amdgcn_readfirstlane(int(v.x));
+                    e.fl = __builtin_amdgcn_readfirstlane(int(v.y));
+                    e.blk0 = __builtin_amdgcn_readfirstlane(int(v.z));
+                } else {
+                    e.base = -1; e.fl = 0; e.blk0 = 0;
                 }
+                return e;
             };
             // gather of one step: 32 list entries x up to 128 channels, one 16-byte load per quad (unconditional,
             // clamped address; masked at conversion time)
-            auto fetch = [&](const TlIter& it, float4 (&P)[NQ]) {
-                const int base = __builtin_amdgcn_readfirstlane(lstart[it.a]) + 32 * it.g;
+            auto fetch = [&](const Step& it, float4 (&P)[NQ]) {
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) {
-                    const unsigned row = plist[base + q_row[j]] & 0xFFFFFFu;
-                    const int ch = 32 * it.s0 + q_col[j];
+                    const unsigned row = plist[it.base + q_row[j]] & 0xFFFFFFu;
+                    const int ch = 32 * it.s0() + q_col[j];
                     const unsigned cu = ch < cin ? unsigned(ch) : 0u;
                     P[j] = *reinterpret_cast<const float4*>(in + (uint64_t(row) * unsigned(cin) + cu));
                 }
             };
-            auto step = [&](const TlIter& it, float4 (&P)[NQ], const TlIter& nf) {
-                // ---- split the fetched quads into three bf16 pieces (registers)
+            auto step = [&](const Step& it, float4 (&P)[NQ], const Step& nf) {
+                // ---- split the fetched quads into three bf16 pieces (registers), two elements per conversion; channels past
+                // the input (only when cin is not a multiple of the chunk) are zeroed first
                 bf16x4 p1[NQ], p2[NQ], p3[NQ];
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) {
-                    const bool ok = 32 * it.s0 + q_col[j] < cin;
-                    const float x[4] = {P[j].x, P[j].y, P[j].z, P[j].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = ok ? x[e] : 0.f;
-                        const __bf16 h1 = (__bf16)v;
-                        const float r1 = v - (float)h1;
-                        const __bf16 h2 = (__bf16)r1;
-                        const float r2 = r1 - (float)h2;
-                        p1[j][e] = h1; p2[j][e] = h2; p3[j][e] = (__bf16)r2;
-                    }
+                    float4 v = P[j];
+                    if (ragged && !(32 * it.s0() + q_col[j] < cin)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    tl_split4(v, p1[j], p2[j], p3[j]);
                 }
                 TL_TICK(2)                                 // 2: wait for the gathered rows + split
                 // ---- new (offset, chunk): B fragments of this wave's 32 columns, one coalesced 1 KB load each
-                if (it.g == 0 && wave < NW) {
-                    const int k = __builtin_amdgcn_readfirstlane(klist[it.a]);    // wave-uniform: scalar address math
+                if (it.first() && wave < NW) {
+                    const char* ub = reinterpret_cast<const char*>(Wp) + (size_t(it.blk0) << 10);     // wave-uniform
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) {
-                            // k-steps past the last chunk are never multiplied and column blocks past the weight feed
-                            // output columns that are never stored: load block 0 instead (valid memory), and do NOT
-                            // touch the loaded value here (a use would make the compiler wait before the barrier)
-                            const bool on = it.s0 + ks < ns && cb0 + nb < ncb;
-                            const unsigned sb = on ? unsigned(it.s0 + ks) : 0u, cb = on ? unsigned(cb0 + nb) : 0u;
+                        for (int pl = 0; pl < 3; ++pl) {
+                            // k-steps past the last chunk (ragged only) are never multiplied: any valid block will do (ks 0's)
+                            const int kk = (!ragged || it.s0() + ks < ns) ? ks : 0;
+                            const char* up = ub + (size_t(pl) * plane_bytes + size_t(kk) * kstep_bytes);     // scalar
 #pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) {
-                                const unsigned blk = (unsigned(pl * K + k) * unsigned(ns) + sb) * unsigned(ncb) + cb;   // 1 KB blocks
-                                B[ks][nb][pl] = (Wp + (size_t(blk) << 6))[lane];
-                            }
+                            for (int nb = 0; nb < 2; ++nb) B[ks][nb][pl] = *reinterpret_cast<const bf16x8*>(up + boff[nb]);
                         }
                 }
                 TL_TICK(8)                                 // 8: B-load issue
@@ -340,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                         *reinterpret_cast<bf16x4*>(&stage[2][q_row[j]][q_col[j]]) = p3[j];
                     }
                 }
-                if (nf.a < a1) fetch(nf, P);               // ahead of time; in flight during the MFMAs below
+                if (nf.valid()) fetch(nf, P);              // ahead of time; in flight during the MFMAs below
                 TL_TICK(9)                                 // 9: stage write + next gather issue
                 __syncthreads();                           // stage ready
                 TL_TICK(4)                                 // 4: barrier B
@@ -348,16 +389,32 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                 // ---- 32 pairs x 32 columns per wave: accumulator blocks [pair half][column block]
                 // (the last step of an offset may hold at most 16 pairs -- the average (tile, offset) of a 100 k-row map
                 // has 36 -- : its second 16-pair half is all padding and is skipped: MFMAs, fragment reads, tile update)
-                const bool half1 = it.np - 32 * it.g > 16;          // wave-uniform
+                const bool half1 = it.np() > 16;                    // wave-uniform
+                // Round 4: the accumulators START from the output tile's cells and are stored back after the last MFMA.  The
+                // MFMAs take the WEIGHT fragment as their first operand and the staged rows as the second (same registers either
+                // way round: both fragment layouts are [16 rows or columns][8 k per lane group]), i.e. they produce the block
+                // TRANSPOSED: lane l holds columns 4 (l >> 4) .. + 3 of pair l & 15 -- four consecutive floats of one output row,
+                // one 16-byte LDS access.  Round 3 added the finished block in a separate read-add-write phase, which the
+                // compiler turned into a chain of eight dependent 8-byte LDS round trips (it could not prove the 16-byte
+                // alignment): 920 of a step's 7 100 clocks.  Now the tile cells are read while the fragments are, and written
+                // once.  (Within one offset an output row occurs at most once and a wave owns its columns: no other access to
+                // these cells between the read and the write.)
+                const int pbase = it.base + (lane & 15);
+                int ocell[2];
                 f32x4 acc[2][2];
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 0 || half1) {
+                        ocell[h] = int(plist[pbase + 16 * h] >> 24) * S + 32 * wave + 4 * (lane >> 4);
+                        const f32x4* cell = reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&otile[ocell[h]], 16));
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) acc[h][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        for (int nb = 0; nb < 2; ++nb) acc[h][nb] = cell[4 * nb];
+                    }
+                }
                 const int akq = 8 * (lane >> 4);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    if (it.s0 + ks < ns) {
+                    if (!ragged || it.s0() + ks < ns) {
                         bf16x8 af[2][3];
 #pragma unroll
                         for (int h = 0; h < 2; ++h)
@@ -393,56 +450,32 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) sink += acc[h][nb][0];
+                        for (int nb = 0; nb < 2; ++nb)
+                            if (h == 0 || half1) sink += acc[h][nb][0];
                     asm volatile("" ::"v"(sink));
                 }
-                TL_TICK(5)                                 // 5: B-load wait + fragment reads + MFMAs
-                // ---- add the result blocks into the output tile.  The MFMAs above take the WEIGHT fragment as their first
-                // operand and the staged rows as the second (same registers either way round: both fragment layouts are
-                // [16 rows or columns][8 k per lane group]), i.e. they produce the block TRANSPOSED: lane l holds columns
-                // 4 (l >> 4) .. + 3 of pair l & 15 -- four CONSECUTIVE floats of one output row, one 16-byte LDS access instead
-                // of four 4-byte ones (round 3: the tile update was 13 % of a step).  All reads first, then all writes: a lane's
-                // cells are distinct -- one output row per pair within an offset -- but the compiler cannot know, and a
-                // read-add-write chain per cell would serialise the LDS round trips.
-                const int pbase = __builtin_amdgcn_readfirstlane(lstart[it.a]) + 32 * it.g + (lane & 15);
-                auto update = [&](auto nh) {                // nh halves: all reads, then all writes
-                    constexpr int NH = decltype(nh)::value;
-                    int ocell[NH];
+                TL_TICK(5)                                 // 5: B-load wait + tile / fragment reads + MFMAs
 #pragma unroll
-                    for (int h = 0; h < NH; ++h) ocell[h] = int(plist[pbase + 16 * h] >> 24) * S + 32 * wave + 4 * (lane >> 4);
-                    float4 cur[NH][2];
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 0 || half1) {
+                        f32x4* cell = reinterpret_cast<f32x4*>(__builtin_assume_aligned(&otile[ocell[h]], 16));
 #pragma unroll
-                    for (int h = 0; h < NH; ++h)
-#pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) cur[h][nb] = *reinterpret_cast<const float4*>(&otile[ocell[h] + 16 * nb]);
-#pragma unroll
-                    for (int h = 0; h < NH; ++h)
-#pragma unroll
-                        for (int nb = 0; nb < 2; ++nb)
-                            *reinterpret_cast<float4*>(&otile[ocell[h] + 16 * nb]) =
-                                make_float4(cur[h][nb].x + acc[h][nb][0], cur[h][nb].y + acc[h][nb][1], cur[h][nb].z + acc[h][nb][2],
-                                            cur[h][nb].w + acc[h][nb][3]);
-                };
-                if (half1) update(std::integral_constant<int, 2>{});
-                else update(std::integral_constant<int, 1>{});
-                TL_TICK(6)                                 // 6: output-tile read-add-write
+                        for (int nb = 0; nb < 2; ++nb) cell[4 * nb] = acc[h][nb];
+                    }
+                }
+                TL_TICK(6)                                 // 6: output-tile write-back
             };
 
-            TlIter cur = first(a0);
-            TlIter n1 = cur;
-            advance(n1);
-            TlIter n2 = n1;
-            if (n1.a < a1) advance(n2);
-            fetch(cur, P0);
-            if (n1.a < a1) fetch(n1, P1);
-            while (cur.a < a1) {
+            Step cur = entry(0), n1 = entry(1), n2 = entry(2);
+            int tn = 3;
+            if (cur.valid()) fetch(cur, P0);
+            if (n1.valid()) fetch(n1, P1);
+            while (cur.valid()) {
                 step(cur, P0, n2);
-                cur = n1; n1 = n2;
-                if (n2.a < a1) advance(n2);
-                if (cur.a >= a1) break;
+                cur = n1; n1 = n2; n2 = entry(tn++);
+                if (!cur.valid()) break;
                 step(cur, P1, n2);
-                cur = n1; n1 = n2;
-                if (n2.a < a1) advance(n2);
+                cur = n1; n1 = n2; n2 = entry(tn++);
             }
             a0 = a1;
         }
@@ -1193,14 +1226,23 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
     // k-steps per channel chunk: the whole contraction when it fits (<= 4 k-steps), else the divisor of the k-step count
     // that leaves no padded chunk (192 channels: 2 x 3), else 4
     const int ks = ns <= 4 ? ns : (ns % 4 == 0 ? 4 : (ns % 3 == 0 ? 3 : 4));
+    OSN_REQUIRE(cdiv(ns, ks) * (TL_LCAP / 32) <= TL_STEPS, OSN_E_RANGE,
+                "osn_spconv_fwd_tl: %d input channels need more than %d channel chunks per list batch (the kernel's step table); "
+                "use osn_dense_fwd (K == 1) or osn_spconv_fwd_x6", cin, TL_STEPS / (TL_LCAP / 32));
+    const bool ragged = (cin & 31) != 0 || ns % ks != 0;
+#define OSN_TL3(NW_, KS_, RG_, PF_)                                                                                        \
+    hipLaunchKernelGGL((spconv_tl_kernel<NW_, KS_, RG_, PF_>), grid, dim3(256), 0, st, in, wp, cnt, lst, out_rows, out,     \
+                       bn_partial, counter, partial, nz, int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof)
 #define OSN_TL2(NW_, KS_)                                                                                                  \
     do {                                                                                                                   \
-        if (prof)                                                                                                          \
-            hipLaunchKernelGGL((spconv_tl_kernel<NW_, KS_, true>), grid, dim3(256), 0, st, in, wp, cnt, lst, out_rows, out, \
-                               bn_partial, counter, partial, nz, int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof); \
-        else                                                                                                               \
-            hipLaunchKernelGGL((spconv_tl_kernel<NW_, KS_, false>), grid, dim3(256), 0, st, in, wp, cnt, lst, out_rows, out, \
-                               bn_partial, counter, partial, nz, int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof); \
+        if (prof) {                                                                                                        \
+            if (ragged) OSN_TL3(NW_, KS_, true, true);                                                                     \
+            else OSN_TL3(NW_, KS_, false, true);                                                                           \
+        } else if (ragged) {                                                                                               \
+            OSN_TL3(NW_, KS_, true, false);                                                                                \
+        } else {                                                                                                           \
+            OSN_TL3(NW_, KS_, false, false);                                                                               \
+        }                                                                                                                  \
     } while (0)
 #define OSN_TL(NW_)                                                                                                        \
     do {                                                                                                                   \
@@ -1219,6 +1261,7 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
     }
 #undef OSN_TL
 #undef OSN_TL2
+#undef OSN_TL3
     OSN_LAUNCH_CHECK();
     if (nz > 1) {
         const int64_t total4 = n_out * (cout / 4);

@@ -505,8 +505,9 @@ def tile_lists(nbr, out_rows=None, bm=None):
 
 
 def tl_eligible(K, cin, cout, n_in=0):
-    """Shapes the tile-list kernel takes (everything of the U-Net but the 3-channel stem; up to 2^24 input rows)."""
-    return cin % 4 == 0 and cin >= 8 and cout % 4 == 0 and K <= 128 and n_in <= (1 << 24)
+    """Shapes the tile-list kernel takes (everything of the U-Net but the 3-channel stem; up to 2^24 input rows; up to 512
+    input channels = four 128-channel chunks in the kernel's step table: wider 1x1 convs are the dense kernel's)."""
+    return cin % 4 == 0 and 8 <= cin <= 512 and cout % 4 == 0 and K <= 128 and n_in <= (1 << 24)
 
 
 def weight_prep_tl(weight, flip=False, want_fwd=True, want_dgrad=True):
