@@ -1272,6 +1272,8 @@ def main():
                                "%s launches (HIP events recorded by the library on the launch stream)"
                                % (n_sv, "forward-pass" if dom_fwd_only else "own"),
                   "traffic": (pmc or {}).get("hbm_bytes"), "traffic_unit": "bytes per launch (PMC, profiles/pmc_traffic.json)",
+                  "evidence": (pmc or {}).get("evidence", "profiles/pmc_traffic.json; rocprofv3 dispatches of this shape: the newest "
+                                                          "profiles/r*_tl33_by_position.txt"),
                   "traffic_detail": pmc,
                   "avg_launch_us": 1e3 * gk["ms"] / gk["launches"], "launches_per_step": gk["launches"] / float(n_steps_rf),
                   "shape_launches_per_step_both_passes": (survey_shapes[dom_key]["launches"] / float(n_sv)) if survey_shapes.get(dom_key) else None,

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 t0=$(date +%s)
 timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest exit $? in $(( $(date +%s) - t0 )) s"; tail -2 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke exit $?"; tail -1 $O/smoke.log
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit $?"
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit $?"; cp bench_detail.json $O/bench_detail.json 2>/dev/null
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/whole -o trace -- python $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 python $R/tools/rocpd_stats.py $O/whole/trace_results.db > $O/kernel_stats_whole_run.csv
@@ -19,11 +19,19 @@ rm -rf $O/whole
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o trace -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events --train-only > $O/prof.json 2> $O/prof.err
 python $R/tools/rocpd_stats.py $O/prof/trace_results.db 13 > $O/stats.csv
 python $R/tools/rocpd_stats.py $O/prof/trace_results.db --streams 13 > $O/streams.txt
+# the dominant launch SHAPE by itself: a step issues its 13 spconv_tl_kernel<3, 3> launches in a fixed order (tools/tl_launch_sequence.py:
+# positions 3-5 = forward, 6-8 = input gradient of the 3^3 96 -> 96 convs on the 100 999-row map), so folding the dispatches modulo 13
+# separates the shapes without any help from the application
+python $R/tools/tl_launch_sequence.py MinkUNet18A 768 3 3 > $O/tl33_labels.json
+python $R/tools/rocpd_stats.py $O/prof/trace_results.db --by-position spconv_tl_kernelILi3ELi3E 13 $O/tl33_labels.json > $O/tl33_by_position.txt
+python $R/tools/rocpd_stats.py $O/prof/trace_results.db --by-position wgrad_tl_kernelILi3ELi3E 7 > $O/wgrad33_by_position.txt
 python $R/tools/group_stats.py $O/stats.csv > $O/groups.txt
 rm -rf $O/prof
 cat $O/groups.txt | head -24
 cd $R
 bash tools/pmc_tl.sh > $O/pmc_tl.log 2>&1; cp gpurun_out/pmc_tl/summary.txt $O/pmc_tl_summary.txt 2>/dev/null; rm -rf gpurun_out/pmc_tl/*_p*; tail -3 $O/pmc_tl.log
+bash tools/pmc_tl_sq.sh > $O/pmc_tl_sq.log 2>&1; cp gpurun_out/pmc_tl_sq/summary.txt $O/pmc_tl_sq_summary.txt 2>/dev/null; rm -rf gpurun_out/pmc_tl_sq/*_p*; tail -3 $O/pmc_tl_sq.log
+cat $O/tl33_by_position.txt
 python -c "
 import json
 for l in open('$O/bench.json'):

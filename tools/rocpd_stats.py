@@ -4,6 +4,10 @@
 usage: rocpd_stats.py trace_results.db [steps]   (steps: divide the calls / totals to per-step figures)
        rocpd_stats.py trace_results.db --dispatches PATTERN [N]   (durations in us of the last N dispatches of the kernels
                                                                    whose name contains PATTERN, in launch order)
+       rocpd_stats.py trace_results.db --by-position PATTERN PER_STEP [LABELS.json]   (the dispatches of the kernels matching
+                                                                   PATTERN, in launch order, folded modulo PER_STEP -- a step issues
+                                                                   them in a fixed order, so position p is ONE launch shape; LABELS:
+                                                                   a JSON list of PER_STEP strings, tools/tl_launch_sequence.py)
        rocpd_stats.py trace_results.db --timeline PATTERN [BEFORE_US [AFTER_US]]   (every dispatch around the last PATTERN launch)"""
 import re
 import sqlite3
@@ -23,6 +27,20 @@ def dispatches(db, pattern, n):
     print("# last %d dispatches of kernels matching %r (us, launch order)" % (len(sel), pattern))
     for k, us in sel:
         print("%-60s %9.2f" % (k[:60], us))
+
+
+def by_position(db, pattern, per_step, labels):
+    rows = db.cursor().execute("select s.kernel_name, d.start, d.end - d.start from rocpd_kernel_dispatch d join "
+                               "rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start").fetchall()
+    sel = [dur / 1e3 for k, _, dur in rows if pattern in k]
+    print("# %d dispatches of kernels matching %r = %d per step x %.2f steps" % (len(sel), pattern, per_step, len(sel) / float(per_step)))
+    if len(sel) % per_step:
+        print("# WARNING: not a multiple of %d -- the first %d dispatches are dropped" % (per_step, len(sel) % per_step))
+        sel = sel[len(sel) % per_step:]
+    print("# position  launches  mean_us  min_us  max_us  label")
+    for p in range(per_step):
+        v = sel[p::per_step]
+        print("%3d %6d %9.2f %9.2f %9.2f  %s" % (p, len(v), sum(v) / len(v), min(v), max(v), labels[p] if labels and p < len(labels) else ""))
 
 
 def timeline(db, pattern, before, after):
@@ -105,6 +123,10 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     if len(sys.argv) > 3 and sys.argv[2] == "--dispatches":
         return dispatches(db, sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 64)
+    if len(sys.argv) > 4 and sys.argv[2] == "--by-position":
+        import json
+        labels = json.load(open(sys.argv[5])) if len(sys.argv) > 5 else None
+        return by_position(db, sys.argv[3], int(sys.argv[4]), labels)
     if len(sys.argv) > 3 and sys.argv[2] == "--timeline":
         return timeline(db, sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 500.0, float(sys.argv[5]) if len(sys.argv) > 5 else 500.0)
     if len(sys.argv) > 2 and sys.argv[2] == "--streams":
