@@ -209,6 +209,8 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
     for (int nb = 0; nb < 2; ++nb) boff[nb] = (cb0 + nb < ncb ? unsigned(cb0 + nb) : 0u) * 1024u + 16u * unsigned(lane);
     const uint32_t plane_bytes = unsigned(K) * unsigned(ns) * unsigned(ncb) * 1024u;      // one bf16 piece of the whole weight
     const uint32_t kstep_bytes = unsigned(ncb) * 1024u;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(Wp), 0, int(3u * plane_bytes), 0x00020000);   // raw buffer, 32-bit offsets
 
     for (;;) {
         // ---- draw the next tile (densest first: a tile-ordered table has the rows with most neighbours last)
@@ -358,16 +360,19 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                 TL_TICK(2)                                 // 2: wait for the gathered rows + split
                 // ---- new (offset, chunk): B fragments of this wave's 32 columns, one coalesced 1 KB load each
                 if (it.first() && wave < NW) {
-                    const char* ub = reinterpret_cast<const char*>(Wp) + (size_t(it.blk0) << 10);     // wave-uniform
+                    // buffer loads: resource = the whole weight image, scalar offset = (offset, chunk, k-step, plane), vector
+                    // offset = the lane's two precomputed registers -- no address arithmetic per load
+                    const uint32_t ub = uint32_t(it.blk0) << 10;                                       // wave-uniform
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                         for (int pl = 0; pl < 3; ++pl) {
                             // k-steps past the last chunk (ragged only) are never multiplied: any valid block will do (ks 0's)
                             const int kk = (!ragged || it.s0() + ks < ns) ? ks : 0;
-                            const char* up = ub + (size_t(pl) * plane_bytes + size_t(kk) * kstep_bytes);     // scalar
+                            const uint32_t so = ub + uint32_t(pl) * plane_bytes + uint32_t(kk) * kstep_bytes;  // scalar
 #pragma unroll
-                            for (int nb = 0; nb < 2; ++nb) B[ks][nb][pl] = *reinterpret_cast<const bf16x8*>(up + boff[nb]);
+                            for (int nb = 0; nb < 2; ++nb)
+                                B[ks][nb][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, boff[nb], so, 0));
                         }
                 }
                 TL_TICK(8)                                 // 8: B-load issue
