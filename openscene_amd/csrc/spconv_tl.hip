@@ -124,14 +124,6 @@ __device__ __forceinline__ void tl_split4(const float4 x, bf16x4& p1, bf16x4& p2
 }
 
 // ------------------------------------------------------------------------------------------ conv
-struct TlIter {
-    int a;        // offset index in klist
-    int s0;       // first 32-deep k-step of the channel chunk
-    int g;        // 32-pair step within the offset
-    int niter;    // steps of offset a
-    int np;       // pairs of offset a
-};
-
 // PROF (tools only): wave 0 accumulates s_memtime deltas of the phases into prof[workgroup][10].
 #define TL_TICK(slot)                                              \
     if (PROF) {                                                    \
@@ -347,7 +339,22 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                     P[j] = *reinterpret_cast<const float4*>(in + (uint64_t(row) * unsigned(cin) + cu));
                 }
             };
-            auto step = [&](const Step& it, float4 (&P)[NQ], const Step& nf) {
+            // fragments of k-step ks of the (offset, chunk) that step `u` belongs to: buffer loads -- resource = the whole weight
+            // image, scalar offset = (offset, chunk, k-step, plane), vector offset = the lane's two precomputed registers
+            auto load_b = [&](int ks, const Step& u) {
+                const uint32_t ub = uint32_t(u.blk0) << 10;                                           // wave-uniform
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    // k-steps past the last chunk (ragged only) are never multiplied: any valid block will do (ks 0's)
+                    const int kk = (!ragged || u.s0() + ks < ns) ? ks : 0;
+                    const uint32_t so = ub + uint32_t(pl) * plane_bytes + uint32_t(kk) * kstep_bytes;  // scalar
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        B[ks][nb][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, boff[nb], so, 0));
+                }
+            };
+            bool b_ahead = false;          // this step's fragments were loaded during the previous step
+            auto step = [&](const Step& it, float4 (&P)[NQ], const Step& n1s, const Step& nf) {
                 // ---- split the fetched quads into three bf16 pieces (registers), two elements per conversion; channels past
                 // the input (only when cin is not a multiple of the chunk) are zeroed first
                 bf16x4 p1[NQ], p2[NQ], p3[NQ];
@@ -358,23 +365,16 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                     tl_split4(v, p1[j], p2[j], p3[j]);
                 }
                 TL_TICK(2)                                 // 2: wait for the gathered rows + split
-                // ---- new (offset, chunk): B fragments of this wave's 32 columns, one coalesced 1 KB load each
-                if (it.first() && wave < NW) {
-                    // buffer loads: resource = the whole weight image, scalar offset = (offset, chunk, k-step, plane), vector
-                    // offset = the lane's two precomputed registers -- no address arithmetic per load
-                    const uint32_t ub = uint32_t(it.blk0) << 10;                                       // wave-uniform
+                // ---- new (offset, chunk): B fragments of this wave's 32 columns, one coalesced 1 KB load each -- unless the
+                // previous step already fetched them behind its own MFMAs (see the end of the k-step loop)
+                if (it.first() && !b_ahead && wave < NW) {
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) {
-                            // k-steps past the last chunk (ragged only) are never multiplied: any valid block will do (ks 0's)
-                            const int kk = (!ragged || it.s0() + ks < ns) ? ks : 0;
-                            const uint32_t so = ub + uint32_t(pl) * plane_bytes + uint32_t(kk) * kstep_bytes;  // scalar
-#pragma unroll
-                            for (int nb = 0; nb < 2; ++nb)
-                                B[ks][nb][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, boff[nb], so, 0));
-                        }
+                    for (int ks = 0; ks < KS; ++ks) load_b(ks, it);
                 }
+                // the NEXT step opens a new (offset, chunk): its fragments are loaded into the registers of k-step ks as soon as
+                // this step's MFMAs of ks are issued (the last use of the current ones), i.e. beside the remaining MFMAs, the tile
+                // write-back and the two barriers -- no second register set
+                const bool ahead = n1s.valid() && n1s.first() && wave < NW;
                 TL_TICK(8)                                 // 8: B-load issue
                 __syncthreads();                           // every wave is done reading the previous stage
                 TL_TICK(3)                                 // 3: barrier A
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                 TL_TICK(9)                                 // 9: stage write + next gather issue
                 __syncthreads();                           // stage ready
                 TL_TICK(4)                                 // 4: barrier B
-                if (wave >= NW) return;                    // staging-only wave
+                if (wave >= NW) { b_ahead = false; return; }   // staging-only wave
                 // ---- 32 pairs x 32 columns per wave: accumulator blocks [pair half][column block]
                 // (the last step of an offset may hold at most 16 pairs -- the average (tile, offset) of a 100 k-row map
                 // has 36 -- : its second 16-pair half is all padding and is skipped: MFMAs, fragment reads, tile update)
@@ -449,7 +449,9 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
                         }
 #undef TL_MFMA
                     }
+                    if (ahead) load_b(ks, n1s);
                 }
+                b_ahead = ahead;
                 if (PROF) {                                // force the MFMA results (and thus the B loads) before the tick
                     float sink = 0.f;
 #pragma unroll
@@ -476,10 +478,10 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
             if (cur.valid()) fetch(cur, P0);
             if (n1.valid()) fetch(n1, P1);
             while (cur.valid()) {
-                step(cur, P0, n2);
+                step(cur, P0, n1, n2);
                 cur = n1; n1 = n2; n2 = entry(tn++);
                 if (!cur.valid()) break;
-                step(cur, P1, n2);
+                step(cur, P1, n1, n2);
                 cur = n1; n1 = n2; n2 = entry(tn++);
             }
             a0 = a1;
@@ -533,487 +535,12 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
 #undef TL_TICK
 
 
-// ================================================================================================================
-// Round 4: the same convolution with the gathered rows brought into LDS by LDS-DMA (global_load_lds_dwordx4) and ONE
-// workgroup barrier per 32-pair step.
-//
-// What round 3's phase timers said about spconv_tl_kernel: a 32-pair step is a serial chain -- wait for the gathered
-// rows in registers -> split to three bf16 planes (all 256 threads) -> barrier -> stage to LDS -> barrier -> fragment reads
-// + 72 MFMAs -> tile update: ~6 600 clocks of which 1 800 are MFMA.  Here:
-//   * the rows of a step travel global -> LDS without touching registers, as fp32, into a ring of RING slots
-//     ([32 rows][32 KS channels], lane-linear as the DMA requires; bank conflicts are avoided by permuting the 16-byte chunks
-//     of a row on the SOURCE side and reading with the same involution), issued RING - 1 steps ahead;
-//   * every MFMA wave reads ITS A fragments from the fp32 slot and splits them to the three bf16 pieces in registers right
-//     before the MFMAs (same conversions, same product order as spconv_tl_kernel => bitwise the same result): the split of
-//     one wave runs beside the MFMAs of the other workgroup's wave on the same SIMD instead of in front of a barrier;
-//   * a step needs one barrier: "slot t has landed and slot t - 1 is free".  Raw s_barrier + counted s_waitcnt vmcnt: the
-//     DMA of later steps stays in flight across it (a __syncthreads() would drain it).
-// Same lists, same weight image, same persistent tile draw, same epilogue as spconv_tl_kernel.  Shapes: input channels a
-// multiple of 32 with a chunk of 32 KS (KS <= 3) dividing them; everything else stays on spconv_tl_kernel.
-typedef __attribute__((address_space(3))) void* tl_lds_ptr;
-typedef const __attribute__((address_space(1))) void* tl_gbl_ptr;
-constexpr int TL2_LCAP = 1024;    // packed list entries resident in LDS per batch of offsets
-
-// One 1 KB LDS-DMA wave-instruction: lane l's 16 bytes at `src` land at lds + 16 l.  Inline asm on purpose: through the
-// builtin the compiler knows that LDS is written asynchronously and puts s_waitcnt vmcnt(0) in front of EVERY later LDS
-// read of the kernel (it cannot tell the ring from the output tile), which drains the groups that are meant to stay in
-// flight.  Hidden from it, the ordering is this file's job: a counted vmcnt wait + the step barrier before a slot is read.
-// (Its own vmcnt arithmetic for ordinary loads stays safe: extra outstanding operations only make its waits stricter.)
-__device__ __forceinline__ void tl2_dma16(const float* src, const float* lds) {
-    const uint32_t dst = uint32_t(uintptr_t((tl_lds_ptr)lds));
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src), "s"(dst)
-                 : "memory");
-}
-
-// fp32 x 8 -> the three bf16 pieces of every element, as MFMA fragments (element e of a piece = piece of x[e]); the same
-// round-to-nearest conversions as everywhere else in this library (x = h1 + h2 + h3 exactly), two elements per instruction
-__device__ __forceinline__ void tl2_split8(const float4 lo, const float4 hi, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    const f2 v[4] = {f2{lo.x, lo.y}, f2{lo.z, lo.w}, f2{hi.x, hi.y}, f2{hi.z, hi.w}};
-    u4 q1, q2, q3;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const b2 h1 = __builtin_convertvector(v[j], b2);
-        const uint32_t u1 = __builtin_bit_cast(uint32_t, h1);
-        const f2 r1 = v[j] - f2{__builtin_bit_cast(float, u1 << 16), __builtin_bit_cast(float, u1 & 0xFFFF0000u)};
-        const b2 h2 = __builtin_convertvector(r1, b2);
-        const uint32_t u2 = __builtin_bit_cast(uint32_t, h2);
-        const f2 r2 = r1 - f2{__builtin_bit_cast(float, u2 << 16), __builtin_bit_cast(float, u2 & 0xFFFF0000u)};
-        const b2 h3 = __builtin_convertvector(r2, b2);
-        q1[j] = u1; q2[j] = u2; q3[j] = __builtin_bit_cast(uint32_t, h3);
-    }
-    p1 = __builtin_bit_cast(bf16x8, q1);
-    p2 = __builtin_bit_cast(bf16x8, q2);
-    p3 = __builtin_bit_cast(bf16x8, q3);
-}
-
-template <int N>
-__device__ __forceinline__ void tl_wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// chunk permutation of a staged row (an involution on the chunk index): rows 0 .. 15 of a 16-pair half must spread over the
-// 64 banks when every lane reads the same logical chunk.  Row stride 32 KS words: KS odd -> rows alternate between the two
-// bank halves, 8 row pairs x 3 bits; KS = 2 -> every row starts on bank 0, 16 rows x 4 bits.
-template <int KS>
-__device__ __forceinline__ int tl2_swz(int r) {
-    return (KS & 1) ? ((r >> 1) & 7) : (r & 15);
-}
-
-__host__ __device__ inline size_t tl2_lds_bytes(int nw, int ks, int ring, int bm) {
-    const size_t S = size_t(32 * nw + 4);
-    return (size_t(bm) + 1) * S * 4 + size_t(ring) * 32 * 32 * ks * 4 + size_t(TL2_LCAP) * 4 + size_t(2 * TL_KMAX + TL_KMAX + 4) * 4 +
-           64 + 16;
-}
-
-// PROF (tools only): wave 0 accumulates s_memtime deltas into prof[workgroup][10]: 0 tile prologue, 1 list load, 2 counted
-// wait at the top of a step, 3 barrier, 4 tail-fragment issue, 5 accumulator / fragment reads + k-step 0, 6 DMA + prefetch
-// issue, 7 remaining k-steps + write-back, 8 epilogue
-#define TL2_TICK(slot)                                             \
-    if (PROF) {                                                    \
-        __builtin_amdgcn_sched_barrier(0);                         \
-        const long long now_ = __builtin_amdgcn_s_memtime();       \
-        tacc[slot] += now_ - tlast;                                \
-        tlast = now_;                                              \
-        __builtin_amdgcn_sched_barrier(0);                         \
-    }
-template <int NW, int KS, int RING, bool PROF = false>
-__global__ __launch_bounds__(256, 2) void spconv_tl2_kernel(const float* __restrict__ in, const bf16x8* __restrict__ Wp,
-                                                                const int32_t* __restrict__ cnt, const int2* __restrict__ lst,
-                                                                const int32_t* __restrict__ out_rows, float* __restrict__ out,
-                                                                double* __restrict__ bn_partial, int32_t* __restrict__ counter,
-                                                                float* __restrict__ partial, int nz, int n_out, int K, int cin,
-                                                                int cout, int bm, int n_tiles, int ns, int ncb, int self_reset, long long* __restrict__ prof) {
-    constexpr int NT = 256;
-    constexpr int CW = 32 * NW;               // output columns of the workgroup
-    constexpr int S = CW + 4;                 // fp32 row stride of the output tile
-    constexpr int CK = 32 * KS;               // input channels per chunk
-    constexpr int CPR = CK / 4;               // 16-byte chunks per staged row
-    constexpr int SLOT = 32 * CK;             // floats per ring slot
-    constexpr int NI = SLOT * 4 / 1024;       // DMA wave-instructions per slot (1 KB each) = 4 KS
-    constexpr int IPW = NI / 4;               // per wave = KS
-    constexpr int NBL = KS * 2 * 3;           // B-fragment loads of an MFMA wave per (offset, chunk)
-    constexpr int NL = (TL2_LCAP + NT - 1) / NT;
-    static_assert(RING == 2 || RING == 3, "ring depth");
-    extern __shared__ __attribute__((aligned(16))) unsigned char tl2_smem[];
-    float* otile = reinterpret_cast<float*>(tl2_smem);                        // [(bm + 1)][S]; row bm = dump row of padded pairs
-    float* ring = otile + (bm + 1) * S;                                       // [RING][32][CK]
-    uint32_t* plist = reinterpret_cast<uint32_t*>(ring + RING * SLOT);        // (local output row << 24) | input row
-    int* klist = reinterpret_cast<int*>(plist + TL2_LCAP);
-    int* kcnt = klist + TL_KMAX;
-    int* lstart = kcnt + TL_KMAX;                                             // [TL_KMAX + 1]
-    unsigned char* gowner = reinterpret_cast<unsigned char*>(lstart + TL_KMAX + 4);
-    int* scal = reinterpret_cast<int*>(gowner + 64);                          // nact, batch end, tile draw
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col0 = blockIdx.y * CW;
-    const int cb0 = blockIdx.y * (2 * NW) + 2 * wave;
-
-    // DMA geometry of this lane: instruction i = wave + 4 j covers slot chunks [64 i, 64 i + 64)
-    int d_row[IPW], d_col[IPW];
-#pragma unroll
-    for (int j = 0; j < IPW; ++j) {
-        const int q = (wave + 4 * j) * 64 + lane;
-        const int r = q / CPR, c = q - r * CPR;
-        d_row[j] = r;
-        d_col[j] = 4 * (c ^ tl2_swz<KS>(r));
-    }
-    // fragment geometry: pair row h * 16 + (lane & 15), k group lane >> 4 (8 channels = chunks 2 g, 2 g + 1 of a k-step)
-    // (float offset of logical chunk c of row r = r CK + ((4 c) ^ (4 swz(r))): the permutation acts on bits 2.. of the offset)
-    int a_row[2], a_z4[2];
-    const int a_g8 = 8 * (lane >> 4);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int r = h * 16 + (lane & 15);
-        a_row[h] = r * CK;
-        a_z4[h] = 4 * tl2_swz<KS>(r);
-    }
-
-    // B fragments: k-step 0 of the current and of the NEXT (offset, chunk) in two alternating sets, k-steps >= 1 in one tail
-    // set filled at the top of a unit (needed 400+ clocks later): 96 registers for 96 input channels instead of 144
-    bf16x8 B0[2][3], B1[2][3], Bt[KS > 1 ? KS - 1 : 1][2][3];
-    const bool dbg_nob = (self_reset & 2) != 0, dbg_nodma = (self_reset & 4) != 0;      // tools only (osn_dbg_set_tl2 bits 1, 2)
-    long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast = PROF ? __builtin_amdgcn_s_memtime() : 0;
-
-    for (;;) {
-        if (tid == 0) scal[2] = atomicAdd(&counter[blockIdx.y], 1);
-        __syncthreads();
-        const int draw = __builtin_amdgcn_readfirstlane(scal[2]);
-        if (draw >= n_tiles * nz) break;
-        const int tile = n_tiles - 1 - draw / nz;
-        const int zpart = draw - (draw / nz) * nz;
-        const int row0 = tile * bm;
-        const int rows = min(bm, n_out - row0);
-
-        for (int i = tid; i < (bm + 1) * S / 4; i += NT)
-            reinterpret_cast<float4*>(otile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-        if (cnt) {
-            if (wave == 0) {
-                int n = 0;
-                for (int k0 = 0; k0 < K; k0 += 64) {
-                    const int k = k0 + lane;
-                    const int c = k < K ? cnt[int64_t(tile) * K + k] : 0;
-                    const unsigned long long m = __ballot(c > 0);
-                    if (c > 0) {
-                        const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-                        klist[pos] = k;
-                        kcnt[pos] = c;
-                    }
-                    n += __popcll(m);
-                }
-                if (lane == 0) scal[0] = n;
-            }
-        } else if (tid == 0) {
-            klist[0] = 0;
-            kcnt[0] = rows;
-            scal[0] = 1;
-        }
-        __syncthreads();
-        const int nact_all = __builtin_amdgcn_readfirstlane(scal[0]);
-        const int nact = nact_all * (zpart + 1) / nz;
-        TL2_TICK(0)
-
-        int a0 = nact_all * zpart / nz;
-        while (a0 < nact) {
-            if (tid == 0) {
-                int tot = 0, a = a0;
-                while (a < nact) {
-                    const int np = (kcnt[a] + 31) & ~31;
-                    if (tot + np > TL2_LCAP) break;
-                    lstart[a] = tot;
-                    tot += np;
-                    ++a;
-                }
-                lstart[a] = tot;
-                scal[1] = a;
-            }
-            __syncthreads();
-            const int a1 = __builtin_amdgcn_readfirstlane(scal[1]);
-            const int E = __builtin_amdgcn_readfirstlane(lstart[a1]);
-            for (int a = a0 + tid; a < a1; a += NT)
-                for (int g = lstart[a] >> 5; g < (lstart[a + 1] >> 5); ++g) gowner[g] = (unsigned char)a;
-            __syncthreads();
-            if (cnt) {
-                int2 x[NL];
-                bool okv[NL];
-#pragma unroll
-                for (int j = 0; j < NL; ++j) {
-                    const int e = tid + NT * j;
-                    const int ec = e < E ? e : 0;
-                    const int a = gowner[ec >> 5];
-                    const int p = ec - lstart[a];
-                    okv[j] = e < E && p < kcnt[a];
-                    x[j] = lst[(int64_t(tile) * K + klist[a]) * bm + (okv[j] ? p : 0)];
-                }
-#pragma unroll
-                for (int j = 0; j < NL; ++j) {
-                    const uint32_t v = okv[j] ? ((uint32_t(x[j].y) << 24) | uint32_t(x[j].x)) : (uint32_t(bm) << 24);
-                    if (tid + NT * j < E) plist[tid + NT * j] = v;
-                }
-            } else {
-                for (int e = tid; e < E; e += NT)
-                    plist[e] = e < rows ? ((uint32_t(e) << 24) | uint32_t(row0 + e)) : (uint32_t(bm) << 24);
-            }
-            __syncthreads();                               // lists ready; no DMA is in flight here (the pipeline below drains)
-            // (an S_WAITCNT the compiler's scoreboard sees: without it its model carries the list loads above into the loop as
-            // "possibly pending" and guards their registers with vmcnt(1) / vmcnt(0) on every step -- which, at run time, drains
-            // the DMA groups and fragment loads it does not know about)
-            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0), expcnt / lgkmcnt untouched
-            TL2_TICK(1)
-
-            auto first = [&](int a) {
-                TlIter it;
-                it.a = a; it.s0 = 0; it.g = 0;
-                it.np = a < a1 ? __builtin_amdgcn_readfirstlane(kcnt[a]) : 0;
-                it.niter = (it.np + 31) >> 5;
-                return it;
-            };
-            auto advance = [&](TlIter& it) {
-                if (++it.g == it.niter) {
-                    it.g = 0;
-                    it.s0 += KS;
-                    if (it.s0 >= ns) {
-                        it.s0 = 0;
-                        ++it.a;
-                        it.np = it.a < a1 ? __builtin_amdgcn_readfirstlane(kcnt[it.a]) : 0;
-                        it.niter = (it.np + 31) >> 5;
-                    }
-                }
-            };
-            // one step's rows -> ring slot `slot`: IPW 1 KB DMA instructions per wave
-            auto fetch = [&](const TlIter& it, int slot) {
-                const int base = __builtin_amdgcn_readfirstlane(lstart[it.a]) + 32 * it.g;
-                float* dst = ring + slot * SLOT + wave * 256;
-#pragma unroll
-                for (int j = 0; j < IPW; ++j) {
-                    const unsigned row = plist[base + d_row[j]] & 0xFFFFFFu;
-                    const float* src = in + (uint64_t(row) * unsigned(cin) + unsigned(32 * it.s0 + d_col[j]));
-                    if (!dbg_nodma) tl2_dma16(src, dst + j * 1024);
-                }
-            };
-
-            // ---- the batch as a sequence of UNITS (offset, channel chunk), each a run of 32-pair steps.  The B fragments of
-            // unit u + 1 are loaded into the OTHER register set in the middle of unit u's first step: the 54 KB a workgroup pulls
-            // per unit (a burst the CU's load path needs ~900 clocks for, 2 500 with the other workgroup's burst beside it: round
-            // 3's "B issue" timer) travel while unit u multiplies.  They are ordinary loads -- the compiler orders their first
-            // use (its wait sits in the peeled first step of a unit only; hiding them in inline asm as well let the register
-            // allocator copy a fragment that had not landed yet) -- and, being vector-memory operations, they count in the
-            // hand-placed waits of the DMA groups.
-            struct Unit { int a, s0, np, niter; };
-            auto unit_at = [&](int a, int s0) {
-                Unit u;
-                u.a = a; u.s0 = s0;
-                u.np = a < a1 ? __builtin_amdgcn_readfirstlane(kcnt[a]) : 0;
-                u.niter = (u.np + 31) >> 5;
-                return u;
-            };
-            auto unit_next = [&](const Unit& u) { return u.s0 + KS >= ns ? unit_at(u.a + 1, 0) : unit_at(u.a, u.s0 + KS); };
-            // fragments of k-step ks of unit u (2 column blocks x 3 planes, one coalesced 1 KB load each)
-            auto load_b = [&](bf16x8 (&Bk)[2][3], const Unit& u, int ks) {
-                const int k = __builtin_amdgcn_readfirstlane(klist[u.a]);
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const unsigned cb = cb0 + nb < ncb ? unsigned(cb0 + nb) : 0u;         // (columns past the weight are never stored)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        const unsigned blk = (unsigned(pl * K + k) * unsigned(ns) + unsigned(u.s0 + ks)) * unsigned(ncb) + cb;
-                        Bk[nb][pl] = (Wp + (size_t(dbg_nob ? 0u : blk) << 6))[lane];
-                    }
-                }
-            };
-
-            TlIter nf = first(a0);             // the step whose rows are fetched next
-            int inflight = 0;                  // ring slots issued and not yet consumed
-            int cslot = 0, fslot = 0;
-            bool pend_b = false;               // a fragment prefetch was issued during the previous step (younger than that step's DMA group)
-            auto fetch_next = [&]() {
-                if (nf.a < a1) {
-                    fetch(nf, fslot);
-                    fslot = fslot + 1 == RING ? 0 : fslot + 1;
-                    ++inflight;
-                    advance(nf);
-                }
-            };
-            // one step of unit u on register set `Bs`; FIRST: the unit's first step, which also starts the prefetch into `Bn`
-            auto step = [&](auto first_c, bf16x8 (&Bs)[2][3], bf16x8 (&Bn)[2][3], const Unit& u, const Unit& un, int g) {
-                constexpr bool FIRST = decltype(first_c)::value;
-                // this wave's share of slot `cslot` has landed (and every older load); the youngest DMA group and a fragment
-                // prefetch issued during the previous step stay in flight
-                const bool young = RING == 3 && inflight > 1;
-                if (young) {
-                    if (pend_b) tl_wait_vm<IPW + NBL>();
-                    else tl_wait_vm<IPW>();
-                } else {
-                    if (pend_b) tl_wait_vm<NBL>();
-                    else tl_wait_vm<0>();
-                }
-                pend_b = false;
-                TL2_TICK(2)
-                __builtin_amdgcn_s_barrier();              // every wave's share has landed; every wave is done with the previous step
-                asm volatile("" ::: "memory");
-                TL2_TICK(3)
-                if (FIRST && KS > 1 && wave < NW) {
-                    // the unit's fragments of k-steps >= 1 into the single tail set (the previous unit is done with it): they are
-                    // first needed after the 12 - 24 MFMAs of k-step 0
-#pragma unroll
-                    for (int ks = 1; ks < KS; ++ks) load_b(Bt[ks - 1], u, ks);
-                    pend_b = true;
-                }
-                TL2_TICK(4)
-                const float* slotp = ring + cslot * SLOT;
-                const bool half1 = u.np - 32 * g > 16;
-                if (wave < NW) {
-                    // NH = 16-pair halves of this step that hold real pairs (the last step of an offset often has <= 16)
-                    auto body = [&](auto nh) {
-                        constexpr int NH = decltype(nh)::value;
-                        // accumulators start from the output tile's cells (read now: the latency hides under the fragment reads and
-                        // the split) and are stored back after the last MFMA: no separate read-add-write phase
-                        const int pbase = __builtin_amdgcn_readfirstlane(lstart[u.a]) + 32 * g + (lane & 15);
-                        int ocell[NH];
-#pragma unroll
-                        for (int h = 0; h < NH; ++h) ocell[h] = int(plist[pbase + 16 * h] >> 24) * S + 32 * wave + 4 * (lane >> 4);
-                        float4 raw[NH][2];
-#pragma unroll
-                        for (int h = 0; h < NH; ++h) {
-                            raw[h][0] = *reinterpret_cast<const float4*>(slotp + a_row[h] + (a_g8 ^ a_z4[h]));
-                            raw[h][1] = *reinterpret_cast<const float4*>(slotp + a_row[h] + ((a_g8 + 4) ^ a_z4[h]));
-                        }
-                        f32x4 acc[NH][2];
-#pragma unroll
-                        for (int h = 0; h < NH; ++h)
-#pragma unroll
-                            for (int nb = 0; nb < 2; ++nb) acc[h][nb] = *reinterpret_cast<const f32x4*>(&otile[ocell[h] + 16 * nb]);
-#pragma unroll
-                        for (int ks = 0; ks < KS; ++ks) {
-                            // one 16-pair half at a time: split its eight channels, then its 12 MFMAs (2 column blocks x 6 products;
-                            // per accumulator smallest terms first: a3b1, a2b2, a1b3, a2b1, a1b2, a1b1, as in spconv_tl_kernel).  The
-                            // second half's split runs beside the first half's MFMAs, and only one half's fragments are live.
-#pragma unroll
-                            for (int h = 0; h < NH; ++h) {
-                                bf16x8 af[3];
-                                tl2_split8(raw[h][0], raw[h][1], af[0], af[1], af[2]);
-                                if (ks + 1 < KS) {
-                                    raw[h][0] = *reinterpret_cast<const float4*>(slotp + a_row[h] + ((32 * (ks + 1) + a_g8) ^ a_z4[h]));
-                                    raw[h][1] = *reinterpret_cast<const float4*>(slotp + a_row[h] + ((32 * (ks + 1) + a_g8 + 4) ^ a_z4[h]));
-                                }
-#define TL2_MFMA(AP, BP)                                                                                     \
-    _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                                         \
-        acc[h][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ks == 0 ? Bs[nb][BP] : Bt[ks > 0 ? ks - 1 : 0][nb][BP], af[AP], acc[h][nb], 0, 0, 0);
-                                TL2_MFMA(2, 0)
-                                TL2_MFMA(1, 1)
-                                TL2_MFMA(0, 2)
-                                TL2_MFMA(1, 0)
-                                TL2_MFMA(0, 1)
-                                TL2_MFMA(0, 0)
-#undef TL2_MFMA
-                            }
-                            if (ks == 0) {
-                                // after the first use of this unit's fragments (the compiler's wait for them covers every load it
-                                // knows to be outstanding): the rows of step t + RING - 1 into the slot of step t - 1 (free since the
-                                // barrier), then the next unit's fragments
-                                if (PROF) {
-                                    float sink = 0.f;
-#pragma unroll
-                                    for (int h = 0; h < NH; ++h) sink += acc[h][0][0] + acc[h][1][0];
-                                    asm volatile("" ::"v"(sink));
-                                }
-                                TL2_TICK(5)
-                                __builtin_amdgcn_sched_barrier(0);
-                                fetch_next();
-                                if (FIRST && un.a < a1) {
-                                    load_b(Bn, un, 0);
-                                    pend_b = true;
-                                }
-                                __builtin_amdgcn_sched_barrier(0);
-                                TL2_TICK(6)
-                            }
-                        }
-#pragma unroll
-                        for (int h = 0; h < NH; ++h)
-#pragma unroll
-                            for (int nb = 0; nb < 2; ++nb) *reinterpret_cast<f32x4*>(&otile[ocell[h] + 16 * nb]) = acc[h][nb];
-                        TL2_TICK(7)
-                    };
-                    if (half1) body(std::integral_constant<int, 2>{});
-                    else body(std::integral_constant<int, 1>{});
-                } else {
-                    fetch_next();                          // staging-only wave (output narrower than 128 columns)
-                }
-                --inflight;
-                cslot = cslot + 1 == RING ? 0 : cslot + 1;
-            };
-            auto run_unit = [&](bf16x8 (&Bs)[2][3], bf16x8 (&Bn)[2][3], const Unit& u, const Unit& un) {
-                step(std::true_type{}, Bs, Bn, u, un, 0);
-                for (int g = 1; g < u.niter; ++g) step(std::false_type{}, Bs, Bn, u, un, g);
-            };
-
-            Unit u = unit_at(a0, 0);
-            if (wave < NW) load_b(B0, u, 0);               // the batch's first unit: nothing to hide it behind
-#pragma unroll
-            for (int d = 0; d < RING - 1; ++d) fetch_next();
-            for (;;) {
-                if (u.a >= a1) break;
-                Unit un = unit_next(u);
-                run_unit(B0, B1, u, un);
-                u = un;
-                if (u.a >= a1) break;
-                un = unit_next(u);
-                run_unit(B1, B0, u, un);
-                u = un;
-            }
-            a0 = a1;
-            __syncthreads();                               // (drains nothing: every issued slot was consumed) tile / lists reusable
-        }
-
-        constexpr int V = CW / 4;
-        for (int idx = tid; idx < rows * V; idx += NT) {
-            const int j = idx / V, c4 = idx - j * V;
-            const int col = col0 + 4 * c4;
-            if (col < cout) {
-                const float4 v = *reinterpret_cast<const float4*>(&otile[j * S + 4 * c4]);
-                if (nz > 1) {
-                    *reinterpret_cast<float4*>(partial + (int64_t(zpart) * n_out + row0 + j) * cout + col) = v;
-                } else {
-                    const int64_t orow = out_rows ? out_rows[row0 + j] : row0 + j;
-                    *reinterpret_cast<float4*>(out + orow * cout + col) = v;
-                }
-            }
-        }
-        if (bn_partial) {
-            for (int c = tid; c < CW; c += NT) {
-                if (col0 + c < cout) {
-                    double s1 = 0, s2 = 0;
-                    for (int j = 0; j < rows; ++j) {
-                        const double v = otile[j * S + c];
-                        s1 += v;
-                        s2 += v * v;
-                    }
-                    bn_partial[(int64_t(tile) * 2 + 0) * cout + col0 + c] = s1;
-                    bn_partial[(int64_t(tile) * 2 + 1) * cout + col0 + c] = s2;
-                }
-            }
-        }
-        __syncthreads();
-        TL2_TICK(8)
-    }
-    if (PROF && tid == 0 && blockIdx.y == 0)
-        for (int i = 0; i < 10; ++i) prof[int64_t(blockIdx.x) * 10 + i] = tacc[i];
-    if ((self_reset & 1) && tid == 0) {
-        const int done = atomicAdd(&counter[64 + blockIdx.y], 1);
-        if (done == int(gridDim.x) - 1) {
-            counter[blockIdx.y] = 0;
-            counter[64 + blockIdx.y] = 0;
-        }
-    }
-}
+// (Round 4 also tried this convolution with the gathered rows brought into LDS by LDS-DMA (global_load_lds_dwordx4), one
+// barrier per step, the bf16 split done by every MFMA wave on its own fragments and the weight fragments of the next
+// (offset, chunk) prefetched into a second register set: three variants, 139 - 173 us against 145 - 159 us for the kernel above
+// at the time, and 149 us with EVERY byte of memory traffic removed -- which is how the kernel turned out to be bound by
+// instruction issue, not by memory or latency.  The experiment is commits f129c6a .. 7a3f559 of this repository; its measurements are
+// profiles/r04_s2_*.  What came out of it is the instruction diet of spconv_tl_kernel above.)
 
 static int tl_waves(int cout) {
     // waves (= 32-column groups) per workgroup: the width with the least padding, the wider one on ties
@@ -1113,18 +640,6 @@ __global__ void tl_reduce_parts_kernel(const float4* __restrict__ partial, int S
     }
 }
 
-static int g_tl2 = -1;
-static bool tl2_on() {
-    if (g_tl2 < 0) {
-        const char* e = getenv("OSN_TL2");
-        g_tl2 = (e && e[0] == '1') ? 1 : 0;         // experimental (round 4): measured SLOWER than spconv_tl_kernel, off by default
-    }
-    return g_tl2 == 1;
-}
-// Tools only: 1 = LDS-DMA kernel where eligible (default), 0 = round-2 kernel
-static int g_tl2_dbg = 0;
-extern "C" void osn_dbg_set_tl2(int on) { g_tl2 = (on & 1) ? 1 : 0; g_tl2_dbg = on & 6; }
-
 static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
                               float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm, void* ws,
                               size_t ws_bytes, int32_t* counters, long long* prof, osn_stream_t stream) {
@@ -1164,70 +679,6 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
     const unsigned gx = unsigned(units < TL_SLOTS ? units : TL_SLOTS);
     const dim3 grid(gx, unsigned(gy));
     const bf16x8* wp = static_cast<const bf16x8*>(Wp);
-    // round 4: the LDS-DMA kernel for input channels in multiples of 32 (every MinkUNet width); OSN_TL2=0 / osn_dbg_set_tl2(0)
-    // keep the round-2 kernel
-    if (tl2_on() && (cin & 31) == 0 && (!prof || (nw == 3 && ns == 3 && tl2_lds_bytes(3, 3, 3, bm) <= 80 * 1024 - 640))) {
-        const int ks2 = ns % 3 == 0 ? 3 : (ns % 2 == 0 ? 2 : (ns == 1 ? 1 : 0));
-        if (ks2 > 0) {
-            int ring = 3;
-            size_t lds = tl2_lds_bytes(nw, ks2, ring, bm);
-            if (lds > 80 * 1024 - 640) { ring = 2; lds = tl2_lds_bytes(nw, ks2, ring, bm); }   // two workgroups per CU (160 KB)
-            int rc2 = OSN_OK;
-#define OSN_TL2K(NW_, KS_, R_)                                                                                               \
-    do {                                                                                                                     \
-        auto kern = spconv_tl2_kernel<NW_, KS_, R_>;                                                                         \
-        static size_t attr_bytes = 0;                                                                                        \
-        if (lds > attr_bytes) {                                                                                              \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) { \
-                rc2 = OSN_E_HIP;                                                                                             \
-                break;                                                                                                       \
-            }                                                                                                                \
-            attr_bytes = lds;                                                                                                \
-        }                                                                                                                    \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, wp, cnt, lst, out_rows, out, bn_partial, counter, partial, nz, \
-                           int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset | g_tl2_dbg, prof);               \
-    } while (0)
-#define OSN_TL2R(NW_, KS_)                                                                                                   \
-    do {                                                                                                                     \
-        if (ring == 3) OSN_TL2K(NW_, KS_, 3);                                                                                \
-        else OSN_TL2K(NW_, KS_, 2);                                                                                          \
-    } while (0)
-#define OSN_TL2W(NW_)                                                                                                        \
-    do {                                                                                                                     \
-        if (ks2 == 3) OSN_TL2R(NW_, 3);                                                                                      \
-        else if (ks2 == 2) OSN_TL2R(NW_, 2);                                                                                 \
-        else OSN_TL2R(NW_, 1);                                                                                               \
-    } while (0)
-            if (prof) {
-                auto kern = spconv_tl2_kernel<3, 3, 3, true>;
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
-                    rc2 = OSN_E_HIP;
-                else
-                    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, wp, cnt, lst, out_rows, out, bn_partial, counter, partial, nz,
-                                       int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof);
-            } else
-            switch (nw) {
-                case 4: OSN_TL2W(4); break;
-                case 3: OSN_TL2W(3); break;
-                case 2: OSN_TL2W(2); break;
-                default: OSN_TL2W(1); break;
-            }
-#undef OSN_TL2W
-#undef OSN_TL2R
-#undef OSN_TL2K
-            OSN_REQUIRE(rc2 == OSN_OK, OSN_E_HIP, "osn_spconv_fwd_tl: cannot reserve %zu bytes of LDS", lds);
-            OSN_LAUNCH_CHECK();
-            if (nz > 1) {
-                const int64_t total4 = n_out * (cout / 4);
-                int g = int(cdiv(total4, 256));
-                if (g > 4096) g = 4096;
-                hipLaunchKernelGGL(tl_reduce_parts_kernel, dim3(g), dim3(256), 0, st, reinterpret_cast<const float4*>(partial), nz, n_out,
-                                   cout / 4, out_rows, reinterpret_cast<float4*>(out));
-                OSN_LAUNCH_CHECK();
-            }
-            return OSN_OK;
-        }
-    }
     // k-steps per channel chunk: the whole contraction when it fits (<= 4 k-steps), else the divisor of the k-step count
     // that leaves no padded chunk (192 channels: 2 x 3), else 4
     const int ks = ns <= 4 ? ns : (ns % 4 == 0 ? 4 : (ns % 3 == 0 ? 3 : 4));

@@ -27,12 +27,8 @@ def main():
     fn.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, ctypes.c_size_t, vp, vp]
     vox = syn.shuffled(syn.grid_voxels(syn.room_points(0), 0.02), 0)
     cm = CoordinateManager(torch.from_numpy(syn.batch_coords([vox])).to(dev))
-    import ctypes as _c
-    set_tl2 = _c.CDLL(_lib.LIB_PATH).osn_dbg_set_tl2
-    variant = int(os.environ.get("TL2", "1"))
-    set_tl2(variant)
-    shapes = ((1, 96, 96), (2, 96, 96)) if variant else ((1, 96, 96), (1, 128, 96), (2, 96, 96), (2, 32, 32))
-    for stride, cin, cout in shapes:
+    variant = 0
+    for stride, cin, cout in ((1, 96, 96), (1, 128, 96), (2, 96, 96), (2, 32, 32)):
         n = cm.size(stride)
         tiles = cm.kmap_tiles(stride, stride, 3)[0]
         tl = ops.tile_lists(tiles[1], out_rows=tiles[0])
