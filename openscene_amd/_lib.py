@@ -8,7 +8,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libopenscene_amd.so")
+LIB_PATH = os.environ.get("OSN_LIB_PATH") or os.path.join(_HERE, "lib", "libopenscene_amd.so")   # (override: tools' A/B builds)
 
 _c = ctypes
 _vp, _i32, _i64, _sz, _f32 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t, _c.c_float

@@ -15,6 +15,7 @@
 // operand, a3b1 + a2b2 + a1b3 + a2b1 + a1b2 + a1b1 in fp32, smallest terms first) and the same weight image
 // (osn_weight_prep_tl with K = 1).
 #include "common.h"
+#include "split.h"
 
 namespace osn {
 
@@ -62,17 +63,8 @@ __global__ __launch_bounds__(256, 2) void dense_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             const bool ok = 32 * s0 + q_col[j] < cin && r0 + q_row[j] < n;
-            const float x[4] = {P[j].x, P[j].y, P[j].z, P[j].w};
             bf16x4 p1, p2, p3;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = ok ? x[e] : 0.f;
-                const __bf16 h1 = (__bf16)v;
-                const float r1 = v - (float)h1;
-                const __bf16 h2 = (__bf16)r1;
-                const float r2 = r1 - (float)h2;
-                p1[e] = h1; p2[e] = h2; p3[e] = (__bf16)r2;
-            }
+            tl_split4(ok ? P[j] : make_float4(0.f, 0.f, 0.f, 0.f), p1, p2, p3);      // split.h: two elements per conversion
             *reinterpret_cast<bf16x4*>(&stage[0][q_row[j]][q_col[j]]) = p1;
             *reinterpret_cast<bf16x4*>(&stage[1][q_row[j]][q_col[j]]) = p2;
             *reinterpret_cast<bf16x4*>(&stage[2][q_row[j]][q_col[j]]) = p3;

@@ -21,6 +21,7 @@
 // resident), which is why the 48 k / 100 k-row levels stay on the tile-list kernel.
 // Arithmetic: "bf16x6" as in spconv_tl.hip (three bf16 pieces per operand, six MFMAs per product block, fp32 accumulate).
 #include "common.h"
+#include "split.h"
 #include "pairlist.h"
 
 namespace osn {
@@ -118,17 +119,8 @@ __global__ __launch_bounds__(256) void spconv_ws_kernel(const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) {
                     const bool ok = 32 * s0 + q_col[j] < cin;
-                    const float x[4] = {P[j].x, P[j].y, P[j].z, P[j].w};
                     bf16x4 p1, p2, p3;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = ok ? x[e] : 0.f;
-                        const __bf16 h1 = (__bf16)v;
-                        const float r1 = v - (float)h1;
-                        const __bf16 h2 = (__bf16)r1;
-                        const float r2 = r1 - (float)h2;
-                        p1[e] = h1; p2[e] = h2; p3[e] = (__bf16)r2;
-                    }
+                    tl_split4(ok ? P[j] : make_float4(0.f, 0.f, 0.f, 0.f), p1, p2, p3);      // split.h: two elements per conversion
                     if (NT * NQ == 32 * QPR || tid + NT * j < 32 * QPR) {
                         *reinterpret_cast<bf16x4*>(&stage[buf][0][q_row[j]][q_col[j]]) = p1;
                         *reinterpret_cast<bf16x4*>(&stage[buf][1][q_row[j]][q_col[j]]) = p2;

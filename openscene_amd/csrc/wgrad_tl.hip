@@ -19,6 +19,7 @@
 //   * 4 waves as 2 x 2 over the (input channel, output channel) block, MB x NB accumulator blocks of 16 x 16
 //     per wave, six MFMAs per block and step (a3g1 + a2g2 + a1g3 + a2g1 + a1g2 + a1g1, fp32 accumulate).
 #include "common.h"
+#include "split.h"
 #include <cstdlib>
 #include "pairlist.h"
 
@@ -217,17 +218,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tl_kernel(const float* __restric
         }
         (void)par;
     };
+    // three bf16 pieces per element, two elements per conversion (split.h); rows of padded pairs and channels past the
+    // operand are zeroed first
     auto split4 = [&](const float4& v, bool ok, bf16x4& h1, bf16x4& h2, bf16x4& h3) {
-        const float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float t = ok ? x[e] : 0.f;
-            const __bf16 a = (__bf16)t;
-            const float r1 = t - (float)a;
-            const __bf16 b = (__bf16)r1;
-            const float r2 = r1 - (float)b;
-            h1[e] = a; h2[e] = b; h3[e] = (__bf16)r2;
-        }
+        tl_split4(ok ? v : make_float4(0.f, 0.f, 0.f, 0.f), h1, h2, h3);
     };
 
     // prologue: indices of step 0 -> LDS -> rows of step 0 in flight, indices of step 1 in registers
