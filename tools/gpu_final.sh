@@ -32,6 +32,23 @@ cd $R
 bash tools/pmc_tl.sh > $O/pmc_tl.log 2>&1; cp gpurun_out/pmc_tl/summary.txt $O/pmc_tl_summary.txt 2>/dev/null; rm -rf gpurun_out/pmc_tl/*_p*; tail -3 $O/pmc_tl.log
 bash tools/pmc_tl_sq.sh > $O/pmc_tl_sq.log 2>&1; cp gpurun_out/pmc_tl_sq/summary.txt $O/pmc_tl_sq_summary.txt 2>/dev/null; rm -rf gpurun_out/pmc_tl_sq/*_p*; tail -3 $O/pmc_tl_sq.log
 cat $O/tl33_by_position.txt
+# what each call-site edit of INTEGRATION.md section 6 buys: the headline step with one of them undone at a time
+cd $R
+for fl in "" "--torch-loss" "--torch-adam" "--no-prefetch-maps" "--no-prefetch-maps --no-prefetch-pyramid" "--torch-loss --torch-adam --no-prefetch-maps --no-prefetch-pyramid"; do
+  timeout 200 python bench.py --steps 30 --warmup 8 --train-only --no-cpu-baseline --no-kernel-events --detail $O/ladder_detail.json $fl > $O/ladder.tmp 2>/dev/null
+  python -c "
+import json
+d=json.loads(open('$O/ladder.tmp').read().strip().splitlines()[-1]); print('%-80s %.3f ms/step' % ('[$fl]', d['ms_per_step']))" >> $O/call_site_ladder.txt
+done
+timeout 200 python bench.py --dist-single --steps 30 --warmup 8 --train-only --no-cpu-baseline --no-kernel-events --detail $O/ladder_detail.json > $O/ladder.tmp 2>$O/dist_single.err
+python -c "
+import json
+d=json.loads(open('$O/ladder.tmp').read().strip().splitlines()[-1]); print('%-80s %.3f ms/step  comm %s' % ('[--dist-single: one-rank RCCL group, sliced exchange]', d['ms_per_step'], d.get('comm')))" >> $O/call_site_ladder.txt
+OSN_GRAD_SEGMENTS=1 timeout 200 python bench.py --dist-single --steps 30 --warmup 8 --train-only --no-cpu-baseline --no-kernel-events --detail $O/ladder_detail.json > $O/ladder.tmp 2>>$O/dist_single.err
+python -c "
+import json
+d=json.loads(open('$O/ladder.tmp').read().strip().splitlines()[-1]); print('%-80s %.3f ms/step' % ('[--dist-single OSN_GRAD_SEGMENTS=1: one collective after backward]', d['ms_per_step']))" >> $O/call_site_ladder.txt
+cat $O/call_site_ladder.txt
 python -c "
 import json
 for l in open('$O/bench.json'):
