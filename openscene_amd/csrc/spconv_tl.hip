@@ -42,6 +42,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TL_BMAX = 88;       // rows per tile at most (LDS budget of the 128-column instance, 2 workgroups / CU)
 constexpr int TL_BMIN = 32;       // rows per tile of small tables
+constexpr int TL_BOCC3 = 64;      // rows per tile that osn_tile_rows hands out at most (three workgroups per CU, see there)
 constexpr int TL_LCAP = 1024;     // packed list entries resident in LDS per batch of offsets
 constexpr int TL_STEPS = TL_LCAP / 32 * 4;   // step-table entries: 32-pair steps of a batch x channel chunks (<= 4: 512 channels)
 constexpr int TL_KMAX = 128;      // kernel offsets a list-mode launch can take (5^3 = 125)
@@ -117,8 +118,8 @@ __global__ void weight_prep_tl_kernel(const float* __restrict__ W, int K, int ci
 // (B fragments of a chunk: KS k-steps x 2 column blocks x 3 planes = 24 KS VGPRs).  KS is the k-step count that
 // tiles the input channels without a remainder where one exists (96 channels: KS = 3 -- with the fixed 128-channel
 // chunk of round 2 a quarter of the weight-fragment loads and of the gather lanes of every 96-channel conv was padding).
-template <int NW, int KS, bool RAGGED, bool PROF = false>
-__global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restrict__ in, const bf16x8* __restrict__ Wp,
+template <int NW, int KS, bool RAGGED, bool PROF = false, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __restrict__ in, const bf16x8* __restrict__ Wp,
                                                                const int32_t* __restrict__ cnt, const int2* __restrict__ lst,
                                                                const int32_t* __restrict__ out_rows, float* __restrict__ out,
                                                                double* __restrict__ bn_partial, int32_t* __restrict__ counter,
@@ -133,7 +134,9 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
     constexpr int QPR = CK / 4;                           // 4-channel quads per staged row
     constexpr int NQ = (32 * QPR + NT - 1) / NT;          // quads per thread per step
     constexpr int NL = (TL_LCAP + NT - 1) / NT;           // list entries per thread per batch
-    __shared__ __attribute__((aligned(16))) float otile[(TL_BMAX + 1) * S];     // + one dump row for padded pairs
+    // the fp32 output tile: bm rows + one dump row for padded pairs.  Dynamic LDS (sized by the launch from the map's tile height):
+    // a 64-row tile leaves room for a third workgroup per CU (the OCC = 3 instances)
+    extern __shared__ __attribute__((aligned(16))) float otile[];
     __shared__ __attribute__((aligned(16))) __bf16 stage[3][32][LDA];
     __shared__ uint32_t plist[TL_LCAP];       // (local output row << 24) | input row, 32-padded per offset
     __shared__ int klist[TL_KMAX];
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
         const int row0 = tile * bm;
         const int rows = min(bm, n_out - row0);
 
-        for (int i = tid; i < (TL_BMAX + 1) * S / 4; i += NT)
+        for (int i = tid; i < (bm + 1) * S / 4; i += NT)
             reinterpret_cast<float4*>(otile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
         // ---- active offsets of the tile, ascending (=> fixed summation order)
@@ -264,12 +267,12 @@ __global__ __launch_bounds__(256, 2) void spconv_tl_kernel(const float* __restri
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
                     // padded pair: input row 0 (valid address), dump row
-                    const uint32_t v = okv[j] ? ((uint32_t(x[j].y) << 24) | uint32_t(x[j].x)) : (uint32_t(TL_BMAX) << 24);
+                    const uint32_t v = okv[j] ? ((uint32_t(x[j].y) << 24) | uint32_t(x[j].x)) : (uint32_t(bm) << 24);
                     if (tid + NT * j < E) plist[tid + NT * j] = v;
                 }
             } else {
                 for (int e = tid; e < E; e += NT)
-                    plist[e] = e < rows ? ((uint32_t(e) << 24) | uint32_t(row0 + e)) : (uint32_t(TL_BMAX) << 24);
+                    plist[e] = e < rows ? ((uint32_t(e) << 24) | uint32_t(row0 + e)) : (uint32_t(bm) << 24);
             }
             // step table of the batch: offset a owns entries [nchunk (lstart[a] / 32), + nchunk niter(a)), chunk-major
             const int nchunk = (ns + KS - 1) / KS;
@@ -536,11 +539,14 @@ static int tl_waves(int cout) {
 using namespace osn;
 
 extern "C" int osn_tile_rows(int64_t n_out) {
-    // rows per tile: about two rounds of 512 workgroups, between 32 and 88 rows, a multiple of 8
-    int64_t bm = cdiv(n_out > 0 ? n_out : 1, 2 * TL_SLOTS);
+    // rows per tile: about two rounds of the persistent workgroups, a multiple of 8 between 32 and 64.  Round 4: at most 64 rows
+    // (was 88) -- with the output tile in dynamic LDS a <= 64-row tile of <= 96 columns lets THREE workgroups share a CU (the
+    // OCC = 3 instances: level-0 96 -> 96 133 -> 126 us, level-1 105 -> 99 us), and the instances that stay at two workgroups per CU
+    // lose nothing (128 -> 96: 162 / 163 us at 88 / 64 rows)
+    int64_t bm = cdiv(n_out > 0 ? n_out : 1, 2 * (TL_SLOTS / 2 * 3));
     bm = (bm + 7) / 8 * 8;
     if (bm < TL_BMIN) bm = TL_BMIN;
-    if (bm > TL_BMAX) bm = TL_BMAX;
+    if (bm > TL_BOCC3) bm = TL_BOCC3;
     return int(bm);
 }
 
@@ -654,8 +660,8 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
     }
     const int ns = (cin + 31) / 32, ncb = (cout + 15) / 16;
     const int64_t units = n_tiles * nz;
-    const unsigned gx = unsigned(units < TL_SLOTS ? units : TL_SLOTS);
-    const dim3 grid(gx, unsigned(gy));
+    unsigned gx = unsigned(units < TL_SLOTS ? units : TL_SLOTS);
+    dim3 grid(gx, unsigned(gy));
     const bf16x8* wp = static_cast<const bf16x8*>(Wp);
     // k-steps per channel chunk: the whole contraction when it fits (<= 4 k-steps), else the divisor of the k-step count
     // that leaves no padded chunk (192 channels: 2 x 3), else 4
@@ -664,9 +670,33 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
                 "osn_spconv_fwd_tl: %d input channels need more than %d channel chunks per list batch (the kernel's step table); "
                 "use osn_dense_fwd (K == 1) or osn_spconv_fwd_x6", cin, TL_STEPS / (TL_LCAP / 32));
     const bool ragged = (cin & 31) != 0 || ns % ks != 0;
-#define OSN_TL3(NW_, KS_, RG_, PF_)                                                                                        \
-    hipLaunchKernelGGL((spconv_tl_kernel<NW_, KS_, RG_, PF_>), grid, dim3(256), 0, st, in, wp, cnt, lst, out_rows, out,     \
-                       bn_partial, counter, partial, nz, int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof)
+    const bool ragged_host = ragged;
+    const int ks_host = ks;
+    // dynamic LDS = the output tile; beyond 64 KB per workgroup in total the kernel needs the opt-in attribute (once per instance)
+    const size_t tile_bytes = size_t(bm + 1) * size_t(32 * nw + 4) * 4;
+    // three workgroups per CU when the tile is low enough (<= 64 rows at <= 96 output columns: 3 x 53.7 KB) -- OSN_TL_OCC3=0 keeps two
+    static const bool occ3_on = [] { const char* e = getenv("OSN_TL_OCC3"); return !(e && e[0] == '0'); }();
+    const bool occ3 = occ3_on && !prof && !ragged_host && nw <= 3 && ks_host <= 3 && tile_bytes + 28 * 1024 <= 54 * 1024;
+    int rc_attr = OSN_OK;
+    if (occ3) {                                       // three persistent workgroups per CU
+        gx = unsigned(units < TL_SLOTS / 2 * 3 ? units : TL_SLOTS / 2 * 3);
+        grid = dim3(gx, unsigned(gy));
+    }
+#define OSN_TL4(NW_, KS_, RG_, PF_, OC_)                                                                                   \
+    do {                                                                                                                   \
+        auto kern = spconv_tl_kernel<NW_, KS_, RG_, PF_, OC_>;                                                             \
+        static size_t attr_bytes = 36 * 1024;                                                                              \
+        if (tile_bytes > attr_bytes) {                                                                                     \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(tile_bytes)) != hipSuccess) { \
+                rc_attr = OSN_E_HIP;                                                                                       \
+                break;                                                                                                     \
+            }                                                                                                              \
+            attr_bytes = tile_bytes;                                                                                       \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(kern, grid, dim3(256), tile_bytes, st, in, wp, cnt, lst, out_rows, out, bn_partial, counter, partial, nz, \
+                           int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof);                         \
+    } while (0)
+#define OSN_TL3(NW_, KS_, RG_, PF_) OSN_TL4(NW_, KS_, RG_, PF_, 2)
 #define OSN_TL2(NW_, KS_)                                                                                                  \
     do {                                                                                                                   \
         if (prof) {                                                                                                        \
@@ -674,6 +704,8 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
             else OSN_TL3(NW_, KS_, false, true);                                                                           \
         } else if (ragged) {                                                                                               \
             OSN_TL3(NW_, KS_, true, false);                                                                                \
+        } else if (occ3 && NW_ <= 3 && KS_ <= 3) {                                                                         \
+            OSN_TL4((NW_ <= 3 ? NW_ : 3), (KS_ <= 3 ? KS_ : 3), false, false, 3);                                          \
         } else {                                                                                                           \
             OSN_TL3(NW_, KS_, false, false);                                                                               \
         }                                                                                                                  \
@@ -696,6 +728,8 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
 #undef OSN_TL
 #undef OSN_TL2
 #undef OSN_TL3
+#undef OSN_TL4
+    OSN_REQUIRE(rc_attr == OSN_OK, OSN_E_HIP, "osn_spconv_fwd_tl: cannot reserve %zu bytes of LDS for the output tile", tile_bytes);
     OSN_LAUNCH_CHECK();
     if (nz > 1) {
         const int64_t total4 = n_out * (cout / 4);

@@ -129,10 +129,10 @@ class TileLists:
 
 
 def tile_rows(n_out):
-    """Spec of osn_tile_rows: about two rounds of 512 workgroups, 32 .. 88 rows, a multiple of 8."""
-    bm = -(-max(int(n_out), 1) // 1024)
+    """Spec of osn_tile_rows: about two rounds of 768 workgroups (three per CU), 32 .. 64 rows, a multiple of 8."""
+    bm = -(-max(int(n_out), 1) // 1536)
     bm = (bm + 7) // 8 * 8
-    return max(32, min(88, bm))
+    return max(32, min(64, bm))
 
 
 def tile_lists(nbr, out_rows=None, bm=None):

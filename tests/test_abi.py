@@ -29,11 +29,11 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert lib.osn_spconv_fwd_ws_bytes(100999, 1, 96, 768) == 0
     assert lib.osn_spconv_fwd_ws_bytes(700, 27, 256, 256) > 0            # deep level: split + reduce buffer
     assert lib.osn_weight_prep_x6_bytes(27, 96, 128, 0) == 3 * 27 * 128 * 96 * 2
-    # second-generation kernels: tile rows between 32 and 88, fragment images of 1 KB blocks, pair-list buffers
-    assert lib.osn_tile_rows(100999) == 88 and lib.osn_tile_rows(3052) == 32 and lib.osn_tile_rows(47618) == 48
+    # second-generation kernels: tile rows between 32 and 64 (round 4: three workgroups per CU), fragment images of 1 KB blocks, pair-list buffers
+    assert lib.osn_tile_rows(100999) == 64 and lib.osn_tile_rows(3052) == 32 and lib.osn_tile_rows(47618) == 32
     assert lib.osn_weight_prep_tl_bytes(27, 96, 96, 0) == 3 * 27 * 3 * 6 * 1024
     assert lib.osn_tile_lists_bytes(1000, 27, 32) > 27 * 1000 * 8 and lib.osn_pair_lists_bytes(1000, 27, 32) > 2 * 27 * 1000 * 4
-    assert lib.osn_spconv_fwd_tl_ws_bytes(100999, 27, 96, 88) == 512                 # big table: no offset split
+    assert lib.osn_spconv_fwd_tl_ws_bytes(100999, 27, 96, 64) == 512                 # big table: no offset split
     assert lib.osn_spconv_fwd_tl_ws_bytes(700, 27, 256, 32) > 256                    # small table: partial tiles
 
 
