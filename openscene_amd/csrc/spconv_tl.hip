@@ -159,7 +159,10 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform => scalar registers
     const int col0 = blockIdx.y * CW;
-    const int cb0 = blockIdx.y * (2 * NW) + 2 * wave;                  // this wave's first 16-column block
+    // (Rotating which wave of a workgroup is the staging-only one -- so that the staging waves of co-resident workgroups do not
+    // all sit on one SIMD -- was measured: 1 - 7 % SLOWER, profiles/r04_s6_ab_wave_role_rotation.txt.  Waves keep their columns.)
+    const int cw = wave;                                               // column-owner index of this wave (>= NW: staging only)
+    const int cb0 = blockIdx.y * (2 * NW) + 2 * cw;                    // this wave's first 16-column block
 
     // loop-invariant staging coordinates of this thread's quads (full 128-channel rows; narrower chunks mask)
     int q_row[NQ], q_col[NQ];
@@ -348,14 +351,14 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
                 TL_TICK(2)                                 // 2: wait for the gathered rows + split
                 // ---- new (offset, chunk): B fragments of this wave's 32 columns, one coalesced 1 KB load each -- unless the
                 // previous step already fetched them behind its own MFMAs (see the end of the k-step loop)
-                if (it.first() && !b_ahead && wave < NW) {
+                if (it.first() && !b_ahead && cw < NW) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) load_b(ks, it);
                 }
                 // the NEXT step opens a new (offset, chunk): its fragments are loaded into the registers of k-step ks as soon as
                 // this step's MFMAs of ks are issued (the last use of the current ones), i.e. beside the remaining MFMAs, the tile
                 // write-back and the two barriers -- no second register set
-                const bool ahead = n1s.valid() && n1s.first() && wave < NW;
+                const bool ahead = n1s.valid() && n1s.first() && cw < NW;
                 TL_TICK(8)                                 // 8: B-load issue
                 __syncthreads();                           // every wave is done reading the previous stage
                 TL_TICK(3)                                 // 3: barrier A
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
                 TL_TICK(9)                                 // 9: stage write + next gather issue
                 __syncthreads();                           // stage ready
                 TL_TICK(4)                                 // 4: barrier B
-                if (wave >= NW) { b_ahead = false; return; }   // staging-only wave
+                if (cw >= NW) { b_ahead = false; return; }     // staging-only wave
                 // ---- 32 pairs x 32 columns per wave: accumulator blocks [pair half][column block]
                 // (the last step of an offset may hold at most 16 pairs -- the average (tile, offset) of a 100 k-row map
                 // has 36 -- : its second 16-pair half is all padding and is skipped: MFMAs, fragment reads, tile update)
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     if (h == 0 || half1) {
-                        ocell[h] = int(plist[pbase + 16 * h] >> 24) * S + 32 * wave + 4 * (lane >> 4);
+                        ocell[h] = int(plist[pbase + 16 * h] >> 24) * S + 32 * cw + 4 * (lane >> 4);
                         const f32x4* cell = reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&otile[ocell[h]], 16));
 #pragma unroll
                         for (int nb = 0; nb < 2; ++nb) acc[h][nb] = cell[4 * nb];
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
         for (int i = 0; i < 10; ++i) prof[int64_t(blockIdx.x) * 10 + i] = tacc[i];
     // caller-owned persistent counters: the last workgroup of a column group to leave (every other one has made its final
     // draw before it took its exit ticket) puts both counters back to zero for the next launch -- no memset per call
-    if (self_reset && tid == 0) {
+    if ((self_reset & 1) && tid == 0) {
         const int done = atomicAdd(&counter[64 + blockIdx.y], 1);
         if (done == int(gridDim.x) - 1) {
             counter[blockIdx.y] = 0;
