@@ -132,6 +132,7 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
         if (o.dst < 0 && o.K == 1 && training) {          // room for osn_net_run.goutput_rows (at most every row)
             L.rows_in_off = b; b += up256(uint64_t(n_in) * o.cin * 4);
             L.rows_gin_off = b; b += up256(uint64_t(n_in) * o.cin * 4);
+            need_ws(osn_spconv_wgrad_ws_bytes(n_out, 1, o.cin, o.cout));      // the row-compacted weight gradient runs on the table kernel
         }
         // ---- forward kernel
         if (stem_eligible(o.K, o.cin, o.cout)) {

@@ -19,6 +19,8 @@ from ._lib import check
 
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, model_or_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if not isinstance(model_or_params, torch.nn.Module):
+            model_or_params = list(model_or_params)          # (a generator such as model.parameters() is consumed once)
         params = self._ordered(model_or_params)
         # checkpoint index of every parameter = its position in `model.parameters()` order (what torch.optim.Adam, built the
         # way run/distill.py:141 builds it, keys its state by) -- NOT its position in the flat layout, which follows the

@@ -147,6 +147,35 @@ def test_disnet_distill_step_and_row_order():
     assert sum(float(g.abs().sum()) for g in grads) > 0
 
 
+def test_row_sparse_head_with_a_narrow_head(monkeypatch):
+    """A head of <= 128 channels plans the pair-array weight gradient; the row-compacted path runs the table kernel instead
+    and needs its scratch (the executor's plan reserves it)."""
+    from openscene_amd import executor as E, losses
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import SparseTensor
+    torch.manual_seed(4)
+    model = mink_unet(3, 64, 3, "MinkUNet14A").to(dev()).train()
+    coords = torch.from_numpy(scene_coords(9, 9000, 0.05)).to(dev())
+    n = coords.shape[0]
+    feats = torch.rand(n, 3, device=dev())
+    sel = torch.arange(0, n, 4, device=dev())
+    target = torch.nn.functional.normalize(torch.randn(sel.shape[0], 64, device=dev()), dim=1)
+    res = []
+    for sparse in (True, False):
+        monkeypatch.setattr(E, "ROW_SPARSE_HEAD", sparse)
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.reset_running_stats()
+        model.zero_grad(set_to_none=True)
+        losses.distill_loss(model(SparseTensor(feats, coords)), sel, target).backward()
+        res.append({k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    for k in res[0]:
+        if k == "final.kernel":
+            assert rel_l2(res[0][k], res[1][k]) <= 2e-6
+        else:
+            assert torch.equal(res[0][k], res[1][k]), k
+
+
 @pytest.mark.parametrize("kind", ["cosine", "l1"])
 def test_row_sparse_head_gradients_equal_the_dense_path(kind, monkeypatch):
     """Round 4: distill_loss hands the executor the non-zero rows of the output gradient (the loss sees `output[sel]`,

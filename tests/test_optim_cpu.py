@@ -147,3 +147,15 @@ def test_flat_adam_checkpoints_round_trip_with_torch_adam_on_a_model(fake_adam):
     other = torch.optim.Adam(mink_unet(3, 20, 3, "MinkUNet18A").parameters(), lr=1e-3).state_dict()
     with pytest.raises(ValueError):
         ours.load_state_dict(other)
+
+
+def test_flat_adam_accepts_a_parameter_generator(fake_adam):
+    """torch.optim.Adam(model.parameters()) is the reference's call (run/distill.py:141): a generator must work here too."""
+    from openscene_amd.optim import FlatAdam
+    lin = torch.nn.Linear(4, 3)
+    opt = FlatAdam(lin.parameters(), lr=1e-2)
+    assert len(opt._params) == 2 and opt._ckpt_index == [0, 1]
+    for p in lin.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    assert fake_adam.calls == 1
