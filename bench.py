@@ -607,6 +607,28 @@ def spawn_command(n, argv, port=None):
             "--master-port", str(port or _free_port()), os.path.abspath(__file__)] + list(argv)
 
 
+_STDOUT_FD = None
+
+
+def claim_stdout():
+    """From here on file descriptor 1 is stderr for everybody in this process -- RCCL prints its version banner to C stdout (it
+    landed BEHIND the headline in a redirected run, profiles/r04_s8_call_site_ladder.txt), hipcc / rocprofv3 helpers may chat --
+    and the one JSON line goes to the descriptor the caller gave us, through emit_line()."""
+    global _STDOUT_FD
+    if _STDOUT_FD is None:
+        sys.stdout.flush()
+        _STDOUT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(text):
+    sys.stdout.flush()
+    data = (text.rstrip("\n") + "\n").encode()
+    fd = _STDOUT_FD if _STDOUT_FD is not None else 1
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def self_spawn(n):
     cmd = spawn_command(n, sys.argv[1:])
     print("[bench] --gpus %d without a launcher: re-executing under torch.distributed.run" % n, file=sys.stderr, flush=True)
@@ -637,7 +659,7 @@ def spawn_self_test(rank, world, args):
                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                   "config": {"workload": "spawn self-test (no GPU work)", "parallelism": "dp%d" % world},
                   "roofline": None, "cpu_baseline": None, "loss": float(acc.sum())}
-        print(json.dumps(headline(detail, None), separators=(",", ":")))
+        emit_line(json.dumps(headline(detail, None), separators=(",", ":")))
     dist.destroy_process_group()
 
 
@@ -696,6 +718,7 @@ def main():
             # called the way N = 1 is called: start the ranks ourselves (the reference spawns its own, run/distill.py:113-116)
             self_spawn(args.gpus)
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    claim_stdout()
     if args.spawn_self_test:
         return spawn_self_test(rank, world, args)
     if os.environ.get("OSN_BENCH_ONE_DEVICE") == "1":
@@ -1331,7 +1354,7 @@ def main():
     }
     detail_path = write_detail(detail, args.detail)
     line = headline(detail, detail_path)
-    print(json.dumps(line, separators=(",", ":")))
+    emit_line(json.dumps(line, separators=(",", ":")))
     if dist_on:
         dist.destroy_process_group()
 

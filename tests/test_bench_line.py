@@ -60,8 +60,8 @@ def test_gpus_n_without_a_launcher_spawns_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--spawn-self-test"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = r.stdout.strip().splitlines()        # file descriptor 1 carries the headline and NOTHING else (claim_stdout)
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
     assert d["value"] > 0 and d["config"]["parallelism"] == "dp2"
@@ -74,3 +74,14 @@ def test_spawn_command_is_the_drivers_launch_line():
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "20"]
+
+
+def test_library_chatter_on_fd1_does_not_reach_the_callers_stdout():
+    """RCCL prints its version banner to C stdout; after claim_stdout() that descriptor is stderr and the headline is the only
+    thing the caller's stdout sees."""
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; bench.claim_stdout(); "
+            "os.write(1, b'RCCL version : x\\n'); print('python chatter'); bench.emit_line('{\"a\":1}')") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == '{"a":1}\n'
+    assert "RCCL version" in r.stderr and "python chatter" in r.stderr

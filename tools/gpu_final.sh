@@ -38,16 +38,16 @@ for fl in "" "--torch-loss" "--torch-adam" "--no-prefetch-maps" "--no-prefetch-m
   timeout 200 python bench.py --steps 30 --warmup 8 --train-only --no-cpu-baseline --no-kernel-events --detail $O/ladder_detail.json $fl > $O/ladder.tmp 2>/dev/null
   python -c "
 import json
-d=json.loads(open('$O/ladder.tmp').read().strip().splitlines()[-1]); print('%-80s %.3f ms/step' % ('[$fl]', d['ms_per_step']))" >> $O/call_site_ladder.txt
+d=[json.loads(l) for l in open('$O/ladder.tmp') if l.startswith('{')][-1]; print('%-80s %.3f ms/step' % ('[$fl]', d['ms_per_step']))" >> $O/call_site_ladder.txt
 done
 timeout 200 python bench.py --dist-single --steps 30 --warmup 8 --train-only --no-cpu-baseline --no-kernel-events --detail $O/ladder_detail.json > $O/ladder.tmp 2>$O/dist_single.err
 python -c "
 import json
-d=json.loads(open('$O/ladder.tmp').read().strip().splitlines()[-1]); print('%-80s %.3f ms/step  comm %s' % ('[--dist-single: one-rank RCCL group, sliced exchange]', d['ms_per_step'], d.get('comm')))" >> $O/call_site_ladder.txt
+d=[json.loads(l) for l in open('$O/ladder.tmp') if l.startswith('{')][-1]; print('%-80s %.3f ms/step  comm %s' % ('[--dist-single: one-rank RCCL group, sliced exchange]', d['ms_per_step'], d.get('comm')))" >> $O/call_site_ladder.txt
 OSN_GRAD_SEGMENTS=1 timeout 200 python bench.py --dist-single --steps 30 --warmup 8 --train-only --no-cpu-baseline --no-kernel-events --detail $O/ladder_detail.json > $O/ladder.tmp 2>>$O/dist_single.err
 python -c "
 import json
-d=json.loads(open('$O/ladder.tmp').read().strip().splitlines()[-1]); print('%-80s %.3f ms/step' % ('[--dist-single OSN_GRAD_SEGMENTS=1: one collective after backward]', d['ms_per_step']))" >> $O/call_site_ladder.txt
+d=[json.loads(l) for l in open('$O/ladder.tmp') if l.startswith('{')][-1]; print('%-80s %.3f ms/step' % ('[--dist-single OSN_GRAD_SEGMENTS=1: one collective after backward]', d['ms_per_step']))" >> $O/call_site_ladder.txt
 cat $O/call_site_ladder.txt
 python -c "
 import json
