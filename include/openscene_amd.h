@@ -576,6 +576,12 @@ typedef struct osn_net_bn {
 } osn_net_bn;
 typedef struct osn_prof osn_prof_t;           /* optional launch timer, see osn_prof_create                       */
 typedef struct osn_events osn_events_t;       /* pool of HIP events for the fork / join of the backward pass      */
+/* osn_net_run.flags.  NO_JOIN (backward pass with a side stream, a call that is NOT the last segment of the pass): return
+ * without making `stream` wait for the side stream.  The weight gradients of the executed ops are then final in SIDE-stream
+ * order only -- a consumer (the gradient exchange of a segmented pass) must queue behind the side stream; the call that
+ * plays the last segment (flags 0) joins everything.  Input gradients a later segment reads are joined by their own events
+ * either way.                                                                                                      */
+#define OSN_NET_RUN_NO_JOIN 1
 typedef struct osn_net_run {
     const int64_t* level_rows;   /* [n_levels] rows of every pyramid level                                        */
     const osn_net_map* maps;
@@ -590,7 +596,7 @@ typedef struct osn_net_run {
     int32_t* tl_counters;        /* 128 persistent tile counters of this stream (osn_spconv_fwd_tl_pc)            */
     int32_t training;            /* batch statistics + running update (1) or running statistics (0)               */
     int32_t first_op, end_op;    /* ops [first_op, end_op) are executed                                           */
-    int32_t reserved;
+    int32_t flags;               /* OSN_NET_RUN_*                                                                 */
     osn_prof_t* prof;            /* nullable                                                                      */
     /* all nullable: work that is off the main dependency chain runs on `side_stream` -- in both passes the BasicBlock
      * shortcut stages (1x1 conv + batch norm, beside conv1 - BN - conv2), in the backward pass also every weight

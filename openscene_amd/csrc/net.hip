@@ -593,7 +593,10 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
     // the pair-array weight gradients still waiting for their reduction: one launch (instead of one per convolution)
     rc = osn_wgrad_tl_reduce_batch(jobs.data(), int(jobs.size()), wstream);
     if (rc) return rc;
-    if (forked) {                                          // join: everything after the pass sees the side stream's work
+    // join: everything after the pass sees the side stream's work.  (Not after an inner segment of a segmented pass when the
+    // caller says so: the main stream would stall three more times per pass on weight gradients nothing on it reads --
+    // 0.27 ms per step, profiles/r04_s9_dist_readiness.txt; the exchange of those gradients queues behind the side stream.)
+    if (forked && !(run->flags & OSN_NET_RUN_NO_JOIN)) {
         OSN_HIP(hipEventRecord(evs->ev[net->n_ops], side));
         OSN_HIP(hipStreamWaitEvent(st, evs->ev[net->n_ops], 0));
     }

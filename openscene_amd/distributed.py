@@ -77,15 +77,13 @@ class FlatGradAllReduce(object):
             self._broadcast(self.int_buffers)
 
     def _common_base(self):
-        """The one contiguous fp32 tensor all gradients are views of (same on every rank: the executor's layout is a function
-        of the module tree), or None."""
-        base = None
-        for p in self.params:
-            g = p.grad
-            b = None if g is None else g._base
-            if b is None or b.dim() != 1 or not b.is_contiguous() or b.dtype != self.flat.dtype or (base is not None and b is not base):
-                return None
-            base = b
+        """The one contiguous fp32 buffer all gradients live in (same on every rank: the executor's layout is a function of
+        the module tree) as a 1-D tensor over their common storage, or None.  See optim.shared_flat for why this is decided
+        by storage and not by `_base`."""
+        from .optim import shared_flat
+        base = shared_flat([p.grad for p in self.params])
+        if base is None or base.dtype != self.flat.dtype or base.device != self.flat.device:
+            return None
         return base
 
     # ---- overlapped exchange of the executor's flat gradient buffer --------------------------------------------
@@ -119,6 +117,13 @@ class FlatGradAllReduce(object):
             if w is not None:
                 self._pending.append(w)
         self._sliced[1] = min(self._sliced[1], lo)
+        if last:
+            # before autograd sees the gradients: it may keep the slices' memory (the normal case) or CLONE them (hooks on a
+            # parameter, a second use) -- a clone taken with a collective in flight would hold half-exchanged values.  With
+            # RCCL this is a stream-side wait (the host does not block), and it is the wait reduce_gradients() would do anyway.
+            for w in self._pending:
+                w.wait()
+            self._pending = []
 
     def reduce_gradients(self):
         """After backward: p.grad <- mean over ranks, as views of the flat buffer (no copy back).
@@ -128,23 +133,27 @@ class FlatGradAllReduce(object):
         run, where such a parameter keeps grad None (no parameter of the MinkUNet family is unused)."""
         # the network executor (openscene_amd/executor.py) hands every gradient out as a view of ONE flat buffer it wrote
         # in place: exchange that buffer itself -- no gather copy, the optimizer keeps reading the same views
+        for w in self._pending:                     # (a backward pass that did not reach its last segment)
+            w.wait()
+        self._pending = []
         base = self._common_base()
         if base is not None:
             sl = getattr(self, "_sliced", None)
-            if sl is not None and sl[0] is base:
+            if sl is not None and sl[0].untyped_storage().data_ptr() == base.untyped_storage().data_ptr():
                 # slices [sl[1], sl[2]) went out during the backward pass: what is left is the head of the kernels' region
                 # (nothing, normally) and the batch-norm region behind it
                 if sl[1] > 0:
                     self._avg(base[:sl[1]], async_op=False)
                 if sl[2] < base.numel():
                     self._avg(base[sl[2]:], async_op=False)
-                for w in self._pending:
-                    w.wait()
-                self._pending = []
                 self._sliced = None
                 return
+            self._sliced = None
             self._avg(base, async_op=False)
             return
+        # (gradients that do not share one buffer -- e.g. autograd cloned them: slices exchanged during the pass are final in
+        # the clones, a second average of equal values changes nothing but round-off)
+        self._sliced = None
         grads = []
         for p, v in zip(self.params, self.views):
             if p.grad is None:

@@ -69,11 +69,14 @@ class _Run(ctypes.Structure):
                 ("bwd_arena", ctypes.c_void_p), ("bwd_arena_bytes", ctypes.c_uint64),
                 ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_uint64),
                 ("tl_counters", ctypes.c_void_p), ("training", ctypes.c_int32), ("first_op", ctypes.c_int32),
-                ("end_op", ctypes.c_int32), ("reserved", ctypes.c_int32), ("prof", ctypes.c_void_p),
+                ("end_op", ctypes.c_int32), ("flags", ctypes.c_int32), ("prof", ctypes.c_void_p),
                 ("side_stream", ctypes.c_void_p), ("ws_side", ctypes.c_void_p), ("ws_side_bytes", ctypes.c_uint64),
                 ("events", ctypes.c_void_p),
                 ("grows_pos", ctypes.c_void_p), ("grows_idx", ctypes.c_void_p), ("goutput_rows", ctypes.c_void_p),
                 ("n_grows", ctypes.c_int64)]
+
+
+RUN_NO_JOIN = 1                                 # include/openscene_amd.h: OSN_NET_RUN_NO_JOIN
 
 
 def _ptr(a):
@@ -422,12 +425,24 @@ class UNetExecutor:
             else:
                 # the pass in segments, highest ops first; after each, the weight-gradient slices of its convolutions are final
                 # (every segment ends with the join of the weight-gradient stream) and the hook may start exchanging them
+                # An inner segment does not join the weight-gradient stream into the main stream (RUN_NO_JOIN): its slices are
+                # final in that stream's order, so its hook runs with THAT stream current -- a collective queues behind what the
+                # current stream holds -- and the main stream goes on with the next segment.  The last segment joins everything.
                 hi = len(p.ops)
+                forked = bool(run.side_stream) and bool(run.events) and not _DRY_RUN
                 for lo in self.backward_cuts():
                     run.first_op, run.end_op = lo, hi
+                    inner = forked and lo > 0
+                    run.flags = RUN_NO_JOIN if inner else 0
                     check(lib.osn_net_backward(ctypes.addressof(self.desc), ctypes.addressof(run), ops._stream(dev)), "osn_net_backward")
-                    hook(grads, self.grad_off[lo], self.grad_off[hi] if hi < nc else self.conv_grad_end, lo == 0)
+                    lo_f, hi_f = self.grad_off[lo], self.grad_off[hi] if hi < nc else self.conv_grad_end
+                    if inner:
+                        with torch.cuda.stream(ops.side_stream(dev)):
+                            hook(grads, lo_f, hi_f, False)
+                    else:
+                        hook(grads, lo_f, hi_f, lo == 0)
                     hi = lo
+                run.flags = 0
         return [grads[o:o + q.numel()].view_as(q) for o, q in zip(self.grad_off, p.params)]
 
     def backward_cuts(self):

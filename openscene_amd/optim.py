@@ -17,6 +17,30 @@ from . import ops
 from ._lib import check
 
 
+def shared_flat(grads):
+    """-> the ONE contiguous 1-D tensor all `grads` live in (a view over their common storage), or None.
+
+    Decided by STORAGE, not by `Tensor._base`: a gradient that came through autograd is `new_grad.detach()` of the slice the
+    backward function returned (AccumulateGrad keeps the memory, torch/csrc/autograd/functions/accumulate_grad.h) -- it
+    still aliases the executor's flat buffer but is no longer a view in the autograd sense, `_base` is None.  (Round 4 found
+    the `_base` test never true on a real backward pass: FlatAdam gathered a copy every step and, worse, an attached sliced
+    exchange fell through to a second full-buffer average on top of its in-flight slices.)"""
+    st = None
+    first = None
+    for g in grads:
+        if g is None or not g.is_contiguous() or g.is_sparse:
+            return None
+        s = g.untyped_storage()
+        if first is None:
+            first, st = g, s.data_ptr()
+        elif s.data_ptr() != st or g.dtype != first.dtype or g.device != first.device:
+            return None
+    if first is None or st == 0:
+        return None
+    n = first.untyped_storage().nbytes() // first.element_size()
+    return torch.empty(0, dtype=first.dtype, device=first.device).set_(first.untyped_storage(), 0, (n,))
+
+
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, model_or_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         if not isinstance(model_or_params, torch.nn.Module):
@@ -78,12 +102,9 @@ class FlatAdam(torch.optim.Optimizer):
         slice of it at the right offset, else a gathered copy (parameters without a gradient contribute zeros: like torch's
         Adam they would be skipped -- no MinkUNet parameter is unused)."""
         ps = self._params
-        g0 = ps[0].grad
-        root = g0._base if g0 is not None else None
-        if (root is not None and root.dim() == 1 and root.dtype == torch.float32 and root.is_contiguous() and
-                root.numel() >= self.total and root.storage_offset() == 0 and
-                all(p.grad is not None and p.grad._base is root and p.grad.storage_offset() == o and p.grad.is_contiguous()
-                    for p, o in zip(ps, self.offsets))):
+        root = shared_flat([p.grad for p in ps])
+        if (root is not None and root.dtype == torch.float32 and root.numel() >= self.total and
+                all(p.grad.storage_offset() == o for p, o in zip(ps, self.offsets))):
             return root[:self.total], True
         if self._grad_scratch is None:
             self._grad_scratch = torch.zeros_like(self.flat)

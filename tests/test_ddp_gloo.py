@@ -307,16 +307,24 @@ def _worker_sliced(rank, world, port, out_dir):
         offs.append(off)
         off += (p.numel() + 3) // 4 * 4
     kernels_end = offs[6]
-    for step in range(2):                                   # two steps: the state of the exchange resets between them
+    for step in range(3):                                   # three steps: the state of the exchange resets between them
         flat = torch.full((off,), float("nan"))
         for p, o in zip(params, offs):
             v = flat[o:o + p.numel()].view_as(p)
             v.copy_(torch.full_like(p, float(rank + 1 + step)) * (o + 1))
-            p.grad = v
+            # what autograd leaves in p.grad: the slice's memory, detached (no `_base`) -- steps 0, 1; or a CLONE taken when
+            # the node returned, i.e. right after the last hook call (hooks on a parameter make AccumulateGrad copy) -- step 2
+            p.grad = v.detach() if step < 2 else None
         for lo_i, hi_i in ((4, 6), (2, 4), (0, 2)):          # segments, highest "ops" first
             fake.grad_ready_hook(flat, offs[lo_i], offs[hi_i] if hi_i < 6 else kernels_end, lo_i == 0)
+        assert ex._pending == []                            # the last segment's hook waited for every slice in flight
+        if step == 2:
+            for p, o in zip(params, offs):
+                p.grad = flat[o:o + p.numel()].view_as(p).clone()
         ex.reduce_gradients()
-        assert all(p.grad._base is flat for p in params), "gradients were copied"
+        if step < 2:
+            assert all(p.grad._base is None and p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+                       for p in params), "gradients were copied"
         assert ex._pending == [] and ex._sliced is None
     torch.save({"g": [p.grad.clone() for p in params], "offs": offs}, os.path.join(out_dir, "s%d.pt" % rank))
     dist.barrier()
@@ -330,4 +338,4 @@ def test_sliced_exchange_during_a_segmented_backward_pass(tmp_path):
     a = torch.load(os.path.join(tmp_path, "s0.pt"))
     b = torch.load(os.path.join(tmp_path, "s1.pt"))
     for ga, gb, o in zip(a["g"], b["g"], a["offs"]):
-        assert torch.equal(ga, gb) and torch.equal(ga, torch.full_like(ga, 2.5 * (o + 1)))     # step 1: mean of 2 and 3
+        assert torch.equal(ga, gb) and torch.equal(ga, torch.full_like(ga, 3.5 * (o + 1)))     # step 2: mean of 3 and 4

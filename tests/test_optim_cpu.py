@@ -159,3 +159,45 @@ def test_flat_adam_accepts_a_parameter_generator(fake_adam):
         p.grad = torch.ones_like(p)
     opt.step()
     assert fake_adam.calls == 1
+
+
+class _FlatNode(torch.autograd.Function):
+    """What the network executor's autograd node does: every parameter's gradient is a slice of ONE buffer made in backward()."""
+    made = []
+
+    @staticmethod
+    def forward(ctx, x, *ps):
+        ctx.shapes = [p.shape for p in ps]
+        return x.sum() + sum((p * p).sum() for p in ps)
+
+    @staticmethod
+    def backward(ctx, g):
+        offs, off = [], 0
+        for s in ctx.shapes:
+            offs.append(off)
+            off += (s.numel() + 3) // 4 * 4
+        flat = torch.arange(off, dtype=torch.float32)
+        _FlatNode.made.append(flat.data_ptr())
+        return (None,) + tuple(flat[o:o + s.numel()].view(s) for o, s in zip(offs, ctx.shapes))
+
+
+def test_gradients_that_came_through_autograd_are_still_found_in_their_flat_buffer(fake_adam):
+    """AccumulateGrad keeps the memory of the slices the node returned but detaches them: `p.grad._base` is None although
+    every gradient still lives in the node's flat buffer.  Both consumers (FlatAdam, FlatGradAllReduce) must find the buffer
+    by storage -- round 4 found the `_base` test never true after a real backward pass."""
+    from openscene_amd.optim import FlatAdam, shared_flat
+    ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 2))]
+    opt = FlatAdam(ps, lr=1e-3)
+    _FlatNode.apply(torch.zeros(2), *ps).backward()
+    assert all(p.grad._base is None for p in ps)                         # the premise
+    flat = shared_flat([p.grad for p in ps])
+    assert flat is not None and flat.data_ptr() == _FlatNode.made[-1] and flat.numel() == 24
+    assert torch.equal(flat, torch.arange(24, dtype=torch.float32))
+    got, in_place = opt._flat_grads()
+    assert in_place and got.data_ptr() == _FlatNode.made[-1] and got.numel() == opt.total
+    # separately allocated gradients, a missing one, or a different layout: no shared buffer / the gathered copy
+    ps[1].grad = ps[1].grad.clone()
+    assert shared_flat([p.grad for p in ps]) is None and opt._flat_grads()[1] is False
+    ps[1].grad = None
+    assert shared_flat([p.grad for p in ps]) is None
+    assert shared_flat([]) is None
