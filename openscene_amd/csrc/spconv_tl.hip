@@ -201,6 +201,15 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
         const int zpart = draw - (draw / nz) * nz;
         const int row0 = tile * bm;
         const int rows = min(bm, n_out - row0);
+        // The tile's output row ids: loaded at the draw, parked before the epilogue in the unused tail of kcnt[] (K <= 40 offsets),
+        // so that no load sits between the last MFMA and the stores: 96 -> 96 -1 %, 128 -> 96 -2 % (profiles/r04_s11_*).  NO new LDS
+        // for it: 352 more bytes cross an allocation granule, the third workgroup per CU is gone and the kernel runs 138 instead
+        // of 125 us (measured).  Also measured there: the next draw issued at the start of the epilogue (-1 % / 0), and a whole
+        // tile of look-ahead -- draw and offset counts in flight across the steps -- 30 % SLOWER: the compiler's waitcnt pass sees
+        // loads pending across the step loop and gives up its counted waits, and a reserved tile is lost to the dynamic balance.
+        const bool park = K <= TL_KMAX - TL_BMAX;
+        int* const orow_s = kcnt + (TL_KMAX - TL_BMAX);
+        const int orow_pre = (park && tid < rows) ? (out_rows ? out_rows[row0 + tid] : row0 + tid) : 0;
 
         for (int i = tid; i < (bm + 1) * S / 4; i += NT)
             reinterpret_cast<float4*>(otile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -470,6 +479,7 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
             }
             a0 = a1;
         }
+        if (park && tid < rows) orow_s[tid] = orow_pre;
         __syncthreads();
 
         // ---- epilogue: tile rows -> out[out_rows[row]] (16-byte stores), optional batch-norm partial sums
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
                 if (nz > 1) {                              // partial tile of part z, table row order
                     *reinterpret_cast<float4*>(partial + (int64_t(zpart) * n_out + row0 + j) * cout + col) = v;
                 } else {
-                    const int64_t orow = out_rows ? out_rows[row0 + j] : row0 + j;
+                    const int64_t orow = park ? orow_s[j] : (out_rows ? out_rows[row0 + j] : row0 + j);
                     *reinterpret_cast<float4*>(out + orow * cout + col) = v;
                 }
             }

@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--points", type=int, default=20000)
     ap.add_argument("--time", type=int, default=0, help="also time N steps of each path (host cost with null launches)")
     ap.add_argument("--dump", action="store_true")
+    ap.add_argument("--profile", type=int, default=0, help="cProfile N executor steps (host cost by function)")
     args = ap.parse_args()
     import collections
     lib = install(build_dry_lib())
@@ -151,6 +152,22 @@ def main():
             for _ in range(args.time):
                 step()
             print("%s: %.2f ms host time per step (null launches, maps excluded)" % (name, (time.perf_counter() - t0) * 1e3 / args.time))
+
+
+    if args.profile:
+        import cProfile
+        import pstats
+        lib.osn_dry_logging(0)
+        executor.ENABLED = True
+        step()
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(args.profile):
+            step()
+        pr.disable()
+        st = pstats.Stats(pr)
+        st.sort_stats("cumulative").print_stats(45)
+        st.sort_stats("tottime").print_stats(30)
 
 
 if __name__ == "__main__":
