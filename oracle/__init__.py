@@ -18,7 +18,16 @@ Pinning status (see DESIGN.md "Oracle"):
     restate ME v0.5.4's published semantics and are
     anchored on the reference's call sites (``models/mink_unet.py:44-174``,
     ``models/resnet_base.py:73-118``) plus hand-derivable known-answer cases
-    (``tests/test_oracle_kat.py``).
+    (``tests/test_oracle_kat.py``).  What IS pinned short of the engine itself:
+    the reference's own ``models/mink_unet.py``, unmodified, executed on a
+    stand-in engine made of torch's dense conv3d / conv_transpose3d
+    (``tests/golden/dense_me.py`` + ``make_golden_unet.py`` ->
+    ``tests/golden/unet_dense_ref.npz``); ``unet_forward`` reproduces its
+    outputs, every gradient and the running statistics to 1e-11 in float64
+    (``tests/test_golden_unet.py``).  Layer plan, skip order, BN / residual
+    placement and operator arithmetic are therefore pinned; the engine's
+    CONVENTIONS (offset enumeration, even-kernel span, [Cin, Cout] 1x1
+    kernels) remain restated from its documentation.
   * query.py -- restates ``run/evaluate.py:283-324`` with plain torch ops (the
     reference expression is itself plain torch, so this is the reference
     arithmetic evaluated on CPU).

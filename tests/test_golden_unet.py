@@ -1,0 +1,100 @@
+"""The network golden vector tests/golden/unet_dense_ref.npz -- the reference's OWN models/mink_unet.py executed on a
+stand-in MinkowskiEngine made of torch's dense conv3d / conv_transpose3d (tests/golden/make_golden_unet.py,
+tests/golden/dense_me.py) -- against
+
+  * the CPU oracle (oracle/sparse_ops.unet_forward): float64, forward in both modes, every parameter gradient, the
+    input gradient and the running statistics -- this is what pins the "parity unpinned" part of the oracle to something
+    that is neither the oracle nor the product: the reference's layer plan run on torch's dense operators;
+  * the HIP path (GPU): fp32 network vs the float64 fixture, SURVEY.md 8(c) tolerance (rel-L2 <= 2e-4, max |delta| <=
+    1e-3 max |reference|), through the network executor and module by module.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_ops as so
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import unet_recipe as R  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    g = np.load(os.path.join(golden_dir, "unet_dense_ref.npz"))
+    coords, feats = R.cloud()
+    assert np.array_equal(coords, g["coords"]) and np.array_equal(feats, g["feats"]), "unet_recipe.cloud() drifted from the fixture"
+    return g
+
+
+def recipe_params(names_and_shapes):
+    return {n: torch.from_numpy(R.parameter(n, s)) for n, s in names_and_shapes if R.parameter(n, s) is not None}
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double(), torch.as_tensor(b).detach().double()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def test_oracle_network_equals_reference_file_on_dense_operators(gold):
+    shapes = {k: tuple(v.shape) for k, v in so.init_params(R.ARCH, R.IN_CH, R.OUT_CH).items()}
+    assert sorted(n for n in shapes if "running" not in n) == sorted(gold["names"].tolist()), \
+        "the oracle's parameter names are not the reference model's"
+    p = recipe_params(shapes.items())
+    coords, feats = gold["coords"], torch.from_numpy(gold["feats"])
+    out_eval = so.unet_forward({k: v.clone() for k, v in p.items()}, feats, coords, R.ARCH, train=False)
+    assert rel(out_eval, gold["out_eval"]) <= 1e-11
+    for k, v in p.items():
+        if "running" not in k:
+            v.requires_grad_(True)
+    x = feats.clone().requires_grad_(True)
+    out = so.unet_forward(p, x, coords, R.ARCH, train=True)
+    assert rel(out, gold["out_train"]) <= 1e-11
+    loss = (out * torch.from_numpy(R.output_weights(coords.shape[0]))).sum()
+    assert abs(float(loss.detach()) - float(gold["loss"])) <= 1e-9 * abs(float(gold["loss"]))
+    loss.backward()
+    assert rel(x.grad, gold["gfeats"]) <= 1e-9
+    for name, gp, gn in zip(gold["names"].tolist(), gold["gproj"], gold["gnorm"]):
+        g = p[name].grad
+        assert abs(float(g.norm()) - gn) <= 1e-8 * gn, name
+        proj = float((g * torch.from_numpy(R.probe(name, tuple(g.shape)))).sum())
+        assert abs(proj - gp) <= 1e-8 * gn * np.sqrt(g.numel()), name
+    for name, rp in zip(gold["rnames"].tolist(), gold["rproj"]):
+        b = p[name]
+        proj = float((b * torch.from_numpy(R.probe(name, tuple(b.shape)))).sum())
+        assert abs(proj - rp) <= 1e-10 * float(b.norm()) * np.sqrt(b.numel()), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["executor", "modules"])
+def test_hip_network_equals_reference_file_on_dense_operators(gold, path, monkeypatch):
+    from openscene_amd import executor
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import SparseTensor
+    monkeypatch.setattr(executor, "ENABLED", path == "executor")
+    dev = torch.device("cuda", 0)
+    model = mink_unet(R.IN_CH, R.OUT_CH, 3, R.ARCH)
+    sd = model.state_dict()
+    assert sorted(n for n, _ in model.named_parameters()) == sorted(gold["names"].tolist())
+    for name, t in sd.items():
+        v = R.parameter(name, tuple(t.shape))
+        if v is not None:
+            t.copy_(torch.from_numpy(v).float())
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    coords = torch.from_numpy(gold["coords"]).to(dev)
+    feats = torch.from_numpy(gold["feats"]).float().to(dev)
+    for train, key in ((False, "out_eval"), (True, "out_train")):
+        model.train(train)
+        with torch.no_grad():
+            out = model(SparseTensor(feats, coords))
+        ref = torch.from_numpy(gold[key])
+        e = rel(out.cpu(), ref)
+        assert e <= 2e-4, "%s rel-L2 %.3e" % (key, e)
+        assert float((out.double().cpu() - ref).abs().max()) <= 1e-3 * float(ref.abs().max()), key
+    for name, rp in zip(gold["rnames"].tolist(), gold["rproj"]):                 # running statistics after ONE training forward
+        b = dict(model.named_buffers())[name].double().cpu()
+        proj = float((b * torch.from_numpy(R.probe(name, tuple(b.shape)))).sum())
+        assert abs(proj - rp) <= 1e-5 * float(b.norm()) * np.sqrt(b.numel()), name
