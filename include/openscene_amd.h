@@ -369,27 +369,6 @@ int osn_bn_backward_multi2(const float* x, const float* y, const float* const* g
                            const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
                            int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c, void* ws,
                            size_t ws_bytes, osn_stream_t stream);
-/* ONE launch per direction for the small and mid-size maps (the U-Net levels below ~16 k rows, where the three launches of a
- * training-mode MinkowskiBatchNorm -- models/resnet_base.py:98, models/mink_unet.py:50-102 -- are latency, not traffic): the
- * row blocks of a 64-column group meet inside the launch (agent-scope hand-off of their partial sums, fixed summation order).
- * `sync`: osn_bn_sync_bytes() bytes owned by the caller, zeroed ONCE, 16-byte aligned, shared by the calls of one device
- * (a call takes the next of 16 slots and leaves its counters zero).  sync == null, or a shape the one-launch kernel does
- * not take (osn_bn_xb_config: off by default until enabled, or OSN_BN_XB=1 in the environment; rows in
- * [fwd_min_rows, max_rows]; c <= 512), = osn_bn_forward_train2 / osn_bn_backward_multi2.  Same formulas; mean / var agree
- * with the three-launch path to fp64 round-off of the column sums.  osn_bn_xb_config: a negative argument keeps the
- * setting; returns enable | max_rows << 1.  osn_bn_sync_check: waits for `stream`, OSN_E_HIP if a workgroup ever gave up
- * waiting for its column group (bounded spin: a lost peer costs a wrong result and this error, never a hung device).     */
-size_t osn_bn_sync_bytes(void);
-int osn_bn_xb_config(int enable, int fwd_min_rows, int max_rows);
-int osn_bn_sync_check(const void* sync, osn_stream_t stream);
-int osn_bn_forward_train3(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
-                          const float* residual, int relu, float momentum, float* mean, float* var,
-                          float* running_mean, float* running_var, float* y, float* y2, int64_t ld2,
-                          void* ws, size_t ws_bytes, void* sync, osn_stream_t stream);
-int osn_bn_backward_multi3(const float* x, const float* y, const float* const* gy_host, const int64_t* gy_ld_host, int n_gy,
-                           const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
-                           int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c, void* ws,
-                           size_t ws_bytes, void* sync, osn_stream_t stream);
 
 /* ---- distillation loss on the supervised rows ------------------------------- *
  * Replaces run/distill.py:322-328 and its autograd chain:
@@ -636,8 +615,6 @@ typedef struct osn_net_run {
     const int64_t* grows_idx;
     const float* goutput_rows;
     int64_t n_grows;
-    void* bn_sync;               /* nullable: osn_bn_sync_bytes() of persistent, zeroed state -> the batch norms of the small
-                                  * and mid-size maps run as one launch per direction (osn_bn_forward_train3)              */
 } osn_net_run;
 int osn_net_plan_query(const osn_net_desc* net, const int64_t* level_rows, int training, osn_net_plan* plan);
 /* out[j, :] = in[idx[j], :] (c % 4 == 0) and its inverse out[r, :] = pos[r] >= 0 ? in[pos[r], :] : 0 over all n rows: the row

@@ -6,8 +6,6 @@
 // Function parity with torch.nn.BatchNorm1d as wrapped by MinkowskiBatchNorm,
 // MinkowskiReLU and the BasicBlock residual add.
 #include "common.h"
-#include <atomic>
-#include <stdlib.h>
 
 namespace osn {
 
@@ -396,299 +394,6 @@ __global__ __launch_bounds__(SB_THREADS) void bn_small_fwd_kernel(const float* _
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Mid-size and small maps in ONE launch per direction (round 4; off until osn_bn_xb_config / OSN_BN_XB=1 turns it on).
-// Below ~16 k rows a training-mode batch norm is not bound by memory but by its launches: column sums, finalize and
-// apply are three dependent kernels of 3 - 6 us each around a few megabytes that sit in L2 (profiles/r04_s10: 20 us
-// per call stand-alone whatever the size).  Here the statistics and the apply pass of a direction are ONE kernel:
-//   * grid (row blocks, 64-column groups) of 512 threads -- at most 32 x 8 workgroups, all resident at once (the grid
-//     is a fraction of the chip's 256 CUs x 4 such workgroups; other streams' kernels can only delay a workgroup's
-//     start, they never wait for this kernel);
-//   * a workgroup sums its rows (fp64, fixed order), publishes 128 partial sums and meets the other row blocks of ITS
-//     column group at an arrival counter -- the in-launch hand-off of the CDNA guide: write-through (agent-scope)
-//     8-byte stores, every storing wave drained, one lane's release fence + drained counter increment; one lane polls
-//     relaxed, ONE agent acquire, then agent-scope loads of the partials (never the scalar cache, never L1);
-//   * every workgroup adds the partials of its column group in block order -- the same bits everywhere, whichever
-//     workgroup arrives first: deterministic -- and re-reads its rows (L2) for the apply pass.
-// State (osn_bn_sync_bytes, caller-owned, zero once): 16 slots x {arrival + exit counters of 8 column groups} and
-// 16 x 256 KB of partials; a call takes the next slot, so the launches of two streams never share counters; the last
-// workgroup of a column group to leave puts both counters back to zero.  Spins are bounded: a workgroup that waits
-// ~1 s sets the state's error word (osn_bn_sync_check) and carries on instead of hanging the device.
-// Same formulas and the same apply expressions as the three-kernel path; the column sums are associated per row lane
-// and row block (fp64), so mean / var agree with it to fp64 round-off (bitwise in fp32 except on a rounding tie).
-constexpr int XB_NT = 512, XB_RL = 32, XB_COLS = 64;
-constexpr int XB_MAX_RB = 32, XB_MAX_CG = 8, XB_SLOTS = 16;
-constexpr int XB_CTL_INTS = 32;                            // per slot: arrive[8], exit[8], spare
-constexpr int XB_ERR_WORD = 1000;                          // int index of the error word inside the control page
-constexpr size_t XB_CTL_BYTES = 4096;
-constexpr size_t XB_XBUF_DOUBLES = size_t(XB_MAX_CG) * XB_MAX_RB * 128;      // per slot: 256 KB
-constexpr unsigned XB_SPIN_MAX = 1u << 20;
-typedef unsigned long long xb_u64;
-
-// `v` of thread tid < 128 (which = tid >> 6, column = tid & 63 of this column group) -> its sum over the gridDim.x row
-// blocks, added in block order.  Returned in the same threads.
-__device__ inline double xb_exchange(double v, double* xbuf, int* ctl, int* err) {
-    const int tid = threadIdx.x, RB = int(gridDim.x);
-    if (RB == 1) return v;
-    xb_u64* mine = reinterpret_cast<xb_u64*>(xbuf + (size_t(blockIdx.y) * XB_MAX_RB + blockIdx.x) * 128);
-    if (tid < 128)
-        __hip_atomic_store(mine + tid, xb_u64(__double_as_longlong(v)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler may drop the fence's own wait: restated in asm)
-        __hip_atomic_fetch_add(ctl + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bool ok = false;
-        for (unsigned spin = 0; spin < XB_SPIN_MAX; ++spin) {
-            if (__hip_atomic_load(ctl + blockIdx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= RB) { ok = true; break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        if (!ok) __hip_atomic_fetch_or(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    double t = 0;
-    if (tid < 128) {
-        xb_u64* base = reinterpret_cast<xb_u64*>(xbuf + size_t(blockIdx.y) * XB_MAX_RB * 128) + tid;
-        xb_u64 raw[XB_MAX_RB];
-#pragma unroll
-        for (int b = 0; b < XB_MAX_RB; ++b)                // all loads in flight, then the adds in block order
-            raw[b] = __hip_atomic_load(base + size_t(b < RB ? b : 0) * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int b = 0; b < XB_MAX_RB; ++b) t += b < RB ? __longlong_as_double((long long)raw[b]) : 0.0;
-    }
-    return t;
-}
-
-// the last row block of a column group to leave (every other one has passed the arrival counter before it took its exit
-// ticket) zeroes both counters for the slot's next user
-__device__ inline void xb_leave(int* ctl) {
-    if (gridDim.x > 1 && threadIdx.x == 0) {
-        const int done = __hip_atomic_fetch_add(ctl + XB_MAX_CG + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == int(gridDim.x) - 1) {
-            __hip_atomic_store(ctl + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ctl + XB_MAX_CG + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-// per-thread (4 columns x its row lane) sums -> per-column sums of the workgroup's rows, in threads tid < 128
-__device__ inline double xb_block_sums(double (&red)[2][XB_RL][XB_COLS], const double (&s1)[4], const double (&s2)[4]) {
-    const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        red[0][rl][cl * 4 + j] = s1[j];
-        red[1][rl][cl * 4 + j] = s2[j];
-    }
-    __syncthreads();
-    double v = 0;
-    if (tid < 128) {
-        const int which = tid >> 6, cc = tid & 63;
-#pragma unroll
-        for (int r = 0; r < XB_RL; ++r) v += red[which][r][cc];
-    }
-    return v;
-}
-
-__global__ __launch_bounds__(XB_NT) void bn_xb_fwd_kernel(const float* __restrict__ x, int64_t n, int c, int rows_per_block,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float eps, const float* __restrict__ residual, int relu,
-                                                          float momentum, float* __restrict__ mean_out,
-                                                          float* __restrict__ var_out, float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var, float* __restrict__ y,
-                                                          float* __restrict__ y2, int64_t ld2, double* xbuf, int* ctl,
-                                                          int* err) {
-    __shared__ double red[2][XB_RL][XB_COLS];
-    __shared__ __attribute__((aligned(16))) float stat[2][XB_COLS];
-    const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
-    const int col = blockIdx.y * XB_COLS + cl * 4;
-    const bool on = col < c;
-    const int64_t r0 = int64_t(blockIdx.x) * rows_per_block;
-    const int64_t r1 = min(n, r0 + rows_per_block);
-    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    if (on) {
-#pragma unroll 4
-        for (int64_t r = r0 + rl; r < r1; r += XB_RL) {
-            const float4 xv = ld4(x + r * c + col);
-            s1[0] += xv.x; s1[1] += xv.y; s1[2] += xv.z; s1[3] += xv.w;
-            s2[0] += double(xv.x) * xv.x; s2[1] += double(xv.y) * xv.y;
-            s2[2] += double(xv.z) * xv.z; s2[3] += double(xv.w) * xv.w;
-        }
-    }
-    const double t = xb_exchange(xb_block_sums(red, s1, s2), xbuf, ctl, err);
-    if (tid < 128) red[tid >> 6][0][tid & 63] = t;         // (a thread overwrites only cells it alone has read)
-    __syncthreads();
-    if (tid < XB_COLS) {                                   // bn_stats_finalize_kernel's formulas
-        const int gc = blockIdx.y * XB_COLS + tid;
-        const double m = red[0][0][tid] / double(n);
-        double v = red[1][0][tid] / double(n) - m * m;
-        if (v < 0) v = 0;
-        stat[0][tid] = float(m);
-        stat[1][tid] = float(v);
-        if (blockIdx.x == 0 && gc < c) {
-            mean_out[gc] = float(m);
-            var_out[gc] = float(v);
-            if (running_mean) running_mean[gc] = (1.f - momentum) * running_mean[gc] + momentum * float(m);
-            if (running_var) {
-                const double unb = n > 1 ? v * double(n) / double(n - 1) : v;
-                running_var[gc] = (1.f - momentum) * running_var[gc] + momentum * float(unb);
-            }
-        }
-    }
-    __syncthreads();
-    if (on) {                                              // bn_apply_kernel's expressions; the rows come from L2 this time
-        const float4 mu = *reinterpret_cast<const float4*>(&stat[0][cl * 4]);
-        const float4 vv = *reinterpret_cast<const float4*>(&stat[1][cl * 4]);
-        const float4 ga = ld4(gamma + col), be = ld4(beta + col);
-#pragma unroll 4
-        for (int64_t r = r0 + rl; r < r1; r += XB_RL) {
-            const float4 xv = ld4(x + r * c + col);
-            float4 o;
-            o.x = bn_val(xv.x, mu.x, bn_is(vv.x, eps), ga.x, be.x);
-            o.y = bn_val(xv.y, mu.y, bn_is(vv.y, eps), ga.y, be.y);
-            o.z = bn_val(xv.z, mu.z, bn_is(vv.z, eps), ga.z, be.z);
-            o.w = bn_val(xv.w, mu.w, bn_is(vv.w, eps), ga.w, be.w);
-            if (residual) {
-                const float4 rv = ld4(residual + r * c + col);
-                o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
-            }
-            if (relu) {
-                o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-            }
-            *reinterpret_cast<float4*>(y + r * c + col) = o;
-            if (y2) *reinterpret_cast<float4*>(y2 + r * ld2 + col) = o;
-        }
-    }
-    xb_leave(ctl);
-}
-
-__global__ __launch_bounds__(XB_NT) void bn_xb_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const GySrc gy,
-                                                          const float* __restrict__ mean, const float* __restrict__ var,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float eps, int relu, int training, int64_t n, int c,
-                                                          int rows_per_block, float* __restrict__ gx, float* __restrict__ gres,
-                                                          float* __restrict__ ggamma, float* __restrict__ gbeta, double* xbuf,
-                                                          int* ctl, int* err) {
-    __shared__ double red[2][XB_RL][XB_COLS];
-    __shared__ __attribute__((aligned(16))) float stat[2][XB_COLS];
-    const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
-    const int col = blockIdx.y * XB_COLS + cl * 4;
-    const bool on = col < c;
-    const int64_t r0 = int64_t(blockIdx.x) * rows_per_block;
-    const int64_t r1 = min(n, r0 + rows_per_block);
-    const bool from_x = relu && !y;                        // the ReLU mask recomputed from x (no residual): y is not read
-    float4 mu = make_float4(0, 0, 0, 0), is = make_float4(0, 0, 0, 0);
-    float4 ga = make_float4(0, 0, 0, 0), be = make_float4(0, 0, 0, 0);
-    if (on) {
-        mu = ld4(mean + col);
-        const float4 v = ld4(var + col);
-        is = make_float4(bn_is(v.x, eps), bn_is(v.y, eps), bn_is(v.z, eps), bn_is(v.w, eps));
-        ga = ld4(gamma + col);
-        if (from_x) be = ld4(beta + col);
-    }
-    // g = relu ? gy * (y > 0) : gy of one row quad, exactly as col_reduce_kernel<1> / bn_bwd_apply_kernel form it
-    auto masked = [&](int64_t r, const float4& xv) {
-        float4 g = gy_load(gy, r, col);
-        if (from_x) {
-            g.x = bn_val(xv.x, mu.x, is.x, ga.x, be.x) > 0.f ? g.x : 0.f;
-            g.y = bn_val(xv.y, mu.y, is.y, ga.y, be.y) > 0.f ? g.y : 0.f;
-            g.z = bn_val(xv.z, mu.z, is.z, ga.z, be.z) > 0.f ? g.z : 0.f;
-            g.w = bn_val(xv.w, mu.w, is.w, ga.w, be.w) > 0.f ? g.w : 0.f;
-        } else if (relu) {
-            const float4 yv = ld4(y + r * c + col);
-            g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
-            g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
-        }
-        return g;
-    };
-    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    if (on) {
-#pragma unroll 2
-        for (int64_t r = r0 + rl; r < r1; r += XB_RL) {
-            const float4 xv = ld4(x + r * c + col);
-            const float4 g = masked(r, xv);
-            s1[0] += g.x; s1[1] += g.y; s1[2] += g.z; s1[3] += g.w;
-            s2[0] += double(g.x) * ((xv.x - mu.x) * is.x); s2[1] += double(g.y) * ((xv.y - mu.y) * is.y);
-            s2[2] += double(g.z) * ((xv.z - mu.z) * is.z); s2[3] += double(g.w) * ((xv.w - mu.w) * is.w);
-        }
-    }
-    const double t = xb_exchange(xb_block_sums(red, s1, s2), xbuf, ctl, err);
-    if (tid < 128) stat[tid >> 6][tid & 63] = float(t);    // bn_bwd_finalize_kernel: the sums leave fp64 here
-    __syncthreads();
-    if (blockIdx.x == 0 && tid < XB_COLS && blockIdx.y * XB_COLS + tid < c) {
-        gbeta[blockIdx.y * XB_COLS + tid] = stat[0][tid];
-        ggamma[blockIdx.y * XB_COLS + tid] = stat[1][tid];
-    }
-    if (on) {                                              // bn_bwd_apply_kernel's expressions
-        const float4 sg = *reinterpret_cast<const float4*>(&stat[0][cl * 4]);
-        const float4 sx = *reinterpret_cast<const float4*>(&stat[1][cl * 4]);
-        const float inv_n = 1.f / float(n);
-#pragma unroll 2
-        for (int64_t r = r0 + rl; r < r1; r += XB_RL) {
-            float4 xv = make_float4(0, 0, 0, 0);
-            if (training || from_x) xv = ld4(x + r * c + col);
-            const float4 g = masked(r, xv);
-            if (gres) *reinterpret_cast<float4*>(gres + r * c + col) = g;
-            float4 o;
-            if (training) {
-                o.x = ga.x * is.x * (g.x - sg.x * inv_n - (xv.x - mu.x) * is.x * sx.x * inv_n);
-                o.y = ga.y * is.y * (g.y - sg.y * inv_n - (xv.y - mu.y) * is.y * sx.y * inv_n);
-                o.z = ga.z * is.z * (g.z - sg.z * inv_n - (xv.z - mu.z) * is.z * sx.z * inv_n);
-                o.w = ga.w * is.w * (g.w - sg.w * inv_n - (xv.w - mu.w) * is.w * sx.w * inv_n);
-            } else {
-                o.x = ga.x * is.x * g.x; o.y = ga.y * is.y * g.y; o.z = ga.z * is.z * g.z; o.w = ga.w * is.w * g.w;
-            }
-            *reinterpret_cast<float4*>(gx + r * c + col) = o;
-        }
-    }
-    xb_leave(ctl);
-}
-
-struct XbPlan {
-    int rb, cg, rows_per_block;
-};
-static XbPlan plan_xb(int64_t n, int c) {
-    XbPlan p;
-    int64_t rb = cdiv(n, 384);
-    if (rb > XB_MAX_RB) rb = XB_MAX_RB;
-    if (rb < 1) rb = 1;
-    p.rows_per_block = int(cdiv(cdiv(n, rb), XB_RL) * XB_RL);
-    p.rb = int(cdiv(n, p.rows_per_block));
-    p.cg = int(cdiv(c, XB_COLS));
-    return p;
-}
-
-struct XbCfg {
-    int enable, fwd_min_rows, max_rows;
-};
-static XbCfg& xb_cfg() {
-    static XbCfg cfg = [] {
-        XbCfg v;
-        const char* e = getenv("OSN_BN_XB");
-        v.enable = e && e[0] == '1';
-        e = getenv("OSN_BN_XB_FWD_MIN_ROWS");
-        v.fwd_min_rows = e ? atoi(e) : 0;      // 0: from SB_MAX_ROWS + 1 (the one-workgroup-per-8-columns kernel below that)
-        e = getenv("OSN_BN_XB_MAX_ROWS");
-        v.max_rows = e ? atoi(e) : 16384;
-        return v;
-    }();
-    return cfg;
-}
-static std::atomic<unsigned> xb_next_slot{0};
-struct XbState {
-    int *ctl, *err;
-    double* xbuf;
-};
-static XbState xb_state(void* sync) {
-    const unsigned slot = xb_next_slot.fetch_add(1u) % XB_SLOTS;
-    XbState s;
-    s.ctl = static_cast<int*>(sync) + slot * XB_CTL_INTS;
-    s.err = static_cast<int*>(sync) + XB_ERR_WORD;
-    s.xbuf = reinterpret_cast<double*>(static_cast<char*>(sync) + XB_CTL_BYTES) + size_t(slot) * XB_XBUF_DOUBLES;
-    return s;
-}
-
 static int ew_grid(int64_t total4) {
     int64_t g = cdiv(total4, 256);
     if (g > 2048) g = 2048;
@@ -772,59 +477,6 @@ extern "C" int osn_bn_forward_train2(const float* x, int64_t n, int c, const flo
     return osn_bn_apply2(x, mean, var, gamma, beta, eps, residual, relu, y, y2, ld2, n, c, stream);
 }
 
-extern "C" size_t osn_bn_sync_bytes(void) { return XB_CTL_BYTES + size_t(XB_SLOTS) * XB_XBUF_DOUBLES * 8; }
-
-extern "C" int osn_bn_xb_config(int enable, int fwd_min_rows, int max_rows) {
-    XbCfg& cfg = xb_cfg();
-    if (enable >= 0) cfg.enable = enable != 0;
-    if (fwd_min_rows >= 0) cfg.fwd_min_rows = fwd_min_rows;
-    if (max_rows >= 0) cfg.max_rows = max_rows;
-    return (cfg.enable ? 1 : 0) | (cfg.max_rows << 1);
-}
-
-// 0 = every exchange of the launches queued on `stream` so far met its peers; blocks until they have run
-extern "C" int osn_bn_sync_check(const void* sync, osn_stream_t stream) {
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    OSN_REQUIRE(sync, OSN_E_ARG, "osn_bn_sync_check: null state");
-    int host = 0;
-    OSN_HIP(hipMemcpyAsync(&host, static_cast<const int*>(sync) + XB_ERR_WORD, 4, hipMemcpyDeviceToHost, st));
-    OSN_HIP(hipStreamSynchronize(st));
-    OSN_REQUIRE(host == 0, OSN_E_HIP, "osn_bn: a workgroup of a one-launch batch norm gave up waiting for its column group (state word %d)", host);
-    return OSN_OK;
-}
-
-static bool xb_takes(int64_t n, int c, bool forward) {
-    const XbCfg& cfg = xb_cfg();
-    const int64_t lo = forward ? (cfg.fwd_min_rows > 0 ? cfg.fwd_min_rows : SB_MAX_ROWS + 1) : 1;
-    return cfg.enable && n >= lo && n <= cfg.max_rows && c >= 4 && (c & 3) == 0 && c <= XB_COLS * XB_MAX_CG;
-}
-
-// osn_bn_forward_train2 with the caller's persistent exchange state: maps the one-launch kernel takes (osn_bn_xb_config) run
-// statistics + apply as ONE launch; everything else (and sync == null) is osn_bn_forward_train2.
-extern "C" int osn_bn_forward_train3(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
-                                     const float* residual, int relu, float momentum, float* mean, float* var,
-                                     float* running_mean, float* running_var, float* y, float* y2, int64_t ld2, void* ws,
-                                     size_t ws_bytes, void* sync, osn_stream_t stream) {
-    if (sync && xb_takes(n, c, true)) {
-        hipStream_t st = static_cast<hipStream_t>(stream);
-        OSN_REQUIRE(x && mean && var && gamma && beta && y, OSN_E_ARG, "osn_bn_forward_train3: null pointer");
-        OSN_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && (!residual || aligned16(residual)) &&
-                        aligned16(sync),
-                    OSN_E_ARG, "osn_bn_forward_train3: pointers must be 16-byte aligned");
-        OSN_REQUIRE(!y2 || (aligned16(y2) && ld2 >= c && (ld2 & 3) == 0), OSN_E_ARG,
-                    "osn_bn_forward_train3: the second destination needs a 16-byte aligned pointer and a row stride >= c, %% 4 == 0");
-        const XbPlan p = plan_xb(n, c);
-        const XbState s = xb_state(sync);
-        hipLaunchKernelGGL(bn_xb_fwd_kernel, dim3(unsigned(p.rb), unsigned(p.cg)), dim3(XB_NT), 0, st, x, n, c, p.rows_per_block, gamma,
-                           beta, eps, residual, relu, momentum, mean, var, running_mean, running_var, y, y2, ld2, s.xbuf, s.ctl,
-                           s.err);
-        OSN_LAUNCH_CHECK();
-        return OSN_OK;
-    }
-    return osn_bn_forward_train2(x, n, c, gamma, beta, eps, residual, relu, momentum, mean, var, running_mean, running_var, y, y2,
-                                 ld2, ws, ws_bytes, stream);
-}
-
 extern "C" int osn_bn_forward_train(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
                                     const float* residual, int relu, float momentum, float* mean, float* var,
                                     float* running_mean, float* running_var, float* y, void* ws, size_t ws_bytes,
@@ -833,10 +485,10 @@ extern "C" int osn_bn_forward_train(const float* x, int64_t n, int c, const floa
                                  nullptr, 0, ws, ws_bytes, stream);
 }
 
-static int bn_backward_impl(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,
-                            const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
-                            int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c, void* ws,
-                            size_t ws_bytes, void* sync, osn_stream_t stream) {
+extern "C" int osn_bn_backward_multi2(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,
+                                      const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
+                                     int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c,
+                                     void* ws, size_t ws_bytes, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n >= 1 && c >= 4 && (c & 3) == 0, OSN_E_ARG, "osn_bn_backward: need n >= 1 and c %% 4 == 0");
     OSN_REQUIRE(gy && gy_ld && n_gy >= 1 && n_gy <= BN_MAX_SRC, OSN_E_ARG,
@@ -859,15 +511,6 @@ static int bn_backward_impl(const float* x, const float* y, const float* const* 
         src.p[i] = gy[j];
         src.ld[i] = gy_ld[j];
     }
-    if (sync && xb_takes(n, c, false)) {                   // statistics + apply in ONE launch (osn_bn_xb_config)
-        OSN_REQUIRE(aligned16(sync), OSN_E_ARG, "osn_bn_backward: the exchange state must be 16-byte aligned");
-        const XbPlan xp = plan_xb(n, c);
-        const XbState xs = xb_state(sync);
-        hipLaunchKernelGGL(bn_xb_bwd_kernel, dim3(unsigned(xp.rb), unsigned(xp.cg)), dim3(XB_NT), 0, st, x, y, src, mean, var, gamma,
-                           beta, eps, relu, training, n, c, xp.rows_per_block, gx, gres, ggamma, gbeta, xs.xbuf, xs.ctl, xs.err);
-        OSN_LAUNCH_CHECK();
-        return OSN_OK;
-    }
     ColReducePlan p = plan_colreduce(n, c);
     const size_t need = size_t(p.n_rb) * 2 * size_t(c) * 8;
     OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_bn_backward: workspace %zu < %zu", ws_bytes, need);
@@ -881,23 +524,6 @@ static int bn_backward_impl(const float* x, const float* y, const float* const* 
                        relu, training, gbeta, ggamma, 1.f / float(n), gx, gres, total4, c / 4, beta);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
-}
-
-extern "C" int osn_bn_backward_multi2(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,
-                                      const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
-                                      int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c,
-                                      void* ws, size_t ws_bytes, osn_stream_t stream) {
-    return bn_backward_impl(x, y, gy, gy_ld, n_gy, mean, var, gamma, beta, eps, relu, training, gx, gres, ggamma, gbeta, n, c, ws,
-                            ws_bytes, nullptr, stream);
-}
-
-// osn_bn_backward_multi2 with the caller's persistent exchange state (see osn_bn_forward_train3)
-extern "C" int osn_bn_backward_multi3(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,
-                                      const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
-                                      int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c,
-                                      void* ws, size_t ws_bytes, void* sync, osn_stream_t stream) {
-    return bn_backward_impl(x, y, gy, gy_ld, n_gy, mean, var, gamma, beta, eps, relu, training, gx, gres, ggamma, gbeta, n, c, ws,
-                            ws_bytes, sync, stream);
 }
 
 extern "C" int osn_bn_backward_multi(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,

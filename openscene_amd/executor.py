@@ -73,7 +73,7 @@ class _Run(ctypes.Structure):
                 ("side_stream", ctypes.c_void_p), ("ws_side", ctypes.c_void_p), ("ws_side_bytes", ctypes.c_uint64),
                 ("events", ctypes.c_void_p),
                 ("grows_pos", ctypes.c_void_p), ("grows_idx", ctypes.c_void_p), ("goutput_rows", ctypes.c_void_p),
-                ("n_grows", ctypes.c_int64), ("bn_sync", ctypes.c_void_p)]
+                ("n_grows", ctypes.c_int64)]
 
 
 RUN_NO_JOIN = 1                                 # include/openscene_amd.h: OSN_NET_RUN_NO_JOIN
@@ -348,7 +348,7 @@ class UNetExecutor:
                    out.data_ptr() if out is not None else None, None, st.arena.data_ptr(), st.arena.numel(), None, 0,
                    ws.data_ptr(), ws.numel(), ops.tl_counters(dev).data_ptr(), int(training), 0, end, 0, self.prof,
                    side if events else None, ws2.data_ptr() if (events and ws2 is not None) else None,
-                   ws2.numel() if (events and ws2 is not None) else 0, events, None, None, None, 0, ops.bn_sync(dev).data_ptr())
+                   ws2.numel() if (events and ws2 is not None) else 0, events, None, None, None, 0)
         with ops._Dev(dev):
             check(lib.osn_net_forward(ctypes.addressof(self.desc), ctypes.addressof(run), ops._stream(dev)), "osn_net_forward")
         if training:
@@ -417,7 +417,7 @@ class UNetExecutor:
                    st.arena.data_ptr(), st.arena.numel(), barena.data_ptr(), barena.numel(), ws.data_ptr(), ws.numel(),
                    ops.tl_counters(dev).data_ptr(), int(st.training), 0, len(p.ops), 0, self.prof,
                    side if events else None, ws2.data_ptr() if (events and ws2 is not None) else None,
-                   ws2.numel() if (events and ws2 is not None) else 0, events, rows_pos, rows_idx, rows_g, n_rows, ops.bn_sync(dev).data_ptr())
+                   ws2.numel() if (events and ws2 is not None) else 0, events, rows_pos, rows_idx, rows_g, n_rows)
         hook = self.grad_ready_hook
         with ops._Dev(dev):
             if hook is None:

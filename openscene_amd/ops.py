@@ -934,32 +934,6 @@ def spconv_fwd_plan(n_out, K, cin, cout):
 
 
 # ------------------------------------------------------------------ batch norm
-_bn_sync = {}
-
-
-def bn_sync(dev):
-    """The persistent exchange state of the one-launch batch-norm kernels of a device (include/openscene_amd.h:
-    osn_bn_forward_train3): zeroed once, every launch leaves its counters zero."""
-    i = _idx(dev)
-    b = _bn_sync.get(i)
-    if b is None:
-        b = _bn_sync[i] = torch.zeros(int(_cached("osn_bn_sync_bytes")) // 4, dtype=torch.int32, device=dev)
-    return b
-
-
-def bn_xb_config(enable=-1, fwd_min_rows=-1, max_rows=-1):
-    """Which maps the one-launch batch-norm kernels take (negative = keep) -> (enabled, max_rows)."""
-    v = int(_lib.load().osn_bn_xb_config(int(enable), int(fwd_min_rows), int(max_rows)))
-    return bool(v & 1), v >> 1
-
-
-def bn_sync_check(dev):
-    """Raises if a workgroup of a one-launch batch norm ever gave up waiting for its column group (waits for the stream)."""
-    lib = _prep(dev)
-    with _Dev(dev):
-        check(lib.osn_bn_sync_check(_p(bn_sync(dev)), _stream(dev)), "osn_bn_sync_check")
-
-
 def bn_stats(x, running_mean=None, running_var=None, momentum=0.1):
     dev = x.device
     lib = _prep(dev)
@@ -1005,9 +979,9 @@ def bn_forward_train(x, gamma, beta, eps, residual, relu, running_mean, running_
     y = torch.empty_like(x)
     ws = _ws(_cached("osn_bn_ws_bytes", n, c), dev)
     with _Dev(dev):
-        check(lib.osn_bn_forward_train3(_p(x), n, c, _p(gamma), _p(beta), float(eps), _p(residual), int(bool(relu)),
-                                        float(momentum), _p(mv[0]), _p(mv[1]), _p(running_mean), _p(running_var), _p(y), None, 0,
-                                        _p(ws), ws.numel(), _p(bn_sync(dev)), _stream(dev)), "osn_bn_forward_train3")
+        check(lib.osn_bn_forward_train(_p(x), n, c, _p(gamma), _p(beta), float(eps), _p(residual), int(bool(relu)),
+                                       float(momentum), _p(mv[0]), _p(mv[1]), _p(running_mean), _p(running_var), _p(y),
+                                       _p(ws), ws.numel(), _stream(dev)), "osn_bn_forward_train")
     return y, mv[0], mv[1]
 
 
@@ -1040,9 +1014,9 @@ def bn_forward_train2(x, gamma, beta, eps, residual, relu, running_mean, running
     y = torch.empty_like(x)
     ws = _ws(_cached("osn_bn_ws_bytes", n, c), dev)
     with _Dev(dev):
-        check(lib.osn_bn_forward_train3(_p(x), n, c, _p(gamma), _p(beta), float(eps), _p(residual), int(bool(relu)),
+        check(lib.osn_bn_forward_train2(_p(x), n, c, _p(gamma), _p(beta), float(eps), _p(residual), int(bool(relu)),
                                         float(momentum), _p(mv[0]), _p(mv[1]), _p(running_mean), _p(running_var), _p(y), p2, ld2,
-                                        _p(ws), ws.numel(), _p(bn_sync(dev)), _stream(dev)), "osn_bn_forward_train3")
+                                        _p(ws), ws.numel(), _stream(dev)), "osn_bn_forward_train2")
     return y, mv[0], mv[1]
 
 
@@ -1063,10 +1037,10 @@ def bn_backward_multi(x, y, gys, mean, var, gamma, eps, relu, training, want_gre
     gbeta = torch.empty(c, dtype=torch.float32, device=dev)
     ws = _ws(_cached("osn_bn_ws_bytes", n, c), dev)
     with _Dev(dev):
-        check(lib.osn_bn_backward_multi3(_p(x), _p(y), ptrs, lds, len(views), _p(mean), _p(var), _p(gamma),
+        check(lib.osn_bn_backward_multi2(_p(x), _p(y), ptrs, lds, len(views), _p(mean), _p(var), _p(gamma),
                                          _p(beta) if (relu and y is None) else None, float(eps),
                                          int(bool(relu)), int(bool(training)), _p(gx), _p(gres), _p(ggamma), _p(gbeta), n, c,
-                                         _p(ws), ws.numel(), _p(bn_sync(dev)), _stream(dev)), "osn_bn_backward_multi3")
+                                         _p(ws), ws.numel(), _stream(dev)), "osn_bn_backward_multi2")
     return gx, gres, ggamma, gbeta
 
 

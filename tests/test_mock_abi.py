@@ -95,7 +95,7 @@ def test_training_step_runs_through_the_real_wrappers(mock_ops):
     assert n_fwd == 2 * n_conv - 1, c
     assert c.get("osn_spconv_wgrad", 0) + c.get("osn_spconv_wgrad_tl", 0) + c.get("osn_stem_conv_wgrad", 0) == n_conv, c
     assert c.get("osn_pair_lists_build", 0) <= 10, c            # pair arrays: once per map, not per conv
-    assert c["osn_bn_forward_train3"] == n_bn and c["osn_bn_backward_multi3"] == n_bn, c  # one C call per BN and direction
+    assert c["osn_bn_forward_train"] == n_bn and c["osn_bn_backward_multi2"] == n_bn, c  # one C call per BN and direction
     # weight images of parameters: served from the per-device cache, refreshed by ONE batched launch per optimizer step
     # (this is the second step: every image exists, every parameter version has changed once)
     assert c.get("osn_weight_prep_x6_pair", 0) + c.get("osn_weight_prep_x6", 0) + c.get("osn_weight_prep_tl", 0) == 0, c
@@ -109,7 +109,7 @@ def test_training_step_runs_through_the_real_wrappers(mock_ops):
     model.eval()
     with torch.no_grad():
         model(SparseTensor(feats, coords))
-    assert mock_ops.get("osn_weight_prep_batch", 0) == 0 and "osn_bn_forward_train3" not in mock_ops, dict(mock_ops)
+    assert mock_ops.get("osn_weight_prep_batch", 0) == 0 and "osn_bn_forward_train" not in mock_ops, dict(mock_ops)
     # a write that bumps the version of ONE parameter refreshes (only what is stale, in one launch)
     with torch.no_grad():
         model.net3d.final.kernel.mul_(1.0)

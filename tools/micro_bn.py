@@ -1,6 +1,8 @@
-"""Stand-alone cost of the batch-norm calls on the step's shapes: the three-launch path against the one-launch kernels
-(osn_bn_forward_train3 / osn_bn_backward_multi3, csrc/bn.hip).  HIP events over back-to-back calls, launch gaps included.
-usage: python tools/micro_bn.py [iters]"""
+"""Stand-alone cost of the batch-norm calls on the step's shapes.  HIP events over back-to-back calls.
+usage: python tools/micro_bn.py [iters] [eager|graph]
+eager: the calls as Python issues them -- on the small maps this measures the HOST (three ctypes calls + torch.empty per call:
+~20 us whatever the size); graph: the same calls replayed from a HIP graph -- the device's own pace (kernel time + dependent-launch
+boundaries): 8.5 - 15 us on the <= 13 k-row maps (profiles/r04_s13_bn_one_launch_exchange_rejected.txt)."""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -46,7 +48,7 @@ MODE = sys.argv[2] if len(sys.argv) > 2 else "eager"
 if MODE == "graph":
     timed = timed_graph
 print("# timing mode: %s" % MODE)
-print("# us per call (fwd = statistics + apply; bwd-x = ReLU mask from x; bwd-res = residual block tail): three launches | one launch")
+print("# us per call (fwd = statistics + apply; bwd-x = ReLU mask from x; bwd-res = residual block tail)")
 for n, c in ((730, 256), (730, 512), (3326, 128), (3326, 384), (13393, 64), (13393, 128), (13393, 192), (52125, 32), (52125, 96),
              (52125, 128), (100999, 32), (100999, 96)):
     x = torch.randn(n, c, device=dev)
@@ -55,16 +57,11 @@ for n, c in ((730, 256), (730, 512), (3326, 128), (3326, 384), (13393, 64), (133
     gamma = torch.rand(c, device=dev) + 0.5
     beta = torch.randn(c, device=dev) * 0.1
     rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
-    row = []
-    for on in (0, 1):
-        ops.bn_xb_config(on, 1, 200000)
-        y, mean, var = ops.bn_forward_train(x, gamma, beta, 1e-5, None, True, rm, rv, 0.1)
-        yr, _, _ = ops.bn_forward_train(x, gamma, beta, 1e-5, res, True, rm, rv, 0.1)
-        t_f = timed(lambda: ops.bn_forward_train(x, gamma, beta, 1e-5, None, True, rm, rv, 0.1))
-        t_b = timed(lambda: ops.bn_backward(x, None, gy, mean, var, gamma, 1e-5, True, True, False, beta=beta))
-        t_br = timed(lambda: ops.bn_backward(x, yr, gy, mean, var, gamma, 1e-5, True, True, True))
-        row.append((t_f, t_b, t_br))
-    ops.bn_xb_config(0, 0, 16384)
-    ops.bn_sync_check(dev)
-    print("n %6d c %3d (%5.1f MB): fwd %5.1f | %5.1f   bwd-x %5.1f | %5.1f   bwd-res %5.1f | %5.1f" % (
-        n, c, n * c * 4 / 1e6, row[0][0], row[1][0], row[0][1], row[1][1], row[0][2], row[1][2]), flush=True)
+    y, mean, var = ops.bn_forward_train(x, gamma, beta, 1e-5, None, True, rm, rv, 0.1)
+    yr, _, _ = ops.bn_forward_train(x, gamma, beta, 1e-5, res, True, rm, rv, 0.1)
+    t_f = timed(lambda: ops.bn_forward_train(x, gamma, beta, 1e-5, None, True, rm, rv, 0.1))
+    t_b = timed(lambda: ops.bn_backward(x, None, gy, mean, var, gamma, 1e-5, True, True, False, beta=beta))
+    t_br = timed(lambda: ops.bn_backward(x, yr, gy, mean, var, gamma, 1e-5, True, True, True))
+    mb = n * c * 4 / 1e6
+    print("n %6d c %3d (%5.1f MB): fwd %5.1f us (3 passes: %.2f TB/s)   bwd-x %5.1f us (5 passes: %.2f TB/s)   bwd-res %5.1f us (7 passes: %.2f TB/s)" % (
+        n, c, mb, t_f, 3 * mb / t_f, t_b, 5 * mb / t_b, t_br, 7 * mb / t_br), flush=True)
