@@ -9,6 +9,7 @@
 // so results are those of the per-module path (same kernels, same order; only the gradient SUMS are associated
 // differently: (a + b) inside the consumer instead of a separate add).
 #include "common.h"
+#include <stdlib.h>
 #include "events.h"
 #include <vector>
 
@@ -447,6 +448,7 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
     hipStream_t side = static_cast<hipStream_t>(run->side_stream);
     const bool forked = side && side != st && evs && int(evs->ev.size()) >= 2 * net->n_ops + 2 && run->ws_side &&
                         run->ws_side_bytes >= L.ws_bytes;
+    static const bool shortcut_main = [] { const char* e = getenv("OSN_NET_BWD_SHORTCUT_MAIN"); return !(e && e[0] == '0'); }();
     std::vector<uint8_t> pending(size_t(net->n_ops), 0);       // side stages whose input gradient the main stream has not joined
     osn_net_run side_run = *run;
     side_run.ws = run->ws_side;
@@ -479,7 +481,7 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
                 }
                 // an input gradient computed on the side stream (a shortcut stage): join before it is read.  (A stage that
                 // itself runs on the side stream never reads one: its only source is a residual gradient of the main stream.)
-                if (from_j && forked && L.side[j] && pending[j] != 2) {
+                if (from_j && forked && L.side[j] && !shortcut_main && pending[j] != 2) {
                     OSN_HIP(hipStreamWaitEvent(st, evs->ev[net->n_ops + 1 + j], 0));
                     pending[j] = 2;
                 }
@@ -487,9 +489,12 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
             OSN_REQUIRE(ng >= 1 && ng <= 3, OSN_E_ARG, "osn_net_backward: the output of op %d has %s consumers inside the executed range (1 .. 3 supported)",
                         i, ng == 0 ? "no" : "more than three");
         }
-        // a shortcut stage runs entirely on the side stream (batch-norm backward, weight gradient, input gradient), behind the
-        // weight gradients queued there; fork: its one gradient source (a residual gradient) is in the main stream's past
-        const bool on_side = forked && L.side[i];
+        // Round 4: a shortcut stage's batch-norm backward and input gradient stay on the MAIN stream.  Queued on the side stream they
+        // sat behind its backlog of weight gradients, and the main stream stalled 24 - 112 us at each of the pass's joins waiting for
+        // them (tools/gap_census.py; -0.09 ms per step, profiles/r04_s15_s16_backward_scheduling_ab.txt; OSN_NET_BWD_SHORTCUT_MAIN=0
+        // restores the old queueing).  Only the weight gradients fork.  (In the FORWARD pass the side stream has no backlog and the
+        // shortcut stages do run there: +0.04 ms with them on the main stream.)
+        const bool on_side = forked && L.side[i] && !shortcut_main;
         if (on_side) {
             OSN_HIP(hipEventRecord(evs->ev[i], st));
             OSN_HIP(hipStreamWaitEvent(side, evs->ev[i], 0));
@@ -532,6 +537,15 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
                                  (!o.need_dgrad || L.dgrad_k[i] == OSN_NET_K_DENSE);
         // ---- weight gradient (fork: the side stream sees everything the main stream has queued up to gx)
         OSN_REQUIRE(w.gW, OSN_E_ARG, "osn_net_backward: op %d: null weight-gradient pointer", i);
+        // the stem is the LAST weight gradient of a pass and nothing is left to hide it behind: the reduction of the pair-array
+        // gradients still pending depends on none of the stem's inputs, so it is queued in FRONT of the side stream's wait for the
+        // stem's output gradient -- it runs beside the main stream's last batch-norm backward instead of in the pass's tail
+        static const bool flush_first = [] { const char* e = getenv("OSN_NET_STEM_FLUSH_FIRST"); return !(e && e[0] == '0'); }();
+        if (forked && flush_first && L.wgrad_k[i] == OSN_NET_K_WGRAD_STEM && !jobs.empty()) {
+            rc = osn_wgrad_tl_reduce_batch(jobs.data(), int(jobs.size()), wstream);
+            jobs.clear();
+            if (rc) return rc;
+        }
         if (forked && !on_side) {
             OSN_HIP(hipEventRecord(evs->ev[i], st));
             OSN_HIP(hipStreamWaitEvent(side, evs->ev[i], 0));
@@ -553,7 +567,7 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
                 if (!rc) jobs.push_back(job);
                 // reduce in batches ON the stream the partial sums were computed on (stream order is all the ordering it needs):
                 // only the last, small batch is left for the tail of the pass
-                if (!rc && forked && jobs.size() >= 12) {
+                if (!rc && forked && jobs.size() >= 12) {          // (6 / 24 measured: within noise, profiles/r04_s15_s16_*)
                     rc = osn_wgrad_tl_reduce_batch(jobs.data(), int(jobs.size()), wstream);
                     jobs.clear();
                 }
