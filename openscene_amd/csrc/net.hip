@@ -369,8 +369,18 @@ extern "C" int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, 
         const int64_t n_in = rows[o.lvl_in], n_out = rows[o.lvl_out];
         const osn_net_weight& w = run->weights[o.weight];
         const bool on_side = forked && L.side[i];
+        // A shortcut stage reads the BLOCK INPUT, like the conv1 queued just before it: its fork event is recorded in front of that
+        // conv1 (look-ahead), not behind it -- the stage then runs beside conv1 - BN - conv2 instead of starting after conv1's batch
+        // norm, finishing after conv2 and stalling the main stream at the residual's join (35 - 49 us on the level-0 / level-1 blocks,
+        // tools/gap_census.py).  OSN_NET_FWD_EARLY_FORK=0: the event behind conv1, as before.
+        static const bool early_fork = [] { const char* e = getenv("OSN_NET_FWD_EARLY_FORK"); return !(e && e[0] == '0'); }();
+        if (forked && early_fork && !L.side[i] && i + 1 < run->end_op && L.side[i + 1] && net->ops[i + 1].src == o.src && !pending[i + 1]) {
+            OSN_HIP(hipEventRecord(evs->ev[i + 1], st));
+            pending[i + 1] = 2;                                // (2 = fork event already recorded; becomes 1 when the stage is queued)
+        }
         if (on_side) {                                         // fork: everything queued so far (the producer of src) is visible
-            OSN_HIP(hipEventRecord(evs->ev[i], st));
+            if (pending[i] != 2) OSN_HIP(hipEventRecord(evs->ev[i], st));
+            pending[i] = 0;
             OSN_HIP(hipStreamWaitEvent(side, evs->ev[i], 0));
         }
         osn_net_run side_run = *run;                           // scratch of the stream the stage runs on
@@ -546,12 +556,17 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
             jobs.clear();
             if (rc) return rc;
         }
-        if (forked && !on_side) {
+        // ... and the stem's own weight gradient runs on the MAIN stream: when the pass reaches it the main stream has nothing else
+        // left, while the side stream may still be draining its backlog -- the two now overlap instead of queueing up
+        // (OSN_NET_STEM_WGRAD_MAIN=0: on the side stream, as before)
+        static const bool stem_main = [] { const char* e = getenv("OSN_NET_STEM_WGRAD_MAIN"); return !(e && e[0] == '0'); }();
+        const bool wg_main = forked && stem_main && L.wgrad_k[i] == OSN_NET_K_WGRAD_STEM;
+        if (forked && !on_side && !wg_main) {
             OSN_HIP(hipEventRecord(evs->ev[i], st));
             OSN_HIP(hipStreamWaitEvent(side, evs->ev[i], 0));
         }
         {
-            Bracket br(run->prof, i, 2, forked ? side : st);
+            Bracket br(run->prof, i, 2, (forked && !wg_main) ? side : st);
             if (sparse_rows) {
                 float* in_rows = reinterpret_cast<float*>(B + L.rows_in_off);
                 rc = osn_rows_gather(in, run->grows_idx, run->n_grows, o.cin, in_rows, wstream);
@@ -573,7 +588,8 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
                 }
             } else if (L.wgrad_k[i] == OSN_NET_K_WGRAD_STEM) {
                 OSN_REQUIRE(v.nbr_f, OSN_E_ARG, "osn_net_backward: op %d: the stem weight gradient needs the plain table", i);
-                rc = osn_stem_conv_wgrad(in, gx, v.nbr_f, w.gW, n_out, o.K, o.cin, o.cout, wws, wws_bytes, wstream);
+                rc = wg_main ? osn_stem_conv_wgrad(in, gx, v.nbr_f, w.gW, n_out, o.K, o.cin, o.cout, run->ws, size_t(run->ws_bytes), stream)
+                             : osn_stem_conv_wgrad(in, gx, v.nbr_f, w.gW, n_out, o.K, o.cin, o.cout, wws, wws_bytes, wstream);
             } else {
                 rc = osn_spconv_wgrad(in, gx, o.K > 1 ? v.nbr_f : nullptr, o.K > 1 && m ? m->counts : nullptr, nullptr, w.gW, n_out, o.K,
                                       o.cin, o.cout, wws, wws_bytes, wstream);

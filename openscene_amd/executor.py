@@ -330,7 +330,10 @@ class UNetExecutor:
         rows = [cm.size(s) for s in p.STRIDES]
         if feats.shape[0] != rows[0]:
             raise ValueError("%d feature rows for %d voxels" % (feats.shape[0], rows[0]))
-        self._plan_query(lib, rows, grad)        # grad: a backward pass will follow (its images and pair lists are prepared now)
+        # sizes for what the C side will lay out: osn_net_forward plans with run.training (batch statistics), which also reserves the
+        # backward kernels' scratch -- a training-mode forward under no_grad (grad False, training True) asked for the inference
+        # plan's smaller workspace and failed the run's size check whenever the pooled buffer had not already grown
+        self._plan_query(lib, rows, grad or training)
         st = _PassState()
         st.rows, st.training, st.feats, st.cm = rows, training, feats, cm
         st.maps, keep_m = self._maps(cm, grad)

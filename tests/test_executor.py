@@ -130,3 +130,35 @@ def test_dry_run_executor_issues_the_launches_of_the_module_path(arch, monkeypat
     assert a[:5] == b[:5]
     # what the executor does NOT launch: the elementwise add / cat kernels of the module path
     assert "cat2_kernel" in logs["modules"] and "cat2_kernel" not in logs["executor"]
+
+
+def test_dry_run_training_mode_forward_without_grad_gets_the_workspace_the_library_plans(monkeypatch):
+    """model.train() under torch.no_grad() as the FIRST call of a process (empty workspace pool): the executor used to ask
+    osn_net_plan_query for the inference plan (no backward follows) while osn_net_forward lays out for run.training = 1, whose
+    workspace also covers the backward kernels -- the run's size check failed unless an earlier call had grown the pooled
+    buffer (found on the GPU by tests/test_golden_unet.py running second in the suite).  The real host code of net.hip runs
+    here (null HIP runtime), size checks included."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "dryrun"))
+    import dry_step
+    dry_step.install(dry_step.build_dry_lib(), monkeypatch.setattr)
+    from openscene_amd import executor, ops, synthetic as syn
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import CoordinateManager, SparseTensor
+    monkeypatch.setattr(executor, "ENABLED", True)
+    torch.manual_seed(0)
+    model = mink_unet(3, 16, 3, "MinkUNet18A")
+    vox = syn.shuffled(syn.grid_voxels(syn.room_points(0, n_pts=12000), 0.04), 0)
+    coords = torch.from_numpy(syn.batch_coords([vox]))
+    feats = torch.ones(coords.shape[0], 3)
+    for train in (False, True):                              # the order of the golden test: eval first, then train, both without grad
+        monkeypatch.setattr(ops, "_ws_pool", {})             # a fresh process: nothing pooled yet
+        model.train(train)
+        with torch.no_grad():
+            out = model(SparseTensor(feats, coordinate_manager=CoordinateManager(coords)))
+        assert out.shape == (coords.shape[0], 16)
+    ex = executor.for_model(model)
+    rows = [12, 6, 3, 2, 1]
+    ex._plan_query(ops._prep(None), [r * 1000 for r in rows], False)
+    inference_ws = int(ex._plan.ws_bytes)
+    ex._plan_query(ops._prep(None), [r * 1000 for r in rows], True)
+    assert int(ex._plan.ws_bytes) >= inference_ws
