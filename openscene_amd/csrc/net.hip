@@ -501,7 +501,7 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
         }
         // Round 4: a shortcut stage's batch-norm backward and input gradient stay on the MAIN stream.  Queued on the side stream they
         // sat behind its backlog of weight gradients, and the main stream stalled 24 - 112 us at each of the pass's joins waiting for
-        // them (tools/gap_census.py; -0.09 ms per step, profiles/r04_s15_s16_backward_scheduling_ab.txt; OSN_NET_BWD_SHORTCUT_MAIN=0
+        // them (tools/gap_census.py; -0.09 ms per step, profiles/r04_s15_to_s19_stream_queueing_ab.txt; OSN_NET_BWD_SHORTCUT_MAIN=0
         // restores the old queueing).  Only the weight gradients fork.  (In the FORWARD pass the side stream has no backlog and the
         // shortcut stages do run there: +0.04 ms with them on the main stream.)
         const bool on_side = forked && L.side[i] && !shortcut_main;
@@ -582,7 +582,7 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
                 if (!rc) jobs.push_back(job);
                 // reduce in batches ON the stream the partial sums were computed on (stream order is all the ordering it needs):
                 // only the last, small batch is left for the tail of the pass
-                if (!rc && forked && jobs.size() >= 12) {          // (6 / 24 measured: within noise, profiles/r04_s15_s16_*)
+                if (!rc && forked && jobs.size() >= 12) {          // (6 / 24 measured: within noise, profiles/r04_s15_to_s19_*)
                     rc = osn_wgrad_tl_reduce_batch(jobs.data(), int(jobs.size()), wstream);
                     jobs.clear();
                 }
