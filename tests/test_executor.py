@@ -162,3 +162,42 @@ def test_dry_run_training_mode_forward_without_grad_gets_the_workspace_the_libra
     inference_ws = int(ex._plan.ws_bytes)
     ex._plan_query(ops._prep(None), [r * 1000 for r in rows], True)
     assert int(ex._plan.ws_bytes) >= inference_ws
+
+
+@pytest.mark.parametrize("arch", ["MinkUNet18A", "MinkUNet34C"])
+def test_dry_run_every_call_gets_by_with_exactly_the_workspace_it_asked_for(arch, monkeypatch):
+    """The workspace pool hands out its largest buffer so far, which hides a request that is too small until a process happens
+    to make that call first (see the test above).  Here every request is served with EXACTLY the bytes asked for, and the real
+    entry points (null HIP runtime) check their sizes: per-module path and executor, training step, evaluation and
+    training-mode forward without grad, one and two scenes."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "dryrun"))
+    import dry_step
+    dry_step.install(dry_step.build_dry_lib(), monkeypatch.setattr)
+    from openscene_amd import executor, functional as F_, ops, synthetic as syn
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import CoordinateManager, SparseTensor
+    asked = []
+
+    def exact(nbytes, dev):
+        asked.append(int(nbytes))
+        return torch.empty(max(int(nbytes), 16), dtype=torch.uint8)
+    monkeypatch.setattr(ops, "_ws", exact)
+    monkeypatch.setattr(F_, "TL_FWD_MIN_ROWS", 6000)         # small scenes: still send level 0 through the tile-list kernels
+    torch.manual_seed(0)
+    model = mink_unet(3, 32, 3, arch)
+    for n_scenes in (1, 2):
+        vox = [syn.shuffled(syn.grid_voxels(syn.room_points(b, n_pts=12000), 0.04), b) for b in range(n_scenes)]
+        coords = torch.from_numpy(syn.batch_coords(vox))
+        feats = torch.ones(coords.shape[0], 3)
+        for use_executor in (False, True):
+            monkeypatch.setattr(executor, "ENABLED", use_executor)
+            model.train()
+            out = model(SparseTensor(feats, coordinate_manager=CoordinateManager(coords)))
+            model.zero_grad(set_to_none=True)
+            out.sum().backward()
+            for train in (False, True):
+                model.train(train)
+                with torch.no_grad():
+                    out = model(SparseTensor(feats, coordinate_manager=CoordinateManager(coords)))
+                assert out.shape == (coords.shape[0], 32)
+    assert len(asked) > 100 and max(asked) > 1 << 20
