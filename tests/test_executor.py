@@ -201,3 +201,51 @@ def test_dry_run_every_call_gets_by_with_exactly_the_workspace_it_asked_for(arch
                     out = model(SparseTensor(feats, coordinate_manager=CoordinateManager(coords)))
                 assert out.shape == (coords.shape[0], 32)
     assert len(asked) > 100 and max(asked) > 1 << 20
+
+
+def test_dry_run_stream_queueing_of_a_training_step(monkeypatch):
+    """What the executor queues where (net.hip; measured in profiles/r04_s15_to_s19_stream_queueing_ab.txt), read from the null
+    runtime's log of one training step (kernel, stream, event records / waits):
+      * forward: every shortcut stage (1x1 conv + batch norm) runs on the side stream, and the event it waits for was recorded
+        on the main stream IN FRONT of the block's conv1 -- at least one main-stream convolution is queued between the record
+        and the wait;  the main stream waits once per shortcut stage (the residual's join) and for nothing else;
+      * backward: the main stream waits exactly once (the pass's final join): no join behind the side stream's backlog;
+        every pair-array weight gradient runs on the side stream, the stem's weight gradient on the main stream, and the last
+        batched reduction of the pair-array gradients is queued before the stem's weight gradient."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "dryrun"))
+    import dry_step
+    lib = dry_step.install(dry_step.build_dry_lib(), monkeypatch.setattr)
+    logs, _step, _sizes = dry_step.step_logs(lib, "MinkUNet18A", points=12000, setattr_=monkeypatch.setattr)
+    recs = []                                                # (kind, text, stream)
+    for line in logs["executor"].split("\n"):
+        if line.startswith("S ") and recs and recs[-1][0] == "K":
+            recs[-1] = ("K", recs[-1][1], line[2:])
+        elif line.startswith("K "):
+            recs.append(("K", line[2:], None))
+        elif line.startswith(("EVENT ", "WAIT ")):
+            kind, ev, st = line.split()
+            recs.append((kind, ev, st[1:]))
+    main, side = "0", "51de"
+    first_bwd = next(i for i, r in enumerate(recs) if r[0] == "K" and ("col_reduce_kernel<1>" in r[1] or "wgrad" in r[1]))
+    fwd, bwd = recs[:first_bwd], recs[first_bwd:]
+    # ---- forward
+    shortcut = [i for i, r in enumerate(fwd) if r[0] == "K" and "dense_kernel" in r[1] and r[2] == side]
+    assert len(shortcut) == 7                                # MinkUNet18A: blocks 2 - 8 change their width
+    for i in shortcut:
+        w = max(j for j in range(i) if fwd[j][0] == "WAIT" and fwd[j][2] == side)
+        e = max(j for j in range(w) if fwd[j] == ("EVENT", fwd[w][1], main))
+        between = [r for r in fwd[e:w] if r[0] == "K" and r[2] == main and "spconv" in r[1]]
+        assert between, "the fork event of a shortcut stage is not in front of conv1"
+    assert sum(r[0] == "WAIT" and r[2] == main for r in fwd) == len(shortcut)
+    assert not any(r[0] == "K" and r[2] == side and "spconv" in r[1] for r in fwd)
+    # ---- backward
+    assert sum(r[0] == "WAIT" and r[2] == main for r in bwd) == 1
+    assert bwd[-1][0] == "WAIT" and bwd[-1][2] == main
+    wg = [r for r in bwd if r[0] == "K" and "wgrad_tl_kernel" in r[1]]
+    assert len(wg) >= 40 and all(r[2] == side for r in wg)
+    stem = [i for i, r in enumerate(bwd) if r[0] == "K" and "stem_wgrad_kernel" in r[1]]
+    assert len(stem) == 1 and bwd[stem[0]][2] == main
+    reduces = [i for i, r in enumerate(bwd) if r[0] == "K" and "wgrad_tl_reduce_batch_kernel" in r[1]]
+    assert reduces and all(r < stem[0] for r in reduces) and all(bwd[r][2] == side for r in reduces)
+    # the shortcut stages' backward (batch norm + 1x1 input gradient) is on the main stream
+    assert not any(r[0] == "K" and r[2] == side and ("dense_kernel" in r[1] or "bn_bwd" in r[1] or "col_reduce" in r[1]) for r in bwd)

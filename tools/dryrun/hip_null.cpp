@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <string.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <string>
 #include <vector>
@@ -43,6 +44,8 @@ hipError_t hipLaunchKernel(const void* fn, dim3 grid, dim3 block, void** args, s
     snprintf(buf, sizeof(buf), "K %s grid=%u,%u,%u block=%u", name, grid.x, grid.y, grid.z, block.x);
     ++g_launches;
     add(buf);
+    snprintf(buf, sizeof(buf), "S %llx", (unsigned long long)reinterpret_cast<uintptr_t>(stream));     // the stream of the line above
+    add(buf);
     return hipSuccess;
 }
 hipError_t hipGetLastError(void) { return hipSuccess; }
@@ -54,11 +57,23 @@ hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipSt
     char buf[128]; snprintf(buf, sizeof(buf), "MEMCPY %zu", n); ++g_launches; add(buf); return hipSuccess;
 }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(0x10); return hipSuccess; }
-hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(0x10); return hipSuccess; }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { add("WAIT"); return hipSuccess; }
+// events are numbered (their handle IS the number): the log says which event a stream records / waits for
+static uintptr_t g_next_event = 0x1000;
+hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(g_next_event++); return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(g_next_event++); return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t st, hipEvent_t e, unsigned) {
+    char buf[128];
+    snprintf(buf, sizeof(buf), "WAIT e%llx s%llx", (unsigned long long)reinterpret_cast<uintptr_t>(e), (unsigned long long)reinterpret_cast<uintptr_t>(st));
+    add(buf);
+    return hipSuccess;
+}
 hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t, hipStream_t) { add("EVENT"); return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t st) {
+    char buf[128];
+    snprintf(buf, sizeof(buf), "EVENT e%llx s%llx", (unsigned long long)reinterpret_cast<uintptr_t>(e), (unsigned long long)reinterpret_cast<uintptr_t>(st));
+    add(buf);
+    return hipSuccess;
+}
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
