@@ -76,11 +76,19 @@ _side_streams = {}
 
 
 def side_stream(dev):
-    """One auxiliary HIP stream per device (created on first use)."""
+    """One auxiliary HIP stream per device (created on first use).  OSN_SIDE_PRIORITY=low | high: created with the lowest /
+    highest stream priority instead of the default one (experiment knob: the weight gradients queued here crowd the main
+    stream's memory-bound kernels; round 3 measured "low" as no change, before the executor moved most work around)."""
     i = _idx(dev)
     s = _side_streams.get(i)
     if s is None:
-        s = _side_streams[i] = torch.cuda.Stream(device=i)
+        want = os.environ.get("OSN_SIDE_PRIORITY", "")
+        if want in ("low", "high"):
+            lo, hi = torch.cuda.Stream.priority_range()          # (lowest, highest): larger number = lower priority
+            s = torch.cuda.Stream(device=i, priority=lo if want == "low" else hi)
+        else:
+            s = torch.cuda.Stream(device=i)
+        _side_streams[i] = s
     return s
 
 
