@@ -7,6 +7,9 @@ import numpy as np
 
 ARCH, IN_CH, OUT_CH, SEED = "MinkUNet18A", 3, 16, 20260924
 EXTENT = 48          # 3 x 16: three cells per axis at tensor stride 16
+# second fixture (unet_dense_ref_34c.npz): the nuScenes configuration's MinkUNet34C (config/nuscenes/ours_openseg.yaml, BASELINE configs[4]) on
+# the same cloud and parameter recipe; the stored output rows are every ROW_STEP-th (file size)
+ARCH_B, ROW_STEP_B = "MinkUNet34C", 4
 
 
 def _rng(*key):

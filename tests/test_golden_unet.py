@@ -1,6 +1,6 @@
-"""The network golden vector tests/golden/unet_dense_ref.npz -- the reference's OWN models/mink_unet.py executed on a
-stand-in MinkowskiEngine made of torch's dense conv3d / conv_transpose3d (tests/golden/make_golden_unet.py,
-tests/golden/dense_me.py) -- against
+"""The network golden vectors tests/golden/unet_dense_ref.npz (MinkUNet18A) and unet_dense_ref_34c.npz (MinkUNet34C, the
+nuScenes configuration) -- the reference's OWN models/mink_unet.py executed on a stand-in MinkowskiEngine made of torch's
+dense conv3d / conv_transpose3d (tests/golden/make_golden_unet.py, tests/golden/dense_me.py) -- against
 
   * the CPU oracle (oracle/sparse_ops.unet_forward): float64, forward in both modes, every parameter gradient, the
     input gradient and the running statistics -- this is what pins the "parity unpinned" part of the oracle to something
@@ -21,12 +21,29 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gol
 import unet_recipe as R  # noqa: E402
 
 
-@pytest.fixture(scope="module")
-def gold(golden_dir):
-    g = np.load(os.path.join(golden_dir, "unet_dense_ref.npz"))
-    coords, feats = R.cloud()
-    assert np.array_equal(coords, g["coords"]) and np.array_equal(feats, g["feats"]), "unet_recipe.cloud() drifted from the fixture"
-    return g
+class Gold:
+    """One fixture: the arrays, its architecture and the row step of the stored outputs (the cloud is unet_recipe.cloud())."""
+
+    def __init__(self, golden_dir, fname, arch):
+        self.g = np.load(os.path.join(golden_dir, fname))
+        self.arch = arch
+        self.step = int(self.g["row_step"]) if "row_step" in self.g.files else 1
+        self.coords, self.feats = R.cloud()
+        if "coords" in self.g.files:
+            assert np.array_equal(self.coords, self.g["coords"]) and np.array_equal(self.feats, self.g["feats"]), \
+                "unet_recipe.cloud() drifted from the fixture"
+
+    def __getitem__(self, k):
+        return self.g[k]
+
+    def rows(self, t):
+        """the rows of a full [N, .] result that the fixture stores"""
+        return t[::self.step]
+
+
+@pytest.fixture(scope="module", params=[("unet_dense_ref.npz", R.ARCH), ("unet_dense_ref_34c.npz", R.ARCH_B)], ids=["18A", "34C"])
+def gold(golden_dir, request):
+    return Gold(golden_dir, *request.param)
 
 
 def recipe_params(names_and_shapes):
@@ -39,23 +56,23 @@ def rel(a, b):
 
 
 def test_oracle_network_equals_reference_file_on_dense_operators(gold):
-    shapes = {k: tuple(v.shape) for k, v in so.init_params(R.ARCH, R.IN_CH, R.OUT_CH).items()}
+    shapes = {k: tuple(v.shape) for k, v in so.init_params(gold.arch, R.IN_CH, R.OUT_CH).items()}
     assert sorted(n for n in shapes if "running" not in n) == sorted(gold["names"].tolist()), \
         "the oracle's parameter names are not the reference model's"
     p = recipe_params(shapes.items())
-    coords, feats = gold["coords"], torch.from_numpy(gold["feats"])
-    out_eval = so.unet_forward({k: v.clone() for k, v in p.items()}, feats, coords, R.ARCH, train=False)
-    assert rel(out_eval, gold["out_eval"]) <= 1e-11
+    coords, feats = gold.coords, torch.from_numpy(gold.feats)
+    out_eval = so.unet_forward({k: v.clone() for k, v in p.items()}, feats, coords, gold.arch, train=False)
+    assert rel(gold.rows(out_eval), gold["out_eval"]) <= 1e-11
     for k, v in p.items():
         if "running" not in k:
             v.requires_grad_(True)
     x = feats.clone().requires_grad_(True)
-    out = so.unet_forward(p, x, coords, R.ARCH, train=True)
-    assert rel(out, gold["out_train"]) <= 1e-11
+    out = so.unet_forward(p, x, coords, gold.arch, train=True)
+    assert rel(gold.rows(out), gold["out_train"]) <= 1e-11
     loss = (out * torch.from_numpy(R.output_weights(coords.shape[0]))).sum()
     assert abs(float(loss.detach()) - float(gold["loss"])) <= 1e-9 * abs(float(gold["loss"]))
     loss.backward()
-    assert rel(x.grad, gold["gfeats"]) <= 1e-9
+    assert rel(gold.rows(x.grad), gold["gfeats"]) <= 1e-9
     for name, gp, gn in zip(gold["names"].tolist(), gold["gproj"], gold["gnorm"]):
         g = p[name].grad
         assert abs(float(g.norm()) - gn) <= 1e-8 * gn, name
@@ -75,7 +92,7 @@ def test_hip_network_equals_reference_file_on_dense_operators(gold, path, monkey
     from openscene_amd.sparse import SparseTensor
     monkeypatch.setattr(executor, "ENABLED", path == "executor")
     dev = torch.device("cuda", 0)
-    model = mink_unet(R.IN_CH, R.OUT_CH, 3, R.ARCH)
+    model = mink_unet(R.IN_CH, R.OUT_CH, 3, gold.arch)
     sd = model.state_dict()
     assert sorted(n for n, _ in model.named_parameters()) == sorted(gold["names"].tolist())
     for name, t in sd.items():
@@ -84,16 +101,17 @@ def test_hip_network_equals_reference_file_on_dense_operators(gold, path, monkey
             t.copy_(torch.from_numpy(v).float())
     model.load_state_dict(sd)
     model = model.to(dev)
-    coords = torch.from_numpy(gold["coords"]).to(dev)
-    feats = torch.from_numpy(gold["feats"]).float().to(dev)
+    coords = torch.from_numpy(gold.coords).to(dev)
+    feats = torch.from_numpy(gold.feats).float().to(dev)
     for train, key in ((False, "out_eval"), (True, "out_train")):
         model.train(train)
         with torch.no_grad():
             out = model(SparseTensor(feats, coords))
         ref = torch.from_numpy(gold[key])
-        e = rel(out.cpu(), ref)
+        got = gold.rows(out.cpu())
+        e = rel(got, ref)
         assert e <= 2e-4, "%s rel-L2 %.3e" % (key, e)
-        assert float((out.double().cpu() - ref).abs().max()) <= 1e-3 * float(ref.abs().max()), key
+        assert float((got.double() - ref).abs().max()) <= 1e-3 * float(ref.abs().max()), key
     for name, rp in zip(gold["rnames"].tolist(), gold["rproj"]):                 # running statistics after ONE training forward
         b = dict(model.named_buffers())[name].double().cpu()
         proj = float((b * torch.from_numpy(R.probe(name, tuple(b.shape)))).sum())
