@@ -22,7 +22,8 @@ Pinning status (see DESIGN.md "Oracle"):
     the reference's own ``models/mink_unet.py``, unmodified, executed on a
     stand-in engine made of torch's dense conv3d / conv_transpose3d
     (``tests/golden/dense_me.py`` + ``make_golden_unet.py`` ->
-    ``tests/golden/unet_dense_ref.npz``); ``unet_forward`` reproduces its
+    ``tests/golden/unet_dense_ref.npz`` for MinkUNet18A, ``unet_dense_ref_34c.npz``
+    for MinkUNet34C); ``unet_forward`` reproduces its
     outputs, every gradient and the running statistics to 1e-11 in float64
     (``tests/test_golden_unet.py``).  Layer plan, skip order, BN / residual
     placement and operator arithmetic are therefore pinned; the engine's
