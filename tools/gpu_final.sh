@@ -26,6 +26,9 @@ python $R/tools/tl_launch_sequence.py MinkUNet18A 768 3 3 > $O/tl33_labels.json
 python $R/tools/rocpd_stats.py $O/prof/trace_results.db --by-position spconv_tl_kernelILi3ELi3E 13 $O/tl33_labels.json > $O/tl33_by_position.txt
 python $R/tools/rocpd_stats.py $O/prof/trace_results.db --by-position wgrad_tl_kernelILi3ELi3E 7 > $O/wgrad33_by_position.txt
 python $R/tools/group_stats.py $O/stats.csv > $O/groups.txt
+# where the main stream idles in a step and what the other streams run meanwhile (host timing under the profiler is distorted: read the
+# GPU-side waits -- joins, tails -- not the host-bound gaps)
+python $R/tools/gap_census.py $O/prof/trace_results.db 3 40 > $O/gap_census.txt 2>&1
 rm -rf $O/prof
 cat $O/groups.txt | head -24
 cd $R
