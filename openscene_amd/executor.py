@@ -29,6 +29,11 @@ SIDE_STREAM = os.environ.get("OSN_SIDE_STREAM", "1") != "0"
 # the head's input / weight gradients on the supervised rows only when the loss says which rows of the output gradient are
 # non-zero (losses.distill_loss does): 20 k of 101 k rows in the reference's configuration.  Exactly the same values.
 ROW_SPARSE_HEAD = os.environ.get("OSN_ROW_SPARSE_HEAD", "1") != "0"
+# Experiment knob (off; not yet measured -- round 4 ran out of GPU time): a training step's first launch is the batched refresh of the
+# weight images (~70 us, needs only the optimizer's output); the stem convolution that follows reads the fp32 kernel itself, no
+# image.  With OSN_PREP_OVERLAP=1 the refresh is queued on the side stream and the forward pass is played as ops [0, 1) -> wait
+# for the refresh -> ops [1, n): refresh and stem run side by side.
+PREP_OVERLAP = os.environ.get("OSN_PREP_OVERLAP", "0") == "1"
 _DRY_RUN = False        # tools/dryrun only: accept host tensors (a null HIP runtime logs the launches instead of running them)
 
 _OP = np.dtype([(n, "<i4") for n in ("K", "cin", "cout", "lvl_in", "lvl_out", "map", "transposed", "src", "dst", "bn", "relu",
@@ -337,7 +342,16 @@ class UNetExecutor:
         st = _PassState()
         st.rows, st.training, st.feats, st.cm = rows, training, feats, cm
         st.maps, keep_m = self._maps(cm, grad)
-        st.weights, keep_w = self._weights(cm, self._img)
+        prep_done = None
+        if PREP_OVERLAP and grad and SIDE_STREAM and not _DRY_RUN and K_NAMES[int(self._kf[0])] == "stem":
+            main, side_t = torch.cuda.current_stream(dev), ops.side_stream(dev)
+            side_t.wait_stream(main)                             # the optimizer step is in the main stream's past
+            with ops.on_stream(side_t):
+                st.weights, keep_w = self._weights(cm, self._img)
+            prep_done = torch.cuda.Event()
+            prep_done.record(side_t)
+        else:
+            st.weights, keep_w = self._weights(cm, self._img)
         st.bns = self._bns(training)
         st.arena = torch.empty(int(self._plan.fwd_arena_bytes), dtype=torch.uint8, device=dev)
         st.plan_fwd_bytes = int(self._plan.fwd_arena_bytes)
@@ -353,6 +367,11 @@ class UNetExecutor:
                    side if events else None, ws2.data_ptr() if (events and ws2 is not None) else None,
                    ws2.numel() if (events and ws2 is not None) else 0, events, None, None, None, 0)
         with ops._Dev(dev):
+            if prep_done is not None and end > 1:
+                run.first_op, run.end_op = 0, 1                  # the stem (fp32 kernel, no image) beside the refresh ...
+                check(lib.osn_net_forward(ctypes.addressof(self.desc), ctypes.addressof(run), ops._stream(dev)), "osn_net_forward")
+                torch.cuda.current_stream(dev).wait_event(prep_done)
+                run.first_op, run.end_op = 1, end                # ... everything else behind it
             check(lib.osn_net_forward(ctypes.addressof(self.desc), ctypes.addressof(run), ops._stream(dev)), "osn_net_forward")
         if training:
             torch._foreach_add_([m.bn.num_batches_tracked for m in p.bns], 1)

@@ -59,17 +59,21 @@ class on_stream:
     """Context: the C-ABI calls of this thread launch on `stream` (a torch.cuda.Stream) instead of torch's current
     stream -- without touching torch's stream state, so tensors are still allocated from the current stream's pool.
     The caller orders the two streams (functional.py forks / joins around the weight gradient)."""
-    __slots__ = ("raw", "prev")
+    __slots__ = ("raw", "prev", "torch_stream", "prev_torch")
 
     def __init__(self, stream):
         self.raw = stream.cuda_stream
+        self.torch_stream = stream
 
     def __enter__(self):
         self.prev = getattr(_tls, "stream", None)
+        self.prev_torch = getattr(_tls, "torch_stream", None)
         _tls.stream = self.raw
+        _tls.torch_stream = self.torch_stream
 
     def __exit__(self, *a):
         _tls.stream = self.prev
+        _tls.torch_stream = self.prev_torch
 
 
 _side_streams = {}
@@ -592,7 +596,14 @@ def _refresh_images(imgs, lib, dev):
             e.ptr = p.data_ptr()
             jobs[i] = (e.ptr, e.image.data_ptr(), first, e.K, e.cin, e.cout, e.flip, e.for_dgrad, e.layout)
             first += e.blocks
-        tbl = (keys, torch.from_numpy(jobs.view(np.uint8)).to(dev), first)
+        # (under ops.on_stream the launch below goes to that stream: the table's upload has to be in ITS past, not in torch's
+        # current stream's)
+        ts = getattr(_tls, "torch_stream", None)
+        if ts is not None:
+            with torch.cuda.stream(ts):
+                tbl = (keys, torch.from_numpy(jobs.view(np.uint8)).to(dev), first)
+        else:
+            tbl = (keys, torch.from_numpy(jobs.view(np.uint8)).to(dev), first)
         imgs.table = tbl
         imgs.keep = (imgs.keep + [tbl[1]])[-8:]
     with _Dev(dev):
