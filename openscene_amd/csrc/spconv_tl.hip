@@ -211,8 +211,14 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
         int* const orow_s = kcnt + (TL_KMAX - TL_BMAX);
         const int orow_pre = (park && tid < rows) ? (out_rows ? out_rows[row0 + tid] : row0 + tid) : 0;
 
-        for (int i = tid; i < (bm + 1) * S / 4; i += NT)
-            reinterpret_cast<float4*>(otile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+            // the zeros are materialised HERE (opaque to the optimiser): hoisted out of the persistent loop they stayed live across
+            // every step, were spilled, had their registers borrowed as an MFMA temporary and were reloaded from scratch memory in
+            // each step of the 96 -> 96 instance (ISA: one scratch_load_dwordx4 per step in the in-order vmcnt queue of the gathers)
+            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            asm volatile("" : "+v"(z.x), "+v"(z.y), "+v"(z.z), "+v"(z.w));
+            for (int i = tid; i < (bm + 1) * S / 4; i += NT) reinterpret_cast<float4*>(otile)[i] = z;
+        }
 
         // ---- active offsets of the tile, ascending (=> fixed summation order)
         if (cnt) {
