@@ -118,14 +118,18 @@ __global__ void weight_prep_tl_kernel(const float* __restrict__ W, int K, int ci
 // (B fragments of a chunk: KS k-steps x 2 column blocks x 3 planes = 24 KS VGPRs).  KS is the k-step count that
 // tiles the input channels without a remainder where one exists (96 channels: KS = 3 -- with the fixed 128-channel
 // chunk of round 2 a quarter of the weight-fragment loads and of the gather lanes of every 96-channel conv was padding).
-template <int NW, int KS, bool RAGGED, bool PROF = false, int OCC = 2>
+// BUFG (experiment, OSN_TL_BUFGATHER=1; full-chunk instances only; not yet run on a GPU): the gathered rows come through a buffer
+// resource over the feature matrix, like the weight fragments -- 32-bit offset row * (4 cin) + 4 col from one v_mad_u32_u24, the chunk's
+// first channel in the scalar offset -- instead of a 64-bit multiply-add, two 64-bit adds and a channel clamp per quad (8 -> 2 VALU).
+template <int NW, int KS, bool RAGGED, bool PROF = false, int OCC = 2, bool BUFG = false>
 __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __restrict__ in, const bf16x8* __restrict__ Wp,
                                                                const int32_t* __restrict__ cnt, const int2* __restrict__ lst,
                                                                const int32_t* __restrict__ out_rows, float* __restrict__ out,
                                                                double* __restrict__ bn_partial, int32_t* __restrict__ counter,
                                                                float* __restrict__ partial, int nz, int n_out, int K, int cin,
                                                                int cout, int bm, int n_tiles, int ns, int ncb,
-                                                               int self_reset, long long* __restrict__ prof) {
+                                                               int self_reset, long long* __restrict__ prof, unsigned in_bytes) {
+    static_assert(!(BUFG && RAGGED), "the buffer gather is for full channel chunks");
     constexpr int NT = 256;
     constexpr int CW = 32 * NW;               // output columns of the workgroup
     constexpr int S = CW + 4;                 // fp32 row stride of the output tile
@@ -172,6 +176,9 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
         q_row[j] = (idx / QPR) & 31;
         q_col[j] = (idx % QPR) * 4;
     }
+    // BUFG: resource over the feature matrix (raw buffer, 32-bit byte offsets; in_bytes < 2^31 is the launch's condition)
+    const __amdgpu_buffer_rsrc_t insrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, int(BUFG ? in_bytes : 0u), 0x00020000);
+    const unsigned cin4 = unsigned(cin) * 4u;
 
     bf16x8 B[KS][2][3];
     float4 P0[NQ], P1[NQ];
@@ -333,9 +340,14 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) {
                     const unsigned row = plist[it.base + q_row[j]] & 0xFFFFFFu;
-                    const int ch = 32 * it.s0() + q_col[j];
-                    const unsigned cu = ch < cin ? unsigned(ch) : 0u;
-                    P[j] = *reinterpret_cast<const float4*>(in + (uint64_t(row) * unsigned(cin) + cu));
+                    if constexpr (BUFG) {
+                        const unsigned voff = __umul24(row, cin4) + 4u * unsigned(q_col[j]);      // < in_bytes < 2^31 for every listed row
+                        P[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(insrc, voff, 128u * unsigned(it.s0()), 0));
+                    } else {
+                        const int ch = 32 * it.s0() + q_col[j];
+                        const unsigned cu = ch < cin ? unsigned(ch) : 0u;
+                        P[j] = *reinterpret_cast<const float4*>(in + (uint64_t(row) * unsigned(cin) + cu));
+                    }
                 }
             };
             // fragments of k-step ks of the (offset, chunk) that step `u` belongs to: buffer loads -- resource = the whole weight
@@ -696,14 +708,20 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
     // three workgroups per CU when the tile is low enough (<= 64 rows at <= 96 output columns: 3 x 53.7 KB) -- OSN_TL_OCC3=0 keeps two
     static const bool occ3_on = [] { const char* e = getenv("OSN_TL_OCC3"); return !(e && e[0] == '0'); }();
     const bool occ3 = occ3_on && !prof && !ragged_host && nw <= 3 && ks_host <= 3 && tile_bytes + 28 * 1024 <= 54 * 1024;
+    // experiment knob: gathers through a buffer resource (full-chunk instances, feature matrices below 2 GB)
+    static const bool bufg_on = [] { const char* e = getenv("OSN_TL_BUFGATHER"); return e && e[0] == '1'; }();
+    const uint64_t in_bytes64 = uint64_t(n_in) * uint64_t(cin) * 4u;
+    const bool bufg = bufg_on && !prof && !ragged_host && in_bytes64 < (uint64_t(1) << 31);
+    const unsigned in_bytes = bufg ? unsigned(in_bytes64) : 0u;
     int rc_attr = OSN_OK;
     if (occ3) {                                       // three persistent workgroups per CU
         gx = unsigned(units < TL_SLOTS / 2 * 3 ? units : TL_SLOTS / 2 * 3);
         grid = dim3(gx, unsigned(gy));
     }
-#define OSN_TL4(NW_, KS_, RG_, PF_, OC_)                                                                                   \
+#define OSN_TL4(NW_, KS_, RG_, PF_, OC_) OSN_TL5(NW_, KS_, RG_, PF_, OC_, false)
+#define OSN_TL5(NW_, KS_, RG_, PF_, OC_, BG_)                                                                              \
     do {                                                                                                                   \
-        auto kern = spconv_tl_kernel<NW_, KS_, RG_, PF_, OC_>;                                                             \
+        auto kern = spconv_tl_kernel<NW_, KS_, RG_, PF_, OC_, BG_>;                                                        \
         static size_t attr_bytes = 36 * 1024;                                                                              \
         if (tile_bytes > attr_bytes) {                                                                                     \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(tile_bytes)) != hipSuccess) { \
@@ -713,7 +731,7 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
             attr_bytes = tile_bytes;                                                                                       \
         }                                                                                                                  \
         hipLaunchKernelGGL(kern, grid, dim3(256), tile_bytes, st, in, wp, cnt, lst, out_rows, out, bn_partial, counter, partial, nz, \
-                           int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof);                         \
+                           int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof, in_bytes);               \
     } while (0)
 #define OSN_TL3(NW_, KS_, RG_, PF_) OSN_TL4(NW_, KS_, RG_, PF_, 2)
 #define OSN_TL2(NW_, KS_)                                                                                                  \
@@ -724,9 +742,11 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
         } else if (ragged) {                                                                                               \
             OSN_TL3(NW_, KS_, true, false);                                                                                \
         } else if (occ3 && NW_ <= 3 && KS_ <= 3) {                                                                         \
-            OSN_TL4((NW_ <= 3 ? NW_ : 3), (KS_ <= 3 ? KS_ : 3), false, false, 3);                                          \
+            if (bufg) OSN_TL5((NW_ <= 3 ? NW_ : 3), (KS_ <= 3 ? KS_ : 3), false, false, 3, true);                          \
+            else OSN_TL4((NW_ <= 3 ? NW_ : 3), (KS_ <= 3 ? KS_ : 3), false, false, 3);                                     \
         } else {                                                                                                           \
-            OSN_TL3(NW_, KS_, false, false);                                                                               \
+            if (bufg) OSN_TL5(NW_, KS_, false, false, 2, true);                                                            \
+            else OSN_TL3(NW_, KS_, false, false);                                                                          \
         }                                                                                                                  \
     } while (0)
 #define OSN_TL(NW_)                                                                                                        \
@@ -748,6 +768,7 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
 #undef OSN_TL2
 #undef OSN_TL3
 #undef OSN_TL4
+#undef OSN_TL5
     OSN_REQUIRE(rc_attr == OSN_OK, OSN_E_HIP, "osn_spconv_fwd_tl: cannot reserve %zu bytes of LDS for the output tile", tile_bytes);
     OSN_LAUNCH_CHECK();
     if (nz > 1) {
