@@ -145,12 +145,15 @@ __global__ __launch_bounds__(256) void pair_plan_kernel(const int32_t* __restric
 // ------------------------------------------------------------------------------------- the kernel
 // MB / NB: 16 x 16 accumulator blocks per wave along the input / output channels; a workgroup covers
 // (32 MB) x (32 NB) of gW[k].  identity (pin == nullptr): K == 1, pair p = (row p, row p), items cut by rows.
-template <int MB, int NB>
+// BUFG (experiment, OSN_TL_BUFGATHER=1; not yet run on a GPU): both operands' rows come through buffer resources -- 32-bit offset
+// row * (4 c) + 4 (block's first channel + quad) from one v_mad_u32_u24 -- instead of a 64-bit multiply-add and two 64-bit adds per
+// quad; needs < 2^24 rows and < 2 GB per operand (the launch checks).  A padded pair reads row 0 (the split zeroes its quad as before).
+template <int MB, int NB, bool BUFG = false>
 __global__ __launch_bounds__(256, 2) void wgrad_tl_kernel(const float* __restrict__ rows_a, const float* __restrict__ rows_g,
                                                           const int32_t* __restrict__ idx_a, const int32_t* __restrict__ idx_g,
                                                           const int32_t* __restrict__ poff, const int4* __restrict__ items,
                                                           float* __restrict__ partial, int ca, int cg, int n_cgb,
-                                                          int ident_rows, int ident_quota) {
+                                                          int ident_rows, int ident_quota, unsigned a_bytes, unsigned g_bytes) {
     constexpr int CA_T = 32 * MB, CG_T = 32 * NB;
     constexpr int LDA = CA_T + 8, LDG = CG_T + 8;        // bf16 row pitch (16-byte aligned rows)
     constexpr int QA = CA_T / 4, QG = CG_T / 4;          // quads per staged row
@@ -190,6 +193,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tl_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < NB; ++j) { const int idx = tid + 256 * j; gr[j] = idx / QG; gc[j] = (idx - gr[j] * QG) * 4; }
 
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rows_a), 0, int(BUFG ? a_bytes : 0u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rows_g), 0, int(BUFG ? g_bytes : 0u), 0x00020000);
+    const unsigned ca4 = unsigned(ca) * 4u, cg4 = unsigned(cg) * 4u;
     float4 pa[MB], pg[NB];
     // the (input row, output row) of pair p0 + s * 32 + (tid & 31): threads 0..31 hold the A index, 32..63 the G index
     auto load_idx = [&](int p) -> int {
@@ -204,6 +210,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_tl_kernel(const float* __restric
         for (int j = 0; j < MB; ++j) {
             const int r = idxbuf[0][ar[j]];
             const int ch = a0 + ac[j];
+            if constexpr (BUFG) {       // (channels past the operand: inside the matrix or past its end, where the resource returns zeros)
+                pa[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       arsrc, __umul24(unsigned(max(r, 0)), ca4) + 4u * unsigned(ch), 0, 0));
+                continue;
+            }
             const bool ok = r >= 0 && ch < ca;
             const unsigned ru = ok ? unsigned(r) : 0u, cu = ok ? unsigned(ch) : 0u;
             pa[j] = *reinterpret_cast<const float4*>(rows_a + (uint64_t(ru) * unsigned(ca) + cu));
@@ -212,6 +223,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_tl_kernel(const float* __restric
         for (int j = 0; j < NB; ++j) {
             const int r = idxbuf[1][gr[j]];
             const int ch = g0 + gc[j];
+            if constexpr (BUFG) {
+                pg[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       grsrc, __umul24(unsigned(max(r, 0)), cg4) + 4u * unsigned(ch), 0, 0));
+                continue;
+            }
             const bool ok = r >= 0 && ch < cg;
             const unsigned ru = ok ? unsigned(r) : 0u, cu = ok ? unsigned(ch) : 0u;
             pg[j] = *reinterpret_cast<const float4*>(rows_g + (uint64_t(ru) * unsigned(cg) + cu));
@@ -439,10 +455,17 @@ extern "C" size_t osn_spconv_wgrad_tl_ws_bytes(int K, int cin, int cout) {
 template <int MB>
 static void launch_wg_tl_nb(int nb, dim3 grid, hipStream_t st, const float* ra, const float* rg, const int32_t* ia,
                             const int32_t* ig, const int32_t* poff, const int4* items, float* partial, int ca, int cg,
-                            int n_gb, int irows, int iquota) {
+                            int n_gb, int irows, int iquota, unsigned a_bytes, unsigned g_bytes) {
+    const bool bufg = a_bytes != 0u && g_bytes != 0u;
 #define OSN_WGTL(NB_)                                                                                              \
-    hipLaunchKernelGGL((wgrad_tl_kernel<MB, NB_>), grid, dim3(256), 0, st, ra, rg, ia, ig, poff, items, partial, ca, cg, \
-                       n_gb, irows, iquota)
+    do {                                                                                                           \
+        if (bufg)                                                                                                  \
+            hipLaunchKernelGGL((wgrad_tl_kernel<MB, NB_, true>), grid, dim3(256), 0, st, ra, rg, ia, ig, poff, items, partial, ca, \
+                               cg, n_gb, irows, iquota, a_bytes, g_bytes);                                         \
+        else                                                                                                       \
+            hipLaunchKernelGGL((wgrad_tl_kernel<MB, NB_, false>), grid, dim3(256), 0, st, ra, rg, ia, ig, poff, items, partial, ca, \
+                               cg, n_gb, irows, iquota, 0u, 0u);                                                   \
+    } while (0)
     switch (nb) {
         case 1: OSN_WGTL(1); break;
         case 2: OSN_WGTL(2); break;
@@ -499,11 +522,17 @@ static int wgrad_tl_partial(const float* in, const float* gout, const void* pl, 
     }
     const WgTlPlan p = plan_wg_tl(ca, cg);
     const dim3 grid(unsigned(p.n_ab * p.n_gb), unsigned(n_items));
+    // experiment knob (with the tile-list kernel's): operand rows through buffer resources -- rows as 24-bit factors, 32-bit byte offsets
+    static const bool bufg_on = [] { const char* e = getenv("OSN_TL_BUFGATHER"); return e && e[0] == '1'; }();
+    const uint64_t ab64 = uint64_t(n_in) * uint64_t(cin) * 4u, gb64 = uint64_t(n_out) * uint64_t(cout) * 4u;
+    const bool bufg = bufg_on && n_in < (int64_t(1) << 24) && n_out < (int64_t(1) << 24) && ab64 < (uint64_t(1) << 31) &&
+                      gb64 < (uint64_t(1) << 31);
+    const unsigned a_bytes = bufg ? unsigned(ab64) : 0u, g_bytes = bufg ? unsigned(gb64) : 0u;
     switch (p.mb) {
-        case 1: launch_wg_tl_nb<1>(p.nb, grid, st, ra, rg, ia, ig, poff, items, partial, ca, cg, p.n_gb, irows, iquota); break;
-        case 2: launch_wg_tl_nb<2>(p.nb, grid, st, ra, rg, ia, ig, poff, items, partial, ca, cg, p.n_gb, irows, iquota); break;
-        case 3: launch_wg_tl_nb<3>(p.nb, grid, st, ra, rg, ia, ig, poff, items, partial, ca, cg, p.n_gb, irows, iquota); break;
-        default: launch_wg_tl_nb<4>(p.nb, grid, st, ra, rg, ia, ig, poff, items, partial, ca, cg, p.n_gb, irows, iquota); break;
+        case 1: launch_wg_tl_nb<1>(p.nb, grid, st, ra, rg, ia, ig, poff, items, partial, ca, cg, p.n_gb, irows, iquota, a_bytes, g_bytes); break;
+        case 2: launch_wg_tl_nb<2>(p.nb, grid, st, ra, rg, ia, ig, poff, items, partial, ca, cg, p.n_gb, irows, iquota, a_bytes, g_bytes); break;
+        case 3: launch_wg_tl_nb<3>(p.nb, grid, st, ra, rg, ia, ig, poff, items, partial, ca, cg, p.n_gb, irows, iquota, a_bytes, g_bytes); break;
+        default: launch_wg_tl_nb<4>(p.nb, grid, st, ra, rg, ia, ig, poff, items, partial, ca, cg, p.n_gb, irows, iquota, a_bytes, g_bytes); break;
     }
     OSN_LAUNCH_CHECK();
     job->partial = partial;
