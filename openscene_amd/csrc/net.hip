@@ -372,9 +372,8 @@ extern "C" int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, 
         // A shortcut stage reads the BLOCK INPUT, like the conv1 queued just before it: its fork event is recorded in front of that
         // conv1 (look-ahead), not behind it -- the stage then runs beside conv1 - BN - conv2 instead of starting after conv1's batch
         // norm, finishing after conv2 and stalling the main stream at the residual's join (35 - 49 us on the level-0 / level-1 blocks,
-        // tools/gap_census.py).  OSN_NET_FWD_EARLY_FORK=0: the event behind conv1, as before.
-        static const bool early_fork = [] { const char* e = getenv("OSN_NET_FWD_EARLY_FORK"); return !(e && e[0] == '0'); }();
-        if (forked && early_fork && !L.side[i] && i + 1 < run->end_op && L.side[i + 1] && net->ops[i + 1].src == o.src && !pending[i + 1]) {
+        // tools/gap_census.py; the event behind conv1 was round 4's A/B loser, profiles/r04_s15_to_s19_stream_queueing_ab.txt).
+        if (forked && !L.side[i] && i + 1 < run->end_op && L.side[i + 1] && net->ops[i + 1].src == o.src && !pending[i + 1]) {
             OSN_HIP(hipEventRecord(evs->ev[i + 1], st));
             pending[i + 1] = 2;                                // (2 = fork event already recorded; becomes 1 when the stage is queued)
         }
@@ -458,11 +457,6 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
     hipStream_t side = static_cast<hipStream_t>(run->side_stream);
     const bool forked = side && side != st && evs && int(evs->ev.size()) >= 2 * net->n_ops + 2 && run->ws_side &&
                         run->ws_side_bytes >= L.ws_bytes;
-    static const bool shortcut_main = [] { const char* e = getenv("OSN_NET_BWD_SHORTCUT_MAIN"); return !(e && e[0] == '0'); }();
-    std::vector<uint8_t> pending(size_t(net->n_ops), 0);       // side stages whose input gradient the main stream has not joined
-    osn_net_run side_run = *run;
-    side_run.ws = run->ws_side;
-    side_run.ws_bytes = run->ws_side_bytes;
     osn_stream_t wstream = forked ? run->side_stream : stream;
     void* wws = forked ? run->ws_side : run->ws;
     const size_t wws_bytes = size_t(forked ? run->ws_side_bytes : run->ws_bytes);
@@ -483,17 +477,10 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
             // earlier segment left their input gradients in the arena)
             for (int j = i + 1; j < net->n_ops && ng < 4; ++j) {
                 const osn_net_op& c = net->ops[j];
-                bool from_j = false;
-                if (c.src == o.dst && c.need_dgrad) { gsrc[ng] = reinterpret_cast<const float*>(B + L.gin_off[j]); gld[ng] = c.cin; ++ng; from_j = true; }
+                if (c.src == o.dst && c.need_dgrad) { gsrc[ng] = reinterpret_cast<const float*>(B + L.gin_off[j]); gld[ng] = c.cin; ++ng; }
                 if (ng < 4 && c.res == o.dst) { gsrc[ng] = reinterpret_cast<const float*>(B + L.gres_off[j]); gld[ng] = c.cout; ++ng; }
                 if (ng < 4 && o.copy_buf >= 0 && c.src == o.copy_buf && c.need_dgrad) {
-                    gsrc[ng] = reinterpret_cast<const float*>(B + L.gin_off[j]) + o.copy_col; gld[ng] = c.cin; ++ng; from_j = true;
-                }
-                // an input gradient computed on the side stream (a shortcut stage): join before it is read.  (A stage that
-                // itself runs on the side stream never reads one: its only source is a residual gradient of the main stream.)
-                if (from_j && forked && L.side[j] && !shortcut_main && pending[j] != 2) {
-                    OSN_HIP(hipStreamWaitEvent(st, evs->ev[net->n_ops + 1 + j], 0));
-                    pending[j] = 2;
+                    gsrc[ng] = reinterpret_cast<const float*>(B + L.gin_off[j]) + o.copy_col; gld[ng] = c.cin; ++ng;
                 }
             }
             OSN_REQUIRE(ng >= 1 && ng <= 3, OSN_E_ARG, "osn_net_backward: the output of op %d has %s consumers inside the executed range (1 .. 3 supported)",
@@ -501,16 +488,11 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
         }
         // Round 4: a shortcut stage's batch-norm backward and input gradient stay on the MAIN stream.  Queued on the side stream they
         // sat behind its backlog of weight gradients, and the main stream stalled 24 - 112 us at each of the pass's joins waiting for
-        // them (tools/gap_census.py; -0.09 ms per step, profiles/r04_s15_to_s19_stream_queueing_ab.txt; OSN_NET_BWD_SHORTCUT_MAIN=0
-        // restores the old queueing).  Only the weight gradients fork.  (In the FORWARD pass the side stream has no backlog and the
-        // shortcut stages do run there: +0.04 ms with them on the main stream.)
-        const bool on_side = forked && L.side[i] && !shortcut_main;
-        if (on_side) {
-            OSN_HIP(hipEventRecord(evs->ev[i], st));
-            OSN_HIP(hipStreamWaitEvent(side, evs->ev[i], 0));
-        }
-        const osn_net_run* r = on_side ? &side_run : run;
-        const osn_stream_t sstream = on_side ? run->side_stream : stream;
+        // them (tools/gap_census.py; -0.09 ms per step, profiles/r04_s15_to_s19_stream_queueing_ab.txt).  Only the weight gradients
+        // fork.  (In the FORWARD pass the side stream has no backlog and the shortcut stages do run there: +0.04 ms with them on the
+        // main stream.)
+        const osn_net_run* r = run;
+        const osn_stream_t sstream = stream;
         const float* gx;
         if (o.bn >= 0) {
             const osn_net_bn& bn = run->bns[o.bn];
@@ -550,18 +532,16 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
         // the stem is the LAST weight gradient of a pass and nothing is left to hide it behind: the reduction of the pair-array
         // gradients still pending depends on none of the stem's inputs, so it is queued in FRONT of the side stream's wait for the
         // stem's output gradient -- it runs beside the main stream's last batch-norm backward instead of in the pass's tail
-        static const bool flush_first = [] { const char* e = getenv("OSN_NET_STEM_FLUSH_FIRST"); return !(e && e[0] == '0'); }();
-        if (forked && flush_first && L.wgrad_k[i] == OSN_NET_K_WGRAD_STEM && !jobs.empty()) {
+        if (forked && L.wgrad_k[i] == OSN_NET_K_WGRAD_STEM && !jobs.empty()) {
             rc = osn_wgrad_tl_reduce_batch(jobs.data(), int(jobs.size()), wstream);
             jobs.clear();
             if (rc) return rc;
         }
         // ... and the stem's own weight gradient runs on the MAIN stream: when the pass reaches it the main stream has nothing else
         // left, while the side stream may still be draining its backlog -- the two now overlap instead of queueing up
-        // (OSN_NET_STEM_WGRAD_MAIN=0: on the side stream, as before)
-        static const bool stem_main = [] { const char* e = getenv("OSN_NET_STEM_WGRAD_MAIN"); return !(e && e[0] == '0'); }();
-        const bool wg_main = forked && stem_main && L.wgrad_k[i] == OSN_NET_K_WGRAD_STEM;
-        if (forked && !on_side && !wg_main) {
+        // (on the side stream it queued up behind the backlog: round 4's A/B, profiles/r04_s15_to_s19_stream_queueing_ab.txt)
+        const bool wg_main = forked && L.wgrad_k[i] == OSN_NET_K_WGRAD_STEM;
+        if (forked && !wg_main) {
             OSN_HIP(hipEventRecord(evs->ev[i], st));
             OSN_HIP(hipStreamWaitEvent(side, evs->ev[i], 0));
         }
@@ -600,7 +580,7 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
         if (o.need_dgrad) {
             float* gin = reinterpret_cast<float*>(B + L.gin_off[i]);
             {
-                Bracket br(run->prof, i, 1, on_side ? side : st);
+                Bracket br(run->prof, i, 1, st);
                 // a self map (flip) is its own mirror: same direction of the pair arrays with the mirrored weight image;
                 // otherwise the input gradient walks them the other way round
                 const int swap_f = o.transposed ? 1 : 0;
@@ -614,10 +594,6 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
                               (m && m->flip) ? swap_f : 1 - swap_f, r, sstream, i);
             }
             if (rc) return rc;
-            if (on_side) {
-                OSN_HIP(hipEventRecord(evs->ev[net->n_ops + 1 + i], side));
-                pending[i] = 1;
-            }
         }
     }
     // the pair-array weight gradients still waiting for their reduction: one launch (instead of one per convolution)

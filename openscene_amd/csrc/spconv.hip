@@ -1108,7 +1108,7 @@ static FwdPlan plan_fwd(int64_t n_out, int K, int cin, int cout) {
     p.kps = int(cdiv(K, S));
     p.S = int(cdiv(K, p.kps));
     // units mode pays when the plain launch would not be split and every tile walks many offsets
-    static const int tune_U = getenv("OSN_UNIT_K") ? atoi(getenv("OSN_UNIT_K")) : UNIT_K;    // experiment knob
+    constexpr int tune_U = UNIT_K;
     p.unit_k = tune_U;
     // ONE eligibility rule for both pipelined kernels and for osn_spconv_fwd_ws_bytes (the fp32 pipe kernel
     // additionally needs cout % 4 == 0 to run at all; when it does not, the simple kernel ignores gmask)
@@ -1133,7 +1133,7 @@ static WgradPlan plan_wgrad(int64_t n_out, int K, int cin, int cout) {
     p.tpw = (tiles + 3) / 4;
     p.min_rows = 512;
     // ~1024 workgroups per launch (4 per CU), but never more items than the rows can feed
-    static const int tune_T = getenv("OSN_WGRAD_T") ? atoi(getenv("OSN_WGRAD_T")) : 512;   // experiment knob
+    constexpr int tune_T = 512;
     int64_t T = cdiv(tune_T, int64_t(p.n_ci) * p.n_co);
     const int64_t tmax = int64_t(K) * cdiv(n_out, p.min_rows);
     if (T > tmax) T = tmax;

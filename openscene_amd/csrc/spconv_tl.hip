@@ -118,9 +118,11 @@ __global__ void weight_prep_tl_kernel(const float* __restrict__ W, int K, int ci
 // (B fragments of a chunk: KS k-steps x 2 column blocks x 3 planes = 24 KS VGPRs).  KS is the k-step count that
 // tiles the input channels without a remainder where one exists (96 channels: KS = 3 -- with the fixed 128-channel
 // chunk of round 2 a quarter of the weight-fragment loads and of the gather lanes of every 96-channel conv was padding).
-// BUFG (experiment, OSN_TL_BUFGATHER=1; full-chunk instances only; not yet run on a GPU): the gathered rows come through a buffer
-// resource over the feature matrix, like the weight fragments -- 32-bit offset row * (4 cin) + 4 col from one v_mad_u32_u24, the chunk's
-// first channel in the scalar offset -- instead of a 64-bit multiply-add, two 64-bit adds and a channel clamp per quad (8 -> 2 VALU).
+// BUFG (full-chunk instances, feature matrices below 2 GB -- every launch of the benchmark configurations): the gathered rows come through
+// a buffer resource over the feature matrix, like the weight fragments -- 32-bit offset row * (4 cin) + 4 col from one v_mad_u32_u24, the
+// chunk's first channel in the scalar offset -- instead of a 64-bit multiply-add, two 64-bit adds and a channel clamp per quad (8 -> 2 VALU;
+// round 5's A/B: step 8.80 -> 8.73 / 8.76 ms, bit-identical results, profiles/r05_s1_knobs_ab.txt).  Ragged chunks and matrices of 2 GB
+// and more keep the 64-bit addresses.
 template <int NW, int KS, bool RAGGED, bool PROF = false, int OCC = 2, bool BUFG = false>
 __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __restrict__ in, const bf16x8* __restrict__ Wp,
                                                                const int32_t* __restrict__ cnt, const int2* __restrict__ lst,
@@ -705,13 +707,11 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
     const int ks_host = ks;
     // dynamic LDS = the output tile; beyond 64 KB per workgroup in total the kernel needs the opt-in attribute (once per instance)
     const size_t tile_bytes = size_t(bm + 1) * size_t(32 * nw + 4) * 4;
-    // three workgroups per CU when the tile is low enough (<= 64 rows at <= 96 output columns: 3 x 53.7 KB) -- OSN_TL_OCC3=0 keeps two
-    static const bool occ3_on = [] { const char* e = getenv("OSN_TL_OCC3"); return !(e && e[0] == '0'); }();
-    const bool occ3 = occ3_on && !prof && !ragged_host && nw <= 3 && ks_host <= 3 && tile_bytes + 28 * 1024 <= 54 * 1024;
-    // experiment knob: gathers through a buffer resource (full-chunk instances, feature matrices below 2 GB)
-    static const bool bufg_on = [] { const char* e = getenv("OSN_TL_BUFGATHER"); return e && e[0] == '1'; }();
+    // three workgroups per CU when the tile is low enough (<= 64 rows at <= 96 output columns: 3 x 53.7 KB)
+    const bool occ3 = !prof && !ragged_host && nw <= 3 && ks_host <= 3 && tile_bytes + 28 * 1024 <= 54 * 1024;
+    // gathers through a buffer resource (full-chunk instances, feature matrices below 2 GB)
     const uint64_t in_bytes64 = uint64_t(n_in) * uint64_t(cin) * 4u;
-    const bool bufg = bufg_on && !prof && !ragged_host && in_bytes64 < (uint64_t(1) << 31);
+    const bool bufg = !prof && !ragged_host && in_bytes64 < (uint64_t(1) << 31);
     const unsigned in_bytes = bufg ? unsigned(in_bytes64) : 0u;
     int rc_attr = OSN_OK;
     if (occ3) {                                       // three persistent workgroups per CU

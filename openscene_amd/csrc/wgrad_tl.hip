@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void pair_plan_kernel(const int32_t* __restric
 // ------------------------------------------------------------------------------------- the kernel
 // MB / NB: 16 x 16 accumulator blocks per wave along the input / output channels; a workgroup covers
 // (32 MB) x (32 NB) of gW[k].  identity (pin == nullptr): K == 1, pair p = (row p, row p), items cut by rows.
-// BUFG (experiment, OSN_TL_BUFGATHER=1; not yet run on a GPU): both operands' rows come through buffer resources -- 32-bit offset
+// BUFG (operands below 2^24 rows and 2 GB -- every launch of the benchmark configurations; round 5's A/B with the tile-list kernel's,
+// profiles/r05_s1_knobs_ab.txt): both operands' rows come through buffer resources -- 32-bit offset
 // row * (4 c) + 4 (block's first channel + quad) from one v_mad_u32_u24 -- instead of a 64-bit multiply-add and two 64-bit adds per
 // quad; needs < 2^24 rows and < 2 GB per operand (the launch checks).  A padded pair reads row 0 (the split zeroes its quad as before).
 template <int MB, int NB, bool BUFG = false>
@@ -415,10 +416,9 @@ extern "C" int osn_pair_lists_build(const void* tl, const int32_t* out_rows, int
     const int32_t* cnt = static_cast<const int32_t*>(tl);
     const int2* lst = reinterpret_cast<const int2*>(static_cast<const char*>(tl) + align_up(size_t(nt) * K * 4, 256));
     hipLaunchKernelGGL(pair_prefix_kernel, dim3(K), dim3(256), 0, st, cnt, int(nt), K, v.pref, v.total);
-    // items per map: PL_ITEMS (one round of two workgroups per CU); OSN_PL_ITEMS lowers it (fewer, longer items: less
-    // partial-sum traffic for the reduction, less parallelism for the kernel; measured per step: 256 +0.13 ms, 384 equal)
-    static const int items_env = [] { const char* e = getenv("OSN_PL_ITEMS"); return e ? atoi(e) : 0; }();
-    const int items_max = (items_env > K + 32 && items_env <= PL_ITEMS) ? items_env : PL_ITEMS;
+    // items per map: PL_ITEMS (one round of two workgroups per CU).  Fewer, longer items (less partial-sum traffic for the reduction,
+    // less parallelism for the kernel) were measured per step: 256 items +0.02 .. +0.13 ms, 384 equal (profiles/r05_s1_knobs_ab.txt)
+    const int items_max = PL_ITEMS;
     hipLaunchKernelGGL(pair_plan_kernel, dim3(1), dim3(256), 0, st, v.total, K, v.items, v.range, items_max);
     hipLaunchKernelGGL(pair_fill_kernel, dim3(unsigned(nt)), dim3(256), 0, st, cnt, lst, out_rows, v.pref, v.total, int(nt), K,
                        bm, v.pin, v.pout, v.poff);
@@ -522,10 +522,9 @@ static int wgrad_tl_partial(const float* in, const float* gout, const void* pl, 
     }
     const WgTlPlan p = plan_wg_tl(ca, cg);
     const dim3 grid(unsigned(p.n_ab * p.n_gb), unsigned(n_items));
-    // experiment knob (with the tile-list kernel's): operand rows through buffer resources -- rows as 24-bit factors, 32-bit byte offsets
-    static const bool bufg_on = [] { const char* e = getenv("OSN_TL_BUFGATHER"); return e && e[0] == '1'; }();
+    // operand rows through buffer resources -- rows as 24-bit factors, 32-bit byte offsets -- whenever both operands allow it
     const uint64_t ab64 = uint64_t(n_in) * uint64_t(cin) * 4u, gb64 = uint64_t(n_out) * uint64_t(cout) * 4u;
-    const bool bufg = bufg_on && n_in < (int64_t(1) << 24) && n_out < (int64_t(1) << 24) && ab64 < (uint64_t(1) << 31) &&
+    const bool bufg = n_in < (int64_t(1) << 24) && n_out < (int64_t(1) << 24) && ab64 < (uint64_t(1) << 31) &&
                       gb64 < (uint64_t(1) << 31);
     const unsigned a_bytes = bufg ? unsigned(ab64) : 0u, g_bytes = bufg ? unsigned(gb64) : 0u;
     switch (p.mb) {

@@ -29,11 +29,10 @@ SIDE_STREAM = os.environ.get("OSN_SIDE_STREAM", "1") != "0"
 # the head's input / weight gradients on the supervised rows only when the loss says which rows of the output gradient are
 # non-zero (losses.distill_loss does): 20 k of 101 k rows in the reference's configuration.  Exactly the same values.
 ROW_SPARSE_HEAD = os.environ.get("OSN_ROW_SPARSE_HEAD", "1") != "0"
-# Experiment knob (off; not yet measured -- round 4 ran out of GPU time): a training step's first launch is the batched refresh of the
-# weight images (~70 us, needs only the optimizer's output); the stem convolution that follows reads the fp32 kernel itself, no
-# image.  With OSN_PREP_OVERLAP=1 the refresh is queued on the side stream and the forward pass is played as ops [0, 1) -> wait
-# for the refresh -> ops [1, n): refresh and stem run side by side.
-PREP_OVERLAP = os.environ.get("OSN_PREP_OVERLAP", "0") == "1"
+# A training step's first launch is the batched refresh of the weight images (~70 us, needs only the optimizer's output); the stem
+# convolution that follows reads the fp32 kernel itself, no image.  The refresh is queued on the side stream and the forward pass is
+# played as ops [0, 1) -> wait for the refresh -> ops [1, n): refresh and stem run side by side (round 5's A/B: -0.03 ms alone,
+# -0.08 ms with the buffer-resource gathers, same loss bits; profiles/r05_s1_knobs_ab.txt).
 _DRY_RUN = False        # tools/dryrun only: accept host tensors (a null HIP runtime logs the launches instead of running them)
 
 _OP = np.dtype([(n, "<i4") for n in ("K", "cin", "cout", "lvl_in", "lvl_out", "map", "transposed", "src", "dst", "bn", "relu",
@@ -343,7 +342,7 @@ class UNetExecutor:
         st.rows, st.training, st.feats, st.cm = rows, training, feats, cm
         st.maps, keep_m = self._maps(cm, grad)
         prep_done = None
-        if PREP_OVERLAP and grad and SIDE_STREAM and not _DRY_RUN and K_NAMES[int(self._kf[0])] == "stem":
+        if grad and SIDE_STREAM and not _DRY_RUN and K_NAMES[int(self._kf[0])] == "stem":
             main, side_t = torch.cuda.current_stream(dev), ops.side_stream(dev)
             side_t.wait_stream(main)                             # the optimizer step is in the main stream's past
             with ops.on_stream(side_t):

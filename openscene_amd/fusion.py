@@ -12,24 +12,25 @@ from . import ops
 
 
 def make_intrinsic(fx, fy, mx, my):
-    """fusion_util.py:17-25."""
-    intrinsic = np.eye(4)
-    intrinsic[0][0] = fx
-    intrinsic[1][1] = fy
-    intrinsic[0][2] = mx
-    intrinsic[1][2] = my
-    return intrinsic
+    """4 x 4 pinhole matrix (focal lengths on the diagonal, principal point in column 2): what fusion_util.py:17-25 returns."""
+    K = np.diag([float(fx), float(fy), 1.0, 1.0])
+    K[:2, 2] = (mx, my)
+    return K
 
 
 def adjust_intrinsic(intrinsic, intrinsic_image_dim, image_dim):
-    """fusion_util.py:27-39 (modifies and returns `intrinsic`, like the reference)."""
-    if intrinsic_image_dim == image_dim:
+    """Rescale a pinhole matrix from the calibration resolution to the working resolution, IN PLACE (the caller's matrix is
+    returned, untouched when the two resolutions agree) -- the contract of fusion_util.py:27-39.  Focal lengths scale with the
+    aspect-preserving resize (the width the calibration image would have at the new height), the principal point with the pixel
+    CENTRES (dim - 1): the reference's crop convention, pinned by tests/golden/fusion_mapping.npz."""
+    (w0, h0), (w1, h1) = intrinsic_image_dim, image_dim
+    if (w0, h0) == (w1, h1):                       # (every factor below would be exactly 1.0)
         return intrinsic
-    resize_width = int(math.floor(image_dim[1] * float(intrinsic_image_dim[0]) / float(intrinsic_image_dim[1])))
-    intrinsic[0, 0] *= float(resize_width) / float(intrinsic_image_dim[0])
-    intrinsic[1, 1] *= float(image_dim[1]) / float(intrinsic_image_dim[1])
-    intrinsic[0, 2] *= float(image_dim[0] - 1) / float(intrinsic_image_dim[0] - 1)
-    intrinsic[1, 2] *= float(image_dim[1] - 1) / float(intrinsic_image_dim[1] - 1)
+    w_keep_aspect = int(math.floor(h1 * float(w0) / float(h0)))
+    scale = {(0, 0): float(w_keep_aspect) / float(w0), (1, 1): float(h1) / float(h0),
+             (0, 2): float(w1 - 1) / float(w0 - 1), (1, 2): float(h1 - 1) / float(h0 - 1)}
+    for cell, f in scale.items():
+        intrinsic[cell] *= f
     return intrinsic
 
 

@@ -80,18 +80,13 @@ _side_streams = {}
 
 
 def side_stream(dev):
-    """One auxiliary HIP stream per device (created on first use).  OSN_SIDE_PRIORITY=low | high: created with the lowest /
-    highest stream priority instead of the default one (experiment knob: the weight gradients queued here crowd the main
-    stream's memory-bound kernels; round 3 measured "low" as no change, before the executor moved most work around)."""
+    """One auxiliary HIP stream per device (created on first use), default priority.  (The weight gradients queued here crowd
+    the main stream's memory-bound kernels; a LOW-priority stream was measured twice -- round 3, and round 5 with the executor,
+    profiles/r05_s1_knobs_ab.txt -- as no change: the hardware's priorities do not pre-empt resident workgroups.)"""
     i = _idx(dev)
     s = _side_streams.get(i)
     if s is None:
-        want = os.environ.get("OSN_SIDE_PRIORITY", "")
-        if want in ("low", "high"):
-            lo, hi = torch.cuda.Stream.priority_range()          # (lowest, highest): larger number = lower priority
-            s = torch.cuda.Stream(device=i, priority=lo if want == "low" else hi)
-        else:
-            s = torch.cuda.Stream(device=i)
+        s = torch.cuda.Stream(device=i)
         _side_streams[i] = s
     return s
 

@@ -64,19 +64,16 @@ class Voxelizer:
         return voxelization_matrix, rotation_matrix
 
     def clip(self, coords, center=None, trans_aug_ratio=None):
-        # voxelizer.py:78-95 (dead in every shipped config: clip_bound=None, point_loader.py:95)
-        bound_min = np.min(coords, 0).astype(float)
-        bound_max = np.max(coords, 0).astype(float)
-        bound_size = bound_max - bound_min
-        if center is None:
-            center = bound_min + bound_size * 0.5
-        lim = self.clip_bound
+        """Boolean mask of the points inside ``clip_bound`` (per axis a half-open interval [lo, hi) relative to ``center``, by
+        default the middle of the cloud's bounding box, optionally shifted by a fraction of the box) -- the result of
+        dataset/voxelizer.py:78-95.  Unused by every shipped config (``clip_bound=None``, point_loader.py:95)."""
+        lo, hi = np.min(coords, 0).astype(float), np.max(coords, 0).astype(float)
+        mid = lo + (hi - lo) * 0.5 if center is None else np.asarray(center, dtype=float)
         if trans_aug_ratio is not None:
-            center += np.multiply(trans_aug_ratio, bound_size)
-        keep = np.ones(coords.shape[0], dtype=bool)
-        for a in range(3):
-            keep &= (coords[:, a] >= (lim[a][0] + center[a])) & (coords[:, a] < (lim[a][1] + center[a]))
-        return keep
+            mid = mid + np.multiply(trans_aug_ratio, hi - lo)
+        bound = np.asarray(self.clip_bound, dtype=float)              # [3, 2]
+        xyz = coords[:, :3]
+        return np.all((xyz >= bound[:, 0] + mid) & (xyz < bound[:, 1] + mid), axis=1)
 
     def _device(self):
         if self.device is not None:
