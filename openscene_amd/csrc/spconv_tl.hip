@@ -30,6 +30,7 @@
 // Arithmetic: "bf16x6" -- x = x1 + x2 + x3 (bf16 pieces), a*b ~= a3b1 + a2b2 + a1b3 + a2b1 + a1b2 + a1b1
 // accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (dropped terms <= 2^-24 relative): fp32-class accuracy.
 #include "common.h"
+#include <atomic>
 #include <type_traits>
 #include "weight_prep.h"
 #include "split.h"
@@ -47,6 +48,7 @@ constexpr int TL_LCAP = 1024;     // packed list entries resident in LDS per bat
 constexpr int TL_STEPS = TL_LCAP / 32 * 4;   // step-table entries: 32-pair steps of a batch x channel chunks (<= 4: 512 channels)
 constexpr int TL_KMAX = 128;      // kernel offsets a list-mode launch can take (5^3 = 125)
 constexpr int TL_SLOTS = 512;     // persistent workgroups per column group (2 per CU)
+constexpr int TL_MAX_DEVICES = 64; // per-device "LDS opt-in done" flags of every kernel instance
 
 // ---- layout of a tile-list buffer ("tl"): tiles of bm = osn_tile_rows(n_out) consecutive table rows
 //   int32 cnt[n_tiles][K]        pairs per (tile, offset)                 (256-byte aligned)
@@ -714,6 +716,10 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
     const bool bufg = !prof && !ragged_host && in_bytes64 < (uint64_t(1) << 31);
     const unsigned in_bytes = bufg ? unsigned(in_bytes64) : 0u;
     int rc_attr = OSN_OK;
+    int dev_id = 0;
+    OSN_HIP(hipGetDevice(&dev_id));
+    const bool dev_slot_ok = dev_id >= 0 && dev_id < TL_MAX_DEVICES;      // (beyond: the attribute is set on every tall launch)
+    const int dev_slot = dev_slot_ok ? dev_id : 0;
     if (occ3) {                                       // three persistent workgroups per CU
         gx = unsigned(units < TL_SLOTS / 2 * 3 ? units : TL_SLOTS / 2 * 3);
         grid = dim3(gx, unsigned(gy));
@@ -722,13 +728,16 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
 #define OSN_TL5(NW_, KS_, RG_, PF_, OC_, BG_)                                                                              \
     do {                                                                                                                   \
         auto kern = spconv_tl_kernel<NW_, KS_, RG_, PF_, OC_, BG_>;                                                        \
-        static size_t attr_bytes = 36 * 1024;                                                                              \
-        if (tile_bytes > attr_bytes) {                                                                                     \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(tile_bytes)) != hipSuccess) { \
+        /* dynamic LDS beyond the default limit needs the opt-in attribute: once per (instance, DEVICE), the largest tile any   \
+           launch can ask for; relaxed atomics: a racing second thread (autograd's, the map prefetcher's) sets it again */       \
+        static std::atomic<unsigned char> attr_set[TL_MAX_DEVICES];                                                        \
+        if (tile_bytes > 36 * 1024 && !(dev_slot_ok && attr_set[dev_slot].load(std::memory_order_relaxed))) {              \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                    int(size_t(TL_BMAX + 1) * size_t(32 * NW_ + 4) * 4)) != hipSuccess) {                  \
                 rc_attr = OSN_E_HIP;                                                                                       \
                 break;                                                                                                     \
             }                                                                                                              \
-            attr_bytes = tile_bytes;                                                                                       \
+            if (dev_slot_ok) attr_set[dev_slot].store(1, std::memory_order_relaxed);                                       \
         }                                                                                                                  \
         hipLaunchKernelGGL(kern, grid, dim3(256), tile_bytes, st, in, wp, cnt, lst, out_rows, out, bn_partial, counter, partial, nz, \
                            int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof, in_bytes);               \

@@ -425,12 +425,13 @@ class UNetExecutor:
         side, ws2, events = self._side(lib, dev)
         # a gradient whose producer knows its non-zero rows (openscene_amd.losses.distill_loss: the loss sees `output[sel]`
         # only): the head's two gradients run on those rows.  The hint travels as an attribute of the gradient tensor and is
-        # honoured only when it describes exactly this tensor.
+        # honoured only when it describes exactly this tensor IN THE STATE the loss left it (a tensor hook that edits the
+        # gradient in place moves its version counter: the compacted rows would be stale, the dense gradient is used).
         rows_pos = rows_idx = rows_g = None
         n_rows = 0
         hint = getattr(gout_in, "_osn_rows", None)
         if (ROW_SPARSE_HEAD and hint is not None and hint["ptr"] == gout.data_ptr() and hint["shape"] == tuple(gout.shape)
-                and 0 < hint["idx"].shape[0] < gout.shape[0] and hint["rows"].device == dev):
+                and hint.get("version") == gout_in._version and 0 < hint["idx"].shape[0] < gout.shape[0] and hint["rows"].device == dev):
             rows_pos, rows_idx, rows_g = hint["pos_ptr"], hint["idx"].data_ptr(), hint["rows"].data_ptr()
             n_rows = int(hint["idx"].shape[0])
             keep_hint = hint                      # (the tensors stay referenced until the launches are queued)

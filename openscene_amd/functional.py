@@ -276,9 +276,13 @@ def relu(x):
 
 
 def add(a, b):
-    if not _hip_eligible(a, b) or a.shape != b.shape:
-        if a.is_cuda and b.is_cuda:
-            return a + b
+    """Row-aligned sum of two feature matrices on ONE coordinate map (the BasicBlock residual).  Shapes must agree: a sparse add
+    never broadcasts (a [N, C] + [1, C] would be a coordinate-map bug turned into numbers)."""
+    if a.shape != b.shape:
+        raise ValueError("add: feature matrices of shapes %s and %s (tensors on the same coordinate map have equal shapes)"
+                         % (tuple(a.shape), tuple(b.shape)))
+    if not _hip_eligible(a, b) and a.is_cuda and b.is_cuda:
+        return a + b                    # dtype / stride / alignment the kernel does not take
     return AddFunction.apply(a, b)
 
 

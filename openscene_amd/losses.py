@@ -55,20 +55,23 @@ class _DistillLoss(Function):
         # the gradient of the full output is zero outside the n_sel supervised rows: hand those rows out once more, compacted,
         # with the row <-> position tables of the forward pass.  A consumer that understands the hint (the network executor's
         # head) works on n_sel rows instead of n; everyone else sees the ordinary dense gradient.
-        grows = torch.empty((n_sel, d), dtype=torch.float32, device=dev) if ROWS_HINT and n_sel < n else None
+        # (zeros, not empty: the kernel writes row j only where pos[sel[j]] == j -- with a duplicate in `sel`, which validate=False
+        # does not catch, the losing copy's row would be uninitialised memory multiplied into the head's gradients)
+        grows = torch.zeros((n_sel, d), dtype=torch.float32, device=dev) if ROWS_HINT and n_sel < n else None
         with ops._Dev(dev):
             check(lib.osn_distill_loss_bwd_rows(ops._p(out), ops._p(target), ops._p(gloss), n, n_sel, d, kind, ops._p(gout),
                                                 ops._p(grows), ops._p(state), state.numel(), ops._stream(dev)),
                   "osn_distill_loss_bwd_rows")
         if grows is not None:
             gout._osn_rows = {"ptr": gout.data_ptr(), "shape": tuple(gout.shape), "idx": ctx.sel, "rows": grows,
-                              "pos_ptr": state.data_ptr(), "state": state}
+                              "pos_ptr": state.data_ptr(), "state": state, "version": gout._version}
         return gout, None, None, None, None
 
 
 def distill_loss(output, sel, target, loss_type="cosine", validate=False):
     """Scalar loss of run/distill.py:322-328 over `output[sel]` against `target` (feat_3d).
-    output float32 [N, D] (the network output, input row order); sel: the supervised rows -- int64 indices (distinct; e.g.
+    output float32 [N, D] (the network output, input row order); sel: the supervised rows -- int64 indices (CONTRACT: distinct and
+    in [0, N): an index out of range reads out of bounds, a duplicate is counted once in the backward pass -- validate=True checks both; e.g.
     mask.nonzero().squeeze(1), which the loader hands out next to the mask) or the bool mask itself (resolved here: a host
     synchronisation in the middle of the step); target float [len(sel), D].
     validate: check the indices on the device and raise on an index out of range or a duplicate (synchronises)."""

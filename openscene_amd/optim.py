@@ -50,7 +50,11 @@ class FlatAdam(torch.optim.Optimizer):
         # way run/distill.py:141 builds it, keys its state by) -- NOT its position in the flat layout, which follows the
         # executor's gradient buffer (all conv kernels first, then the BN weight / bias pairs)
         given = (list(model_or_params.parameters()) if isinstance(model_or_params, torch.nn.Module) else list(model_or_params))
-        torch_pos = {id(q): i for i, q in enumerate(q for q in given if q.requires_grad)}
+        # torch keys by position over ALL the parameters it was given, frozen ones included (they simply never get a state entry)
+        torch_pos = {}
+        for q in given:
+            torch_pos.setdefault(id(q), len(torch_pos))
+        self._n_given = len(torch_pos)
         self._ckpt_index = [torch_pos[id(q)] for q in params]
         if not params:
             raise ValueError("FlatAdam got no parameters")
@@ -144,7 +148,7 @@ class FlatAdam(torch.optim.Optimizer):
             n = p.numel()
             state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": self.exp_avg[o:o + n].view_as(p).clone(),
                         "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).clone()}
-        groups = [{**{k: v for k, v in g.items() if k != "params"}, "params": list(range(len(self._params)))} for g in self.param_groups]
+        groups = [{**{k: v for k, v in g.items() if k != "params"}, "params": list(range(self._n_given))} for g in self.param_groups]
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
@@ -152,9 +156,9 @@ class FlatAdam(torch.optim.Optimizer):
             if k != "params":
                 self.param_groups[0][k] = v
         steps = 0
-        if len(sd["param_groups"][0]["params"]) != len(self._params):
-            raise ValueError("loaded state dict holds %d parameters, this optimizer %d"
-                             % (len(sd["param_groups"][0]["params"]), len(self._params)))
+        if len(sd["param_groups"][0]["params"]) != self._n_given:
+            raise ValueError("loaded state dict holds %d parameters, this optimizer was built over %d"
+                             % (len(sd["param_groups"][0]["params"]), self._n_given))
         for i, p, o in zip(self._ckpt_index, self._params, self.offsets):
             st = sd["state"].get(i)
             if st is None:

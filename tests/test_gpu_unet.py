@@ -233,6 +233,38 @@ def test_row_sparse_head_gradients_equal_the_dense_path(kind, monkeypatch):
         assert rel_l2(g_sparse[k], g_torch[k]) <= (2e-5 if kind == "cosine" else 2e-4), k
 
 
+def test_row_hint_is_dropped_when_a_hook_edits_the_gradient_in_place():
+    """The compacted rows that travel with distill_loss's gradient describe the gradient AS THE LOSS WROTE IT: a tensor hook on
+    the network output that scales the gradient in place must reach every parameter, the head included (round 4's advisor
+    finding: the head's two gradients would have been computed from the stale rows)."""
+    from openscene_amd import losses
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import SparseTensor
+    torch.manual_seed(5)
+    net = mink_unet(3, 64, 3, "MinkUNet14A").to(dev()).train()
+    coords = torch.from_numpy(scene_coords(7, 6000, 0.05)).to(dev())
+    n = coords.shape[0]
+    feats = torch.rand(n, 3, device=dev())
+    g = torch.Generator().manual_seed(3)
+    sel = torch.randperm(n, generator=g)[:n // 4].sort()[0].to(dev())
+    target = torch.nn.functional.normalize(torch.randn(sel.shape[0], 64, generator=g), dim=1).to(dev())
+
+    def step(hook):
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.reset_running_stats()
+        net.zero_grad(set_to_none=True)
+        out = net(SparseTensor(feats, coords))
+        if hook:
+            out.register_hook(lambda gr: gr.mul_(2.0))
+        losses.distill_loss(out, sel, target, "cosine").backward()
+        return {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+    plain, doubled = step(False), step(True)
+    for k in plain:
+        assert rel_l2(doubled[k], 2.0 * plain[k]) <= 2e-6, k
+
+
 def test_segmented_backward_pass_is_bitwise_the_single_call(monkeypatch):
     """The backward pass played in 4 segments (what an attached gradient exchange does, distributed.FlatGradAllReduce.attach):
     the hook sees disjoint slices that tile the kernels' region of the flat gradient buffer, highest ops first, and every

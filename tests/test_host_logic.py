@@ -281,3 +281,15 @@ def test_distill_loss_oracle_is_the_reference_expression(loss_type):
     assert abs(loss - ref.item()) <= 1e-12 * max(1.0, abs(ref.item()))
     np.testing.assert_allclose(grad, x.grad.numpy(), rtol=1e-10, atol=1e-14)
     assert not grad[~mask.numpy()].any()
+
+
+def test_sparse_add_never_broadcasts():
+    """tensors on one coordinate map have equal shapes; a mismatch is a coordinate-map bug and raises (MinkowskiEngine's
+    sparse add does not broadcast either), it does not fall back to torch's broadcasting `a + b`."""
+    import pytest
+    import torch
+    from openscene_amd import functional as F_
+    with pytest.raises(ValueError, match="same coordinate map"):
+        F_.add(torch.zeros(8, 4), torch.zeros(1, 4))
+    with pytest.raises(ValueError, match="same coordinate map"):
+        F_.add(torch.zeros(8, 4), torch.zeros(8, 1))

@@ -201,3 +201,39 @@ def test_gradients_that_came_through_autograd_are_still_found_in_their_flat_buff
     ps[1].grad = None
     assert shared_flat([p.grad for p in ps]) is None
     assert shared_flat([]) is None
+
+
+def test_flat_adam_checkpoint_indices_count_frozen_parameters_like_torch(fake_adam):
+    """torch.optim.Adam(model.parameters()) (run/distill.py:141) keys its state by position over ALL the parameters it
+    was given, frozen ones included; FlatAdam numbers its checkpoint the same way, so the two interchange for a model with a
+    frozen parameter (before: shifted indices and a length error)."""
+    from openscene_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(4)
+    shapes = [(4, 4), (6,), (4, 4), (2,)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+
+    def params():
+        ps = [torch.nn.Parameter(t.clone()) for t in init]
+        ps[1].requires_grad_(False)                   # frozen, in the middle
+        return ps
+    ref_p, our_p = params(), params()
+    ref = torch.optim.Adam(ref_p, lr=1e-3)
+    ours = FlatAdam(our_p, lr=1e-3)
+    for _ in range(2):
+        for p, q in zip(ref_p, our_p):
+            if p.requires_grad:
+                p.grad = torch.randn(p.shape, generator=g)
+                q.grad = p.grad.clone()
+        ref.step()
+        ours.step()
+    sd, ref_sd = ours.state_dict(), ref.state_dict()
+    assert sorted(sd["state"]) == sorted(ref_sd["state"]) == [0, 2, 3]
+    assert sd["param_groups"][0]["params"] == ref_sd["param_groups"][0]["params"] == [0, 1, 2, 3]
+    for i in (0, 2, 3):
+        assert torch.allclose(sd["state"][i]["exp_avg_sq"], ref_sd["state"][i]["exp_avg_sq"], rtol=1e-5, atol=1e-7)
+    again = FlatAdam(params(), lr=1.0)
+    again.load_state_dict(ref_sd)                     # a torch checkpoint with a stateless frozen entry
+    assert again.steps == 2
+    ref2 = torch.optim.Adam(params(), lr=1e-3)
+    ref2.load_state_dict(sd)                          # and back
+    assert sorted(ref2.state_dict()["state"]) == [0, 2, 3]
