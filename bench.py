@@ -496,15 +496,23 @@ def cpu_baseline(seed, arch, out_dim):
     n_small, dt_small = runs[2]
     res = {"value": n_small / dt_small, "unit": "voxels/s", "cores": threads, "kind": "port",
            "sample": "median of 5 steps (after warm-ups; maps + fwd + loss + bwd, fp32, no optimizer) of %s on a 1/8-size "
-                     "scene of the S100k generator: %d voxels in %.2f s with %d threads (fastest of the thread ladder)"
-                     % (arch, n_small, dt_small, threads),
-           "cores_visible": cores,
+                     "scene of the S100k generator: %d voxels in %.2f s with %d threads (fastest of the thread ladder; %d cores visible)"
+                     % (arch, n_small, dt_small, threads, cores),
+           "cores_visible": cores, "threads": threads,
            "thread_ladder_voxels_per_s": {str(k): v for k, v in ladder.items()},
            "one_thread": {"value": ladder[1], "voxels": n_small}}
     est_full = dt_small * (100999.0 / n_small)
     if est_full < 40.0:
+        # "same inputs" -- when the full S100k scene fits the time bound IT is the headline value (ONE step, to keep
+        # the baseline leg at ~30 s of CPU work; the thread pool and BLAS are warm from the runs above), the 1/8-size median stays
+        # beside it
         n, dt = _cpu_step(seed, 120000, arch, out_dim)
+        res["eighth_scene"] = {"value": res["value"], "voxels": n_small, "seconds": dt_small}
         res["full_scene"] = {"value": n / dt, "voxels": n, "seconds": dt, "threads": threads}
+        res["value"] = n / dt
+        res["sample"] = ("one step (maps + fwd + loss + bwd, fp32, no optimizer) of %s on the SAME S100k scene "
+                         "the GPU line is quoted on: %d voxels in %.2f s with %d threads (fastest of a 1..64 thread ladder on a 1/8-size "
+                         "scene; %d cores visible)" % (arch, n, dt, threads, cores))
     from oracle import voxelize as ov
     from openscene_amd import synthetic as syn
     pts = syn.room_points(7, n_pts=200000)
@@ -554,15 +562,16 @@ def headline(detail, detail_path=None):
                                           "step_algorithmic_GB", "step_GFLOP") if k in cfg}
     rf = detail.get("roofline")
     if rf:
-        keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "shape", "avg_launch_us", "launches_per_step",
+        keep = ("bound", "achieved", "peak", "unit", "frac", "frac_all", "frac_fwd", "traffic", "kernel", "shape", "avg_launch_us",
+                "avg_launch_us_fwd", "launches_per_step",
                 "bytes_per_launch", "flops_per_launch", "hbm_frac", "mfma_frac", "step_hbm_frac", "step_mfma_frac", "evidence")
         line["roofline"] = {k: _num(rf[k]) for k in keep if k in rf}
     else:
         line["roofline"] = None
     cb = detail.get("cpu_baseline")
     if cb:
-        line["cpu_baseline"] = {k: _num(cb.get(k)) for k in ("value", "unit", "cores", "kind")}
-        line["cpu_baseline"]["sample"] = str(cb.get("sample"))[:240]
+        line["cpu_baseline"] = {k: _num(cb.get(k)) for k in ("value", "unit", "cores", "cores_visible", "kind")}
+        line["cpu_baseline"]["sample"] = str(cb.get("sample"))[:300]
     else:
         line["cpu_baseline"] = None
     q = detail.get("query")
@@ -572,6 +581,8 @@ def headline(detail, detail_path=None):
         for k in ("matterport160", "q1m_labels", "q1m_scores"):
             if k in q:
                 line["query"][k] = {"ms": _num(q[k]["ms"]), "hbm_frac": _num(q[k]["hbm_frac"])}
+        if "torch_call_site" in q:
+            line["query"]["torch_call_site_ms"] = _num(q["torch_call_site"]["ms"])
     if detail.get("voxelizer"):
         line["voxelizer_ms"] = _num(detail["voxelizer"]["ms"])
     ph = detail.get("phases")
@@ -581,6 +592,12 @@ def headline(detail, detail_path=None):
     if cm:
         line["comm"] = {k: _num(cm[k]) for k in ("backend", "ranks", "allreduce_MB", "allreduce_ms_standalone",
                                                  "share_of_step_if_exposed", "ms_per_step_by_rank", "hw_queues") if k in cm}
+    di = (ph or {}).get("drop_in_step")
+    if isinstance(di, dict) and di.get("ms"):
+        # the step with run/distill.py's call sites UNCHANGED (alias + import hook, torch.optim.Adam, bool-mask loss, maps inside
+        # the step), beside ms_per_step (which has the three call-site edits of INTEGRATION.md section 1)
+        line["ms_per_step_call_sites_unchanged"] = _num(di["ms"])
+        line["value_call_sites_unchanged"] = _num(di.get("voxels_per_s"))
     line["loss"] = detail.get("loss")
     line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
     s = json.dumps(line, separators=(",", ":"))
@@ -929,11 +946,11 @@ def main():
             by_flops = max(survey_shapes.items(), key=flops0)
             by_time = max(survey_shapes.items(), key=lambda kv: kv[1]["ms"])
             dom_key, d_g = by_time if by_time[1]["ms"] > 1.15 * by_flops[1]["ms"] else by_flops
-            # bracket its FORWARD launches in the timed region: in the backward pass the same kernel shares the device with the
-            # weight gradients running on the side stream, which stretches the individual launches (and shortens the step)
-            fwd_tags = sorted(t for t in d_g["tags"] if t % 4 == 0)
-            dom_tags = fwd_tags or sorted(d_g["tags"])
-            dom_fwd_only = bool(fwd_tags) and len(fwd_tags) < len(d_g["tags"])
+            # bracket ALL its launches in the timed region, both passes: `frac` is over all of them (in the backward pass the same
+            # kernel shares the device with the weight gradients running on the side stream, which stretches the individual
+            # launches and shortens the step); `frac_fwd` = the forward-pass launches alone, printed beside it
+            dom_tags = sorted(d_g["tags"])
+            dom_fwd_only = False
             prof.only(dom_tags)
     elif legacy is not None:
         for _ in range(max(0, 3 - args.warmup)):
@@ -974,8 +991,10 @@ def main():
             timed = prof.records_of_step(sizes, {i: 0 for i in range(len(ex.program.map_keys))})
             ref = survey_shapes[dom_key]
             per_launch_b, per_launch_f = ref["bytes"] / ref["launches"], ref["flops"] / ref["launches"]      # same for both passes
+            fwd = [r for r in timed if r[1] % 4 == 0]
             g = {"launches": len(timed), "ms": sum(r[2] for r in timed), "bytes": per_launch_b * len(timed),
-                 "flops": per_launch_f * len(timed), "meta": ref["meta"]}
+                 "flops": per_launch_f * len(timed), "meta": ref["meta"],
+                 "launches_fwd": len(fwd), "ms_fwd": sum(r[2] for r in fwd)}
             if g["launches"]:
                 timed_groups = {dom_key[0]: g}
         prof.close()
@@ -1085,6 +1104,26 @@ def main():
         q_bytes = 4.0 * n_pts * out_dim + 2.0 * 20 * out_dim + 8.0 * n_pts + 8.0 * n_pts
         qres = {"ms": q_ms, "n_points": n_pts, "dim": out_dim, "labels": 20,
                 "hbm_frac": q_bytes / (q_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+        # the reference's call site AS WRITTEN (run/evaluate.py:290-292: gather, .half(), matmul, max) through
+        # torch on the same box and inputs -- what an unchanged evaluate.py runs, and so what the one-line edit to
+        # openscene_amd.query.query_distill buys
+        def torch_call_site():
+            predictions = pred[inds_reverse, :]
+            sc = predictions.half() @ text.t()
+            return torch.max(sc, 1)[1]
+        for _ in range(3):
+            torch_call_site()
+        torch.cuda.synchronize(device)
+        e0.record()
+        for _ in range(reps):
+            torch_call_site()
+        e1.record()
+        torch.cuda.synchronize(device)
+        qt_ms = e0.elapsed_time(e1) / reps
+        same = float((torch_call_site() == query_distill(pred, text, inds_reverse)).float().mean())
+        qres["torch_call_site"] = {"ms": qt_ms, "speedup_of_query_distill": qt_ms / q_ms, "labels_equal_frac": same,
+                                   "what": "predictions[inds_reverse].half() @ text.t(); torch.max(.., 1)[1] through torch (run/evaluate.py:290-292 unchanged)"}
         # Matterport-160-shaped query (configs[3]): 500 k points x 160 labels, with the fp16 score matrix
         n2, c2 = 500000, 160
         x2 = torch.randn(n2 // 4, out_dim, generator=gq).to(device)
@@ -1316,6 +1355,13 @@ def main():
         else:
             roofline = dict({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS}, **common)
+        # `frac` = all bracketed launches of the shape (both passes); the forward-pass launches alone beside it
+        roofline["frac_all"] = roofline["frac"]
+        if gk.get("launches_fwd") and gk.get("ms_fwd", 0) > 0:
+            us_f = 1e3 * gk["ms_fwd"] / gk["launches_fwd"]
+            per_f = (gk["flops"] if roofline["bound"] == "mfma" else gk["bytes"]) / gk["launches"]
+            roofline["avg_launch_us_fwd"] = us_f
+            roofline["frac_fwd"] = per_f / (us_f * 1e-6) / (1e12 if roofline["bound"] == "mfma" else 1e9) / roofline["peak"]
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         # separate process (own thread pool, no GPU context) with a hard time bound

@@ -52,6 +52,24 @@ def test_headline_drops_side_blocks_rather_than_outgrow_the_limit():
     assert "phases_ms" not in back and all(k in back for k in REQUIRED)
 
 
+def test_headline_carries_the_round5_fields():
+    """VERDICT r4 'next' #4: the line says what SURVEY 8(d) defines -- roofline fraction over ALL launches of the dominant shape with
+    the forward-pass-only figure beside it, the step with the reference's call sites unchanged next to ms_per_step, the CPU
+    baseline's visible cores next to the threads it used, the torch call-site query time next to the kernel's."""
+    b = _bench()
+    detail = json.loads(open(os.path.join(ROOT, "profiles", "r03_s20_bench_head.json")).read().strip().splitlines()[-1])
+    rf = detail["roofline"]
+    rf.update({"frac_all": rf["frac"], "frac_fwd": rf["frac"] * 1.06, "avg_launch_us_fwd": rf["avg_launch_us"] / 1.06})
+    detail["cpu_baseline"].update({"cores_visible": 256, "cores": 16})
+    detail["phases"] = dict(detail.get("phases") or {}, drop_in_step={"ms": 11.24, "voxels_per_s": 100999 / 11.24e-3})
+    detail["query"]["torch_call_site"] = {"ms": 0.31}
+    back = json.loads(json.dumps(b.headline(detail, None), separators=(",", ":")))
+    assert back["roofline"]["frac_all"] == back["roofline"]["frac"] and back["roofline"]["frac_fwd"] > back["roofline"]["frac"]
+    assert back["ms_per_step_call_sites_unchanged"] == 11.24 and back["value_call_sites_unchanged"] > 0
+    assert back["cpu_baseline"]["cores_visible"] == 256 and back["cpu_baseline"]["cores"] == 16
+    assert back["query"]["torch_call_site_ms"] == 0.31
+
+
 def test_gpus_n_without_a_launcher_spawns_its_own_ranks():
     """`python bench.py --gpus 2` (no torchrun, no RANK in the environment) re-executes under torch.distributed.run; the
     hidden self-test mode runs the N > 1 harness (barrier-bracketed timing, MAX over ranks, rank-0 line) on gloo / CPU."""
