@@ -42,6 +42,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TL_BMAX = 88;       // rows per tile at most (LDS budget of the 128-column instance, 2 workgroups / CU)
+constexpr int TL_LIST_BMAX = 128; // rows per tile the LISTS can describe (a local row is 8 bits of a packed entry; spconv_pl.hip takes 128)
 constexpr int TL_BMIN = 32;       // rows per tile of small tables
 constexpr int TL_BOCC3 = 64;      // rows per tile that osn_tile_rows hands out at most (three workgroups per CU, see there)
 constexpr int TL_LCAP = 1024;     // packed list entries resident in LDS per batch of offsets
@@ -594,7 +595,7 @@ extern "C" int osn_tile_lists_build(const int32_t* nbr, int64_t n_out, int K, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_tile_lists_build: n_out out of range");
     OSN_REQUIRE(K >= 1 && K <= TL_KMAX, OSN_E_ARG, "osn_tile_lists_build: K=%d (at most %d offsets)", K, TL_KMAX);
-    OSN_REQUIRE(bm >= 1 && bm <= TL_BMAX, OSN_E_ARG, "osn_tile_lists_build: bm=%d (at most %d rows per tile)", bm, TL_BMAX);
+    OSN_REQUIRE(bm >= 1 && bm <= TL_LIST_BMAX, OSN_E_ARG, "osn_tile_lists_build: bm=%d (at most %d rows per tile)", bm, TL_LIST_BMAX);
     if (n_out == 0) return OSN_OK;
     OSN_REQUIRE(nbr && tl, OSN_E_ARG, "osn_tile_lists_build: null pointer");
     TlView v = tl_view(tl, n_out, K, bm);
