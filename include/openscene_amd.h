@@ -369,20 +369,6 @@ int osn_bn_backward_multi2(const float* x, const float* y, const float* const* g
                            const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
                            int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c, void* ws,
                            size_t ws_bytes, osn_stream_t stream);
-/* The two training-mode calls with caller-owned PERSISTENT ticket counters (OSN_BN_COUNTERS int32 in device memory, zero
- * before the first call, left zero by every call; ONE buffer per stream -- calls that may run concurrently need their own):
- * the last workgroup of the column reduction finishes the statistics itself (same summation order: bitwise the results of
- * osn_bn_forward_train2 / osn_bn_backward_multi2), so a batch norm (models/resnet_base.py:98, models/mink_unet.py:50-102)
- * above 4096 rows is two launches per direction instead of three.                                                        */
-#define OSN_BN_COUNTERS 64
-int osn_bn_forward_train_pc(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
-                            const float* residual, int relu, float momentum, float* mean, float* var,
-                            float* running_mean, float* running_var, float* y, float* y2, int64_t ld2,
-                            void* ws, size_t ws_bytes, int32_t* counters, osn_stream_t stream);
-int osn_bn_backward_pc(const float* x, const float* y, const float* const* gy_host, const int64_t* gy_ld_host, int n_gy,
-                       const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
-                       int training, float* gx, float* gres, float* ggamma, float* gbeta,
-                       int64_t n, int c, void* ws, size_t ws_bytes, int32_t* counters, osn_stream_t stream);
 
 /* ---- distillation loss on the supervised rows ------------------------------- *
  * Replaces run/distill.py:322-328 and its autograd chain:
@@ -596,7 +582,6 @@ typedef struct osn_events osn_events_t;       /* pool of HIP events for the fork
  * plays the last segment (flags 0) joins everything.  Input gradients a later segment reads are joined by their own events
  * either way.                                                                                                      */
 #define OSN_NET_RUN_NO_JOIN 1
-#define OSN_NET_COUNTERS 256
 typedef struct osn_net_run {
     const int64_t* level_rows;   /* [n_levels] rows of every pyramid level                                        */
     const osn_net_map* maps;
@@ -608,9 +593,7 @@ typedef struct osn_net_run {
     void* fwd_arena; uint64_t fwd_arena_bytes;
     void* bwd_arena; uint64_t bwd_arena_bytes;
     void* ws; uint64_t ws_bytes;
-    int32_t* tl_counters;        /* OSN_NET_COUNTERS persistent counters of this run's streams, zero before the first use:
-                                    [0, 128) tile counters (osn_spconv_fwd_tl_pc), [128, 192) batch-norm tickets of the main
-                                    stream, [192, 256) of the side stream (osn_bn_*_pc)                              */
+    int32_t* tl_counters;        /* 128 persistent tile counters of this stream (osn_spconv_fwd_tl_pc)            */
     int32_t training;            /* batch statistics + running update (1) or running statistics (0)               */
     int32_t first_op, end_op;    /* ops [first_op, end_op) are executed                                           */
     int32_t flags;               /* OSN_NET_RUN_*                                                                 */

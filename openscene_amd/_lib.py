@@ -79,13 +79,10 @@ PROTOTYPES = {
                                _vp, _sz, _vp]),
     "osn_bn_apply2": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _i64, _i64, _i32, _vp]),
     "osn_bn_forward_train2": (_i32, [_vp, _i64, _i32, _vp, _vp, _f32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
-    "osn_bn_forward_train_pc": (_i32, [_vp, _i64, _i32, _vp, _vp, _f32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp, _vp]),
     "osn_bn_backward_multi": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32,
                                      _vp, _sz, _vp]),
     "osn_bn_backward_multi2": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32,
                                      _vp, _sz, _vp]),
-    "osn_bn_backward_pc": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32,
-                                     _vp, _sz, _vp, _vp]),
     "osn_net_plan_query": (_i32, [_vp, _vp, _i32, _vp]),
     "osn_net_forward": (_i32, [_vp, _vp, _vp]),
     "osn_net_backward": (_i32, [_vp, _vp, _vp]),

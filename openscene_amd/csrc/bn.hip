@@ -12,8 +12,6 @@ namespace osn {
 constexpr int CR_COLS = 64;    // columns per block (16 lanes x float4)
 constexpr int CR_RL = 16;      // row lanes per block
 constexpr int CR_MAX_BLOCKS = 512;
-constexpr int FIN_PARTS_ = 64;                              // = FIN_PARTS / FIN_ITERS of the finalize kernels below (same association)
-constexpr int FIN_ITERS_ = CR_MAX_BLOCKS / FIN_PARTS_;
 
 // The gradient arriving at a batch norm's output may be the SUM of several row-aligned matrices (a block input feeds
 // conv1 and the residual; an encoder output feeds the next stride-2 conv and, through ME.cat, two convs of the decoder --
@@ -58,27 +56,13 @@ static ColReducePlan plan_colreduce(int64_t n, int c) {
     return p;
 }
 
-// What the LAST workgroup of a column group does with the finished partial sums when the launch carries a ticket counter
-// (round 5): the work of bn_stats_finalize_kernel (MODE 0: a = mean, b = var, + the running buffers) / bn_bwd_finalize_kernel
-// (MODE 1: a = sum g, b = sum g * xhat) inside the reduction -- one launch and one launch gap per batch-norm direction fewer
-// (78 launches of a MinkUNet18A training step; the finalize kernels were 0.67 ms of it, profiles/r04_s12_kernel_stats_per_step.csv).
-struct BnFin {
-    int32_t* counter;        // [column groups] tickets, zero on entry, left zero; null = the caller launches the finalize kernel
-    float* a;
-    float* b;
-    float* running_mean;
-    float* running_var;
-    float momentum;
-};
-
 // MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat), g = relu ? gy*(y>0) : gy
 template <int MODE>
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const GySrc gy, const float* __restrict__ mean,
                                                          const float* __restrict__ var, float eps, int relu, int64_t n,
                                                          int c, int rows_per_block, double* __restrict__ partial,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const BnFin fin) {
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta) {
     __shared__ double red[2][CR_RL][CR_COLS];
     const int tid = threadIdx.x;
     const int cl = tid & 15, rl = tid >> 4;
@@ -138,69 +122,6 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
         const int gc = blockIdx.y * CR_COLS + cc;
         if (gc < c) partial[(int64_t(blockIdx.x) * 2 + which) * c + gc] = s;
     }
-    if (!fin.counter) return;
-    // ---- ticket: the last workgroup of this column group to get here sums the partial blocks.  Same association as
-    // finalize_sums (slice p = blocks p, p + 64, ...; groups of 8 slices; the 8 group sums): bitwise the two-launch result.
-    __shared__ int last_s;
-    __threadfence();                                   // this workgroup's partial sums are visible device-wide ...
-    __syncthreads();                                   // ... before its ticket is drawn
-    if (tid == 0) last_s = atomicAdd(&fin.counter[blockIdx.y], 1) == int(gridDim.x) - 1;
-    __syncthreads();
-    if (!last_s) return;
-    __threadfence();                                   // (acquire: the other workgroups' sums, not a stale cache line)
-    const int n_rb = int(gridDim.x);
-    const int fc = tid & (CR_COLS - 1), fh = tid >> 6;                     // column of the group, quarter
-    const int gcol = blockIdx.y * CR_COLS + fc;
-    const int ccl = gcol < c ? gcol : 0;
-    double(*tsum)[8][CR_COLS] = reinterpret_cast<double(*)[8][CR_COLS]>(&red[0][0][0]);      // [2][8][64] of red's [2][16][64]
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
-        const int g8 = fh + 4 * gi;                    // group of 8 slices
-        double t1 = 0, t2 = 0;
-        for (int q = 0; q < 8; ++q) {
-            const int part = g8 * 8 + q;
-            double va[FIN_ITERS_], vb[FIN_ITERS_];
-#pragma unroll
-            for (int i = 0; i < FIN_ITERS_; ++i) {
-                const int blk = part + FIN_PARTS_ * i;
-                const int bc = blk < n_rb ? blk : 0;
-                va[i] = partial[(int64_t(bc) * 2 + 0) * c + ccl];
-                vb[i] = partial[(int64_t(bc) * 2 + 1) * c + ccl];
-            }
-            double a = 0, b = 0;
-#pragma unroll
-            for (int i = 0; i < FIN_ITERS_; ++i) {
-                const bool on2 = gcol < c && part + FIN_PARTS_ * i < n_rb;
-                a += on2 ? va[i] : 0.0;
-                b += on2 ? vb[i] : 0.0;
-            }
-            t1 += a;
-            t2 += b;
-        }
-        tsum[0][g8][fc] = t1;
-        tsum[1][g8][fc] = t2;
-    }
-    __syncthreads();
-    if (tid == 0) fin.counter[blockIdx.y] = 0;         // zero again for the next launch on this stream
-    if (tid >= CR_COLS || gcol >= c) return;
-    double f1 = 0, f2 = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { f1 += tsum[0][q][fc]; f2 += tsum[1][q][fc]; }
-    if (MODE == 0) {
-        const double m = f1 / double(n);
-        double v = f2 / double(n) - m * m;
-        if (v < 0) v = 0;
-        fin.a[gcol] = float(m);
-        fin.b[gcol] = float(v);
-        if (fin.running_mean) fin.running_mean[gcol] = (1.f - fin.momentum) * fin.running_mean[gcol] + fin.momentum * float(m);
-        if (fin.running_var) {
-            const double unb = n > 1 ? v * double(n) / double(n - 1) : v;
-            fin.running_var[gcol] = (1.f - fin.momentum) * fin.running_var[gcol] + fin.momentum * float(unb);
-        }
-    } else {
-        fin.a[gcol] = float(f1);
-        fin.b[gcol] = float(f2);
-    }
 }
 
 // Final column sums: 64 columns x 16 slices of the partial blocks per workgroup
@@ -208,7 +129,6 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
 constexpr int FIN_COLS = 16, FIN_PARTS = 64;      // 64 slices: 8 dependent partial reads per thread at 512 row blocks (16 slices: 32 reads, 7.5 us per launch)
 
 constexpr int FIN_ITERS = CR_MAX_BLOCKS / FIN_PARTS;     // partial blocks per thread (8)
-static_assert(FIN_PARTS == FIN_PARTS_ && FIN_ITERS == FIN_ITERS_, "col_reduce_kernel's last-workgroup finalize follows finalize_sums");
 
 __device__ inline void finalize_sums(const double* __restrict__ partial, int n_rb, int c, double& s1, double& s2,
                                      int& col) {
@@ -490,30 +410,22 @@ extern "C" size_t osn_bn_ws_bytes(int64_t n, int c) {
     return size_t(CR_MAX_BLOCKS) * 2 * size_t(c) * 8 + 256;
 }
 
-static int bn_stats_impl(const float* x, int64_t n, int c, float* mean, float* var, float* running_mean, float* running_var,
-                         float momentum, void* ws, size_t ws_bytes, int32_t* counters, osn_stream_t stream) {
+extern "C" int osn_bn_stats(const float* x, int64_t n, int c, float* mean, float* var, float* running_mean,
+                            float* running_var, float momentum, void* ws, size_t ws_bytes, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n >= 1 && c >= 4 && (c & 3) == 0, OSN_E_ARG, "osn_bn_stats: need n >= 1 and c %% 4 == 0 (n=%lld c=%d)", (long long)n, c);
     OSN_REQUIRE(x && mean && var && aligned16(x), OSN_E_ARG, "osn_bn_stats: null or unaligned pointer");
     ColReducePlan p = plan_colreduce(n, c);
     const size_t need = size_t(p.n_rb) * 2 * size_t(c) * 8;
     OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_bn_stats: workspace %zu < %zu", ws_bytes, need);
-    OSN_REQUIRE(!counters || p.n_cg <= OSN_BN_COUNTERS, OSN_E_RANGE, "osn_bn: %d channels need more than %d ticket counters", c, OSN_BN_COUNTERS);
     double* partial = static_cast<double*>(ws);
-    const BnFin fin{counters, mean, var, running_mean, running_var, momentum};
     hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(p.n_rb, p.n_cg), dim3(256), 0, st, x, (const float*)nullptr,
                        GySrc{}, (const float*)nullptr, (const float*)nullptr, 0.f, 0, n, c,
-                       p.rows_per_block, partial, (const float*)nullptr, (const float*)nullptr, fin);
-    if (!counters)
-        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(c, FIN_COLS)), dim3(FIN_COLS * FIN_PARTS), 0, st, partial, p.n_rb, n, c,
-                           mean, var, running_mean, running_var, momentum);
+                       p.rows_per_block, partial, (const float*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(c, FIN_COLS)), dim3(FIN_COLS * FIN_PARTS), 0, st, partial, p.n_rb, n, c, mean, var,
+                       running_mean, running_var, momentum);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
-}
-
-extern "C" int osn_bn_stats(const float* x, int64_t n, int c, float* mean, float* var, float* running_mean,
-                            float* running_var, float momentum, void* ws, size_t ws_bytes, osn_stream_t stream) {
-    return bn_stats_impl(x, n, c, mean, var, running_mean, running_var, momentum, ws, ws_bytes, nullptr, stream);
 }
 
 extern "C" int osn_bn_apply2(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
@@ -544,10 +456,10 @@ extern "C" int osn_bn_apply(const float* x, const float* mean, const float* var,
 // Training-mode forward in ONE call: statistics (+ running buffers) and the fused normalise (+ residual) (+ ReLU) pass
 // (+ the second destination of osn_bn_apply2).  Up to SB_MAX_ROWS rows: ONE launch (bn_small_fwd_kernel); above: the
 // kernels of osn_bn_stats + osn_bn_apply2.
-static int bn_forward_train_impl(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
+extern "C" int osn_bn_forward_train2(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
                                      const float* residual, int relu, float momentum, float* mean, float* var,
                                      float* running_mean, float* running_var, float* y, float* y2, int64_t ld2, void* ws,
-                                     size_t ws_bytes, int32_t* counters, osn_stream_t stream) {
+                                     size_t ws_bytes, osn_stream_t stream) {
     if (n >= 1 && n <= SB_MAX_ROWS && c >= 4 && (c & 3) == 0) {
         hipStream_t st = static_cast<hipStream_t>(stream);
         OSN_REQUIRE(x && mean && var && gamma && beta && y, OSN_E_ARG, "osn_bn_forward_train: null pointer");
@@ -560,26 +472,9 @@ static int bn_forward_train_impl(const float* x, int64_t n, int c, const float* 
         OSN_LAUNCH_CHECK();
         return OSN_OK;
     }
-    int rc = bn_stats_impl(x, n, c, mean, var, running_mean, running_var, momentum, ws, ws_bytes, counters, stream);
+    int rc = osn_bn_stats(x, n, c, mean, var, running_mean, running_var, momentum, ws, ws_bytes, stream);
     if (rc) return rc;
     return osn_bn_apply2(x, mean, var, gamma, beta, eps, residual, relu, y, y2, ld2, n, c, stream);
-}
-
-extern "C" int osn_bn_forward_train2(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
-                                     const float* residual, int relu, float momentum, float* mean, float* var,
-                                     float* running_mean, float* running_var, float* y, float* y2, int64_t ld2, void* ws,
-                                     size_t ws_bytes, osn_stream_t stream) {
-    return bn_forward_train_impl(x, n, c, gamma, beta, eps, residual, relu, momentum, mean, var, running_mean, running_var, y, y2, ld2, ws,
-                                 ws_bytes, nullptr, stream);
-}
-
-extern "C" int osn_bn_forward_train_pc(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
-                                       const float* residual, int relu, float momentum, float* mean, float* var,
-                                       float* running_mean, float* running_var, float* y, float* y2, int64_t ld2, void* ws,
-                                       size_t ws_bytes, int32_t* counters, osn_stream_t stream) {
-    OSN_REQUIRE(counters, OSN_E_ARG, "osn_bn_forward_train_pc: null counters (%d int32, zero before the first call)", OSN_BN_COUNTERS);
-    return bn_forward_train_impl(x, n, c, gamma, beta, eps, residual, relu, momentum, mean, var, running_mean, running_var, y, y2, ld2, ws,
-                                 ws_bytes, counters, stream);
 }
 
 extern "C" int osn_bn_forward_train(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
@@ -590,10 +485,10 @@ extern "C" int osn_bn_forward_train(const float* x, int64_t n, int c, const floa
                                  nullptr, 0, ws, ws_bytes, stream);
 }
 
-static int bn_backward_impl(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,
+extern "C" int osn_bn_backward_multi2(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,
                                       const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
                                      int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c,
-                                     void* ws, size_t ws_bytes, int32_t* counters, osn_stream_t stream) {
+                                     void* ws, size_t ws_bytes, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n >= 1 && c >= 4 && (c & 3) == 0, OSN_E_ARG, "osn_bn_backward: need n >= 1 and c %% 4 == 0");
     OSN_REQUIRE(gy && gy_ld && n_gy >= 1 && n_gy <= BN_MAX_SRC, OSN_E_ARG,
@@ -620,36 +515,15 @@ static int bn_backward_impl(const float* x, const float* y, const float* const* 
     const size_t need = size_t(p.n_rb) * 2 * size_t(c) * 8;
     OSN_REQUIRE(ws && ws_bytes >= need, OSN_E_WS, "osn_bn_backward: workspace %zu < %zu", ws_bytes, need);
     double* partial = static_cast<double*>(ws);
-    OSN_REQUIRE(!counters || p.n_cg <= OSN_BN_COUNTERS, OSN_E_RANGE, "osn_bn: %d channels need more than %d ticket counters", c, OSN_BN_COUNTERS);
-    // ggamma = sum g*xhat, gbeta = sum g  (also the two column sums the apply pass needs): by the reduction's last workgroups
-    // when the caller brought ticket counters, else by the finalize kernel
-    const BnFin fin{counters, gbeta, ggamma, nullptr, nullptr, 0.f};
     hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(p.n_rb, p.n_cg), dim3(256), 0, st, x, y, src, mean, var, eps, relu, n,
-                       c, p.rows_per_block, partial, gamma, beta, fin);
-    if (!counters)
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, FIN_COLS)), dim3(FIN_COLS * FIN_PARTS), 0, st, partial, p.n_rb, c, gbeta, ggamma);
+                       c, p.rows_per_block, partial, gamma, beta);
+    // ggamma = sum g*xhat, gbeta = sum g  (also the two column sums the apply pass needs)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, FIN_COLS)), dim3(FIN_COLS * FIN_PARTS), 0, st, partial, p.n_rb, c, gbeta, ggamma);
     const int64_t total4 = n * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, y, src, mean, var, gamma, eps,
                        relu, training, gbeta, ggamma, 1.f / float(n), gx, gres, total4, c / 4, beta);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
-}
-
-extern "C" int osn_bn_backward_multi2(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,
-                                      const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
-                                      int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c,
-                                      void* ws, size_t ws_bytes, osn_stream_t stream) {
-    return bn_backward_impl(x, y, gy, gy_ld, n_gy, mean, var, gamma, beta, eps, relu, training, gx, gres, ggamma, gbeta, n, c, ws, ws_bytes,
-                            nullptr, stream);
-}
-
-extern "C" int osn_bn_backward_pc(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,
-                                  const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
-                                  int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c,
-                                  void* ws, size_t ws_bytes, int32_t* counters, osn_stream_t stream) {
-    OSN_REQUIRE(counters, OSN_E_ARG, "osn_bn_backward_pc: null counters (%d int32, zero before the first call)", OSN_BN_COUNTERS);
-    return bn_backward_impl(x, y, gy, gy_ld, n_gy, mean, var, gamma, beta, eps, relu, training, gx, gres, ggamma, gbeta, n, c, ws, ws_bytes,
-                            counters, stream);
 }
 
 extern "C" int osn_bn_backward_multi(const float* x, const float* y, const float* const* gy, const int64_t* gy_ld, int n_gy,

@@ -422,12 +422,8 @@ extern "C" int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, 
         }
         if (run->training) {
             float* mv = reinterpret_cast<float*>(A + L.stat_off[i]);
-            // (ticket counters of the stream the stage runs on: a shortcut stage's batch norm runs beside the main stream's)
-            int32_t* tickets = run->tl_counters ? run->tl_counters + (on_side ? 192 : 128) : nullptr;
-            rc = tickets ? osn_bn_forward_train_pc(x, n_out, o.cout, bn.gamma, bn.beta, bn.eps, res, o.relu, bn.momentum, mv, mv + o.cout,
-                                                   bn.running_mean, bn.running_var, y, y2, ld2, r->ws, size_t(r->ws_bytes), tickets, sstream)
-                         : osn_bn_forward_train2(x, n_out, o.cout, bn.gamma, bn.beta, bn.eps, res, o.relu, bn.momentum, mv, mv + o.cout,
-                                                 bn.running_mean, bn.running_var, y, y2, ld2, r->ws, size_t(r->ws_bytes), sstream);
+            rc = osn_bn_forward_train2(x, n_out, o.cout, bn.gamma, bn.beta, bn.eps, res, o.relu, bn.momentum, mv, mv + o.cout,
+                                       bn.running_mean, bn.running_var, y, y2, ld2, r->ws, size_t(r->ws_bytes), sstream);
         } else {
             OSN_REQUIRE(bn.running_mean && bn.running_var, OSN_E_ARG, "osn_net_forward: op %d: evaluation-mode batch norm without running statistics", i);
             rc = osn_bn_apply2(x, bn.running_mean, bn.running_var, bn.gamma, bn.beta, bn.eps, res, o.relu, y, y2, ld2, n_out, o.cout, sstream);
@@ -512,11 +508,7 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
             OSN_REQUIRE(bn.ggamma && bn.gbeta, OSN_E_ARG, "osn_net_backward: op %d: null batch-norm gradient pointers", i);
             // bn -> relu without a residual: the mask is recomputed from x, y is not read (one tensor less per backward kernel)
             const bool from_x = o.relu && o.res < 0 && bn.beta;
-            int32_t* tickets = run->tl_counters ? run->tl_counters + 128 : nullptr;
-            rc = tickets ? osn_bn_backward_pc(x, from_x ? nullptr : y, gsrc, gld, ng, mean, var, bn.gamma, from_x ? bn.beta : nullptr, bn.eps,
-                                        o.relu, run->training, gxw, gres, bn.ggamma, bn.gbeta, n_out, o.cout, r->ws, size_t(r->ws_bytes),
-                                        tickets, sstream)
-                         : osn_bn_backward_multi2(x, from_x ? nullptr : y, gsrc, gld, ng, mean, var, bn.gamma, from_x ? bn.beta : nullptr, bn.eps,
+            rc = osn_bn_backward_multi2(x, from_x ? nullptr : y, gsrc, gld, ng, mean, var, bn.gamma, from_x ? bn.beta : nullptr, bn.eps,
                                         o.relu, run->training, gxw, gres, bn.ggamma, bn.gbeta, n_out, o.cout, r->ws, size_t(r->ws_bytes),
                                         sstream);
             if (rc) return rc;

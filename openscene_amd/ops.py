@@ -641,16 +641,14 @@ def weight_image(weight, flip=False, for_dgrad=False, layout=PREP_X6):
 
 
 _tl_counters = {}
-BN_TICKETS = True        # training-mode batch norms through osn_bn_*_pc (tests compare both ways)
 
 
 def tl_counters(dev):
-    """The OSN_NET_COUNTERS (256) persistent counters of (device, current stream): [0, 128) the tile-list kernel's, [128, 256) the
-    network executor's batch-norm tickets (main / side stream).  Zero once; every kernel leaves them zero."""
+    """The 128 persistent tile counters of (device, current stream): zero once, the tile-list kernel leaves them zero."""
     ck = (_idx(dev), _stream(dev))
     c = _tl_counters.get(ck)
     if c is None:
-        c = _tl_counters[ck] = torch.zeros(256, dtype=torch.int32, device=dev)
+        c = _tl_counters[ck] = torch.zeros(128, dtype=torch.int32, device=dev)
     return c
 
 
@@ -679,7 +677,7 @@ def spconv_fwd_tl(feats, wp, tl, n_out, K, cout, bn_partial=None):
     ck = (_idx(dev), st)
     counters = _tl_counters.get(ck)
     if counters is None:                # 128 tile counters per (device, stream), zero once: the kernel leaves them zero
-        counters = _tl_counters[ck] = torch.zeros(256, dtype=torch.int32, device=dev)
+        counters = _tl_counters[ck] = torch.zeros(128, dtype=torch.int32, device=dev)
     with _Dev(dev):
         try:
             check(lib.osn_spconv_fwd_tl_pc(_p(feats), feats.shape[0], _p(wp), _p(buf), _p(rows), _p(out), _p(bn_partial), n_out,
@@ -995,14 +993,9 @@ def bn_forward_train(x, gamma, beta, eps, residual, relu, running_mean, running_
     y = torch.empty_like(x)
     ws = _ws(_cached("osn_bn_ws_bytes", n, c), dev)
     with _Dev(dev):
-        if BN_TICKETS:
-            check(lib.osn_bn_forward_train_pc(_p(x), n, c, _p(gamma), _p(beta), float(eps), _p(residual), int(bool(relu)),
-                                              float(momentum), _p(mv[0]), _p(mv[1]), _p(running_mean), _p(running_var), _p(y), None, 0,
-                                              _p(ws), ws.numel(), _p(tl_counters(dev)[128:192]), _stream(dev)), "osn_bn_forward_train_pc")
-        else:
-            check(lib.osn_bn_forward_train(_p(x), n, c, _p(gamma), _p(beta), float(eps), _p(residual), int(bool(relu)),
-                                           float(momentum), _p(mv[0]), _p(mv[1]), _p(running_mean), _p(running_var), _p(y),
-                                           _p(ws), ws.numel(), _stream(dev)), "osn_bn_forward_train")
+        check(lib.osn_bn_forward_train(_p(x), n, c, _p(gamma), _p(beta), float(eps), _p(residual), int(bool(relu)),
+                                       float(momentum), _p(mv[0]), _p(mv[1]), _p(running_mean), _p(running_var), _p(y),
+                                       _p(ws), ws.numel(), _stream(dev)), "osn_bn_forward_train")
     return y, mv[0], mv[1]
 
 
@@ -1035,14 +1028,9 @@ def bn_forward_train2(x, gamma, beta, eps, residual, relu, running_mean, running
     y = torch.empty_like(x)
     ws = _ws(_cached("osn_bn_ws_bytes", n, c), dev)
     with _Dev(dev):
-        if BN_TICKETS:          # statistics finished by the reduction's last workgroup: one launch fewer, the same bits
-            check(lib.osn_bn_forward_train_pc(_p(x), n, c, _p(gamma), _p(beta), float(eps), _p(residual), int(bool(relu)),
-                                              float(momentum), _p(mv[0]), _p(mv[1]), _p(running_mean), _p(running_var), _p(y), p2, ld2,
-                                              _p(ws), ws.numel(), _p(tl_counters(dev)[128:192]), _stream(dev)), "osn_bn_forward_train_pc")
-        else:
-            check(lib.osn_bn_forward_train2(_p(x), n, c, _p(gamma), _p(beta), float(eps), _p(residual), int(bool(relu)),
-                                            float(momentum), _p(mv[0]), _p(mv[1]), _p(running_mean), _p(running_var), _p(y), p2, ld2,
-                                            _p(ws), ws.numel(), _stream(dev)), "osn_bn_forward_train2")
+        check(lib.osn_bn_forward_train2(_p(x), n, c, _p(gamma), _p(beta), float(eps), _p(residual), int(bool(relu)),
+                                        float(momentum), _p(mv[0]), _p(mv[1]), _p(running_mean), _p(running_var), _p(y), p2, ld2,
+                                        _p(ws), ws.numel(), _stream(dev)), "osn_bn_forward_train2")
     return y, mv[0], mv[1]
 
 
@@ -1063,16 +1051,10 @@ def bn_backward_multi(x, y, gys, mean, var, gamma, eps, relu, training, want_gre
     gbeta = torch.empty(c, dtype=torch.float32, device=dev)
     ws = _ws(_cached("osn_bn_ws_bytes", n, c), dev)
     with _Dev(dev):
-        if BN_TICKETS:
-            check(lib.osn_bn_backward_pc(_p(x), _p(y), ptrs, lds, len(views), _p(mean), _p(var), _p(gamma),
+        check(lib.osn_bn_backward_multi2(_p(x), _p(y), ptrs, lds, len(views), _p(mean), _p(var), _p(gamma),
                                          _p(beta) if (relu and y is None) else None, float(eps),
                                          int(bool(relu)), int(bool(training)), _p(gx), _p(gres), _p(ggamma), _p(gbeta), n, c,
-                                         _p(ws), ws.numel(), _p(tl_counters(dev)[128:192]), _stream(dev)), "osn_bn_backward_pc")
-        else:
-            check(lib.osn_bn_backward_multi2(_p(x), _p(y), ptrs, lds, len(views), _p(mean), _p(var), _p(gamma),
-                                             _p(beta) if (relu and y is None) else None, float(eps),
-                                             int(bool(relu)), int(bool(training)), _p(gx), _p(gres), _p(ggamma), _p(gbeta), n, c,
-                                             _p(ws), ws.numel(), _stream(dev)), "osn_bn_backward_multi2")
+                                         _p(ws), ws.numel(), _stream(dev)), "osn_bn_backward_multi2")
     return gx, gres, ggamma, gbeta
 
 

@@ -549,30 +549,3 @@ def test_voxelizer_full_size_properties():
     assert np.array_equal(grid[inds][inv], grid)                      # every point maps to its voxel
     first = np.full(inds.shape[0], xyz.shape[0]); np.minimum.at(first, inv, np.arange(xyz.shape[0]))
     assert np.array_equal(first, inds)                                # first occurrence
-
-
-@pytest.mark.parametrize("n,c", [(5000, 32), (47618, 64), (100999, 96), (20000, 768), (4097, 256)])
-def test_bn_ticket_calls_are_bitwise_the_three_launch_calls(n, c, monkeypatch):
-    """Round 5: osn_bn_forward_train_pc / osn_bn_backward_pc finish the column sums in the reduction's last workgroup (ticket
-    counters) instead of a separate finalize launch -- same summation order, so every output is bit for bit the older call's,
-    twice in a row (the counters return to zero)."""
-    from openscene_amd import ops
-    d = dev()
-    g = torch.Generator().manual_seed(n + c)
-    x = torch.randn(n, c, generator=g).to(d) * 2 + 0.5
-    res = torch.randn(n, c, generator=g).to(d)
-    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(d), torch.randn(c, generator=g).to(d)
-    gy = [torch.randn(n, c, generator=g).to(d) for _ in range(2)]
-
-    def run(tickets):
-        monkeypatch.setattr(ops, "BN_TICKETS", tickets)
-        rm, rv = torch.zeros(c, device=d), torch.ones(c, device=d)
-        y, mean, var = ops.bn_forward_train(x, gamma, beta, 1e-5, res, True, rm, rv, 0.1)
-        back = ops.bn_backward_multi(x, y, gy, mean, var, gamma, 1e-5, True, True, True)
-        y0, mean0, var0 = ops.bn_forward_train(x, gamma, beta, 1e-5, None, True, rm, rv, 0.1)
-        back0 = ops.bn_backward(x, None, gy[0], mean0, var0, gamma, 1e-5, True, True, False, beta=beta)
-        return [y, mean, var, rm, rv, y0, mean0, var0] + [t for t in back + back0 if t is not None]
-    a, b, a2 = run(False), run(True), run(True)
-    for i, (p, q, r) in enumerate(zip(a, b, a2)):
-        assert torch.equal(p, q) and torch.equal(q, r), i
-    assert int(ops.tl_counters(d).abs().sum()) == 0
