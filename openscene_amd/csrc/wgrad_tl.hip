@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void pair_plan_kernel(const int32_t* __restric
 // profiles/r05_s1_knobs_ab.txt): both operands' rows come through buffer resources -- 32-bit offset
 // row * (4 c) + 4 (block's first channel + quad) from one v_mad_u32_u24 -- instead of a 64-bit multiply-add and two 64-bit adds per
 // quad; needs < 2^24 rows and < 2 GB per operand (the launch checks).  A padded pair reads row 0 (the split zeroes its quad as before).
-template <int MB, int NB, bool BUFG = false, int DEPTH = 1>
+template <int MB, int NB, bool BUFG = false>
 __global__ __launch_bounds__(256, 2) void wgrad_tl_kernel(const float* __restrict__ rows_a, const float* __restrict__ rows_g,
                                                           const int32_t* __restrict__ idx_a, const int32_t* __restrict__ idx_g,
                                                           const int32_t* __restrict__ poff, const int4* __restrict__ items,
@@ -241,120 +241,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tl_kernel(const float* __restric
         tl_split4(ok ? v : make_float4(0.f, 0.f, 0.f, 0.f), h1, h2, h3);
     };
 
-    if constexpr (DEPTH >= 2) {
-        // ---- DEPTH gather sets in flight (round 5 experiment): the rows of step s + DEPTH are requested while step s multiplies.
-        // With one set the gathers of step s + 1 have only step s's MFMA phase (~0.4 us) to arrive in, and random 384-byte rows
-        // take 1 - 3 us under load: every step ends in an exposed memory wait.  Everything in the loop is unconditional (clamped
-        // indices, zeroed by `ok`) so that the loop body is ONE basic block and the wait counts stay exact; the trip count is
-        // rounded up to a multiple of DEPTH, the surplus steps multiply zeros (acc + 0 = acc: same bits).
-        static_assert(BUFG, "the deep gather pipeline is built on the buffer-resource loads");
-        __shared__ int idxd[DEPTH][2][32];
-        float4 ra_[DEPTH][MB], rg_[DEPTH][NB];
-        bool oka_[DEPTH][MB], okg_[DEPTH][NB];
-        // threads 0 .. 31 of every wave: A index of pair p + lane, 32 .. 63: G index; -1 past the item.  Branch-free (every thread
-        // loads, from a clamped slot): a load under a branch ends in s_waitcnt vmcnt(0) at the join, which would also drain the
-        // row gathers issued just before it.  (Pair arrays only: the host keeps DEPTH = 1 for the identity map.)
-        const int32_t* const idx_mine = ((tid & 32) ? idx_g : idx_a) + base;
-        auto idx_of = [&](int p) -> int {
-            const int q = p + (tid & 31);
-            const int v = idx_mine[min(q, p1 - 1)];
-            return q < p1 ? v : -1;
-        };
-        auto fetch_d = [&](int slot, float4 (&pa_)[MB], float4 (&pg_)[NB], bool (&ok_a_)[MB], bool (&ok_g_)[NB]) {
-#pragma unroll
-            for (int j = 0; j < MB; ++j) {
-                const int r = idxd[slot][0][ar[j]];
-                ok_a_[j] = r >= 0 && a0 + ac[j] < ca;
-                pa_[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                        arsrc, __umul24(unsigned(max(r, 0)), ca4) + 4u * unsigned(a0 + ac[j]), 0, 0));
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int r = idxd[slot][1][gr[j]];
-                ok_g_[j] = r >= 0 && g0 + gc[j] < cg;
-                pg_[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                        grsrc, __umul24(unsigned(max(r, 0)), cg4) + 4u * unsigned(g0 + gc[j]), 0, 0));
-            }
-        };
-        const int n_steps = (p1 - p0 + 31) >> 5;
-        const int n_round = (n_steps + DEPTH - 1) / DEPTH * DEPTH;
-#pragma unroll
-        for (int j = 0; j < DEPTH; ++j) {
-            const int v = idx_of(p0 + 32 * j);
-            if (tid < 64) idxd[j][tid >> 5][tid & 31] = v;
-        }
-        __syncthreads();
-        int ireg = idx_of(p0 + 32 * DEPTH);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < DEPTH; ++j) {
-            fetch_d(j, ra_[j], rg_[j], oka_[j], okg_[j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        for (int s0 = 0; s0 < n_round; s0 += DEPTH) {
-#pragma unroll
-            for (int j = 0; j < DEPTH; ++j) {
-                const int p = p0 + 32 * (s0 + j);
-                bf16x4 a1[MB], a2[MB], a3[MB], g1[NB], g2[NB], g3[NB];
-#pragma unroll
-                for (int q = 0; q < MB; ++q) tl_split4(oka_[j][q] ? ra_[j][q] : make_float4(0.f, 0.f, 0.f, 0.f), a1[q], a2[q], a3[q]);
-#pragma unroll
-                for (int q = 0; q < NB; ++q) tl_split4(okg_[j][q] ? rg_[j][q] : make_float4(0.f, 0.f, 0.f, 0.f), g1[q], g2[q], g3[q]);
-                __syncthreads();                                   // the previous step's fragments have been read
-#pragma unroll
-                for (int q = 0; q < MB; ++q) {
-                    *reinterpret_cast<bf16x4*>(&Ap[0][ar[q]][ac[q]]) = a1[q];
-                    *reinterpret_cast<bf16x4*>(&Ap[1][ar[q]][ac[q]]) = a2[q];
-                    *reinterpret_cast<bf16x4*>(&Ap[2][ar[q]][ac[q]]) = a3[q];
-                }
-#pragma unroll
-                for (int q = 0; q < NB; ++q) {
-                    *reinterpret_cast<bf16x4*>(&Gp[0][gr[q]][gc[q]]) = g1[q];
-                    *reinterpret_cast<bf16x4*>(&Gp[1][gr[q]][gc[q]]) = g2[q];
-                    *reinterpret_cast<bf16x4*>(&Gp[2][gr[q]][gc[q]]) = g3[q];
-                }
-                if (tid < 64) idxd[j][tid >> 5][tid & 31] = ireg;      // indices of step s + DEPTH (slot j is free: its rows are staged)
-                __syncthreads();
-                // (the index load FIRST: the memory counter retires in order, so waiting for a load means waiting for every older
-                // one -- issued after the gathers, the indices' wait would drain the gathers with it)
-                ireg = idx_of(p + 32 * (DEPTH + 1));
-                __builtin_amdgcn_sched_barrier(0);
-                fetch_d(j, ra_[j], rg_[j], oka_[j], okg_[j]);          // rows of step s + DEPTH: in flight for DEPTH steps
-                __builtin_amdgcn_sched_barrier(0);
-                const int li = lane & 15, lg = lane >> 4;
-                auto frag = [&](const __bf16* plane, int pitch, int c16) -> bf16x8 {
-                    const __bf16* q = plane + (8 * lg + (li >> 2)) * pitch + c16 + 4 * (li & 3);
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 4 * pitch));
-                    union { s16x4 h[2]; bf16x8 v; } u;
-                    u.h[0] = lo; u.h[1] = hi;
-                    return u.v;
-                };
-                bf16x8 fa[MB][3], fg[NB][3];
-#pragma unroll
-                for (int i = 0; i < MB; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) fa[i][pl] = frag(&Ap[pl][0][0], LDA, (wi * MB + i) * 16);
-#pragma unroll
-                for (int q = 0; q < NB; ++q)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) fg[q][pl] = frag(&Gp[pl][0][0], LDG, (wj * NB + q) * 16);
-#pragma unroll
-                for (int i = 0; i < MB; ++i)
-#pragma unroll
-                    for (int q = 0; q < NB; ++q) {
-                        f32x4 t = acc[i][q];
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][2], fg[q][0], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fg[q][1], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fg[q][2], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fg[q][0], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fg[q][1], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fg[q][0], t, 0, 0, 0);
-                        acc[i][q] = t;
-                    }
-            }
-        }
-    } else {
     // prologue: indices of step 0 -> LDS -> rows of step 0 in flight, indices of step 1 in registers
     int ireg = load_idx(p0);
     if (tid < 64) idxbuf[tid >> 5][tid & 31] = ireg;
@@ -433,8 +319,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tl_kernel(const float* __restric
                 acc[i][j] = t;
             }
     }
-
-    }   // (DEPTH == 1: the round-2 loop)
 
     // ---- partial[item][ca][cg]: C row = 4 (lane >> 4) + r (input channel), col = lane & 15 (output channel)
     float* d = partial + int64_t(blockIdx.y) * ca * cg;
@@ -568,9 +452,6 @@ extern "C" size_t osn_spconv_wgrad_tl_ws_bytes(int K, int cin, int cout) {
     return size_t(PL_ITEMS) * size_t(cin) * size_t(cout) * 4;
 }
 
-static int g_wgrad_depth = 1;        // EXPERIMENT (tools/micro_tl.py MODE=wgrad): gather sets in flight
-extern "C" void osn_dbg_set_wgrad_depth(int d) { g_wgrad_depth = d; }
-
 template <int MB>
 static void launch_wg_tl_nb(int nb, dim3 grid, hipStream_t st, const float* ra, const float* rg, const int32_t* ia,
                             const int32_t* ig, const int32_t* poff, const int4* items, float* partial, int ca, int cg,
@@ -578,13 +459,7 @@ static void launch_wg_tl_nb(int nb, dim3 grid, hipStream_t st, const float* ra, 
     const bool bufg = a_bytes != 0u && g_bytes != 0u;
 #define OSN_WGTL(NB_)                                                                                              \
     do {                                                                                                           \
-        if (bufg && ia && g_wgrad_depth == 2)                                                                      \
-            hipLaunchKernelGGL((wgrad_tl_kernel<MB, NB_, true, 2>), grid, dim3(256), 0, st, ra, rg, ia, ig, poff, items, partial, ca, \
-                               cg, n_gb, irows, iquota, a_bytes, g_bytes);                                         \
-        else if (bufg && ia && g_wgrad_depth == 3)                                                                 \
-            hipLaunchKernelGGL((wgrad_tl_kernel<MB, NB_, true, 3>), grid, dim3(256), 0, st, ra, rg, ia, ig, poff, items, partial, ca, \
-                               cg, n_gb, irows, iquota, a_bytes, g_bytes);                                         \
-        else if (bufg)                                                                                             \
+        if (bufg)                                                                                                  \
             hipLaunchKernelGGL((wgrad_tl_kernel<MB, NB_, true>), grid, dim3(256), 0, st, ra, rg, ia, ig, poff, items, partial, ca, \
                                cg, n_gb, irows, iquota, a_bytes, g_bytes);                                         \
         else                                                                                                       \

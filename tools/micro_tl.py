@@ -125,15 +125,6 @@ def wgrad_main():
             a = ops.spconv_wgrad(x, g, None, 1)
         t_new = timed(lambda: ops.spconv_wgrad_tl(x, g, tl, K, swap=swap), reps)
         b = ops.spconv_wgrad_tl(x, g, tl, K, swap=swap)
-        from openscene_amd import _lib
-        lib = _lib.load()
-        if hasattr(lib, "osn_dbg_set_wgrad_depth"):            # round-5 experiment: gather sets in flight
-            for depth in (2, 3):
-                lib.osn_dbg_set_wgrad_depth(depth)
-                row["tl_depth%d_us" % depth] = timed(lambda: ops.spconv_wgrad_tl(x, g, tl, K, swap=swap), reps)
-                c = ops.spconv_wgrad_tl(x, g, tl, K, swap=swap)
-                row["depth%d_bitwise" % depth] = bool(torch.equal(b, c))
-            lib.osn_dbg_set_wgrad_depth(1)
         fl = 2.0 * pairs * cin * cout
         row.update({"pairs": pairs, "old_us": t_old, "tl_us": t_new, "tl_TF": fl / t_new / 1e6, "old_TF": fl / t_old / 1e6,
                     "max_rel_diff": (a - b).abs().max().item() / a.abs().max().item()})
