@@ -9,6 +9,7 @@
 // contraction: v_mfma_f32_32x32x16_f16, A = 32 point rows x 16 k, B = text rows
 // (text is [C, D] row-major = the K-contiguous B operand, no transpose needed).
 #include "common.h"
+#include <type_traits>
 
 namespace osn {
 
@@ -216,6 +217,242 @@ __global__ __launch_bounds__(256, WGS) void query_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Many labels (65 .. 160: Matterport-40/80/160, run/evaluate.py:64-75): the kernel above re-stages the text matrix for
+// every 128 points -- 246 KB from L2 per 393 KB of point rows -- and at 160 labels stops being bound by HBM (0.53 of the
+// roof, profiles/r04_*).  Here the text matrix is loaded ONCE per workgroup and stays in registers:
+//   * one persistent workgroup per CU, 8 waves.  Waves 0 .. NCW-1 ("consumers") each own 32 labels: the B fragments of
+//     their 32 text rows over the WHOLE feature dimension (D / 16 k-steps x 4 VGPRs = 192 at D = 768) live in registers
+//     for the kernel's life;
+//   * waves NCW .. 7 ("producers") stream the point rows: a tile = 32 points, lane q of the producers holds float4 q of
+//     each of the tile's rows (32 loads in flight per lane, re-issued for the next tile as soon as a register is
+//     converted: a tile's worth of bytes -- 98 KB per CU -- is always in flight), fp32 -> fp16 (the reference's
+//     `.half()`) into one of two LDS buffers;
+//   * one workgroup barrier per tile; a consumer's tile is D / 16 MFMAs (32x32x16 f16, A fragments from LDS two k-steps
+//     ahead: every consumer reads the same tile, LDS is the broadcast medium), the result rounded to fp16 ONCE and
+//     written to a [32 points][labels] LDS tile;
+//   * the argmax over a consumer's 32 labels runs on DPP row rotations over one unsigned key per lane (monotone fp16 bits <<
+//     16 | complemented label: the lower label wins a tie, torch.max) -- no LDS crossbar (the first version reduced the MFMA
+//     accumulator layout with 160 ds_bpermute per tile and wave: half the kernel's time, profiles/r05_s9_query_wide_ablation.txt);
+//     one tile later a producer wave takes the maximum of the NCW keys of every point and writes label / best score, and --
+//     when the score matrix is wanted -- all producer lanes copy the tile's scores out in 16-byte pieces (320-byte rows).
+// Traffic per point: its row once from HBM, nothing else.  Same scores as query_kernel (fp32 accumulation over the
+// feature dimension in ascending order, one fp16 rounding).
+constexpr int QW_TP = 32;        // points per tile
+
+template <int D, int NCW>
+__global__ __launch_bounds__(512, 1) void query_wide_kernel(const float* __restrict__ X0, const int64_t* __restrict__ g0,
+                                                            const float* __restrict__ X1, const int64_t* __restrict__ g1,
+                                                            const uint8_t* __restrict__ sel, const float* __restrict__ rowdiv,
+                                                            const _Float16* __restrict__ T, _Float16* __restrict__ scores,
+                                                            int64_t* __restrict__ argmax, float* __restrict__ rowmax,
+                                                            int64_t n, int c) {
+    constexpr int NP = 8 - NCW;                  // producer waves
+    constexpr int NPL = 64 * NP;                 // producer lanes
+    constexpr int D4 = D / 4;                    // float4 per point row
+    constexpr int PER = QW_TP;                   // float4 per producer lane and tile: lane q < D4 holds float4 q of every point of the tile
+    constexpr int KSTEPS = D / 16;
+    constexpr int LD = D + 8;                    // padded LDS row (halfs): 16-byte aligned rows, conflict-free 16-byte reads
+    constexpr int CP = 32 * NCW;                 // labels, padded to the consumers' 32
+    constexpr int LS = CP + 8;                   // padded row of the score tile (halfs)
+    static_assert(D % 32 == 0 && NCW >= 1 && NCW <= 6 && D4 <= NPL, "shape: one producer lane per float4 of a point row");
+    extern __shared__ __attribute__((aligned(16))) _Float16 xs[];              // [2][QW_TP][LD] point rows, then [2][QW_TP][LS] scores
+    _Float16* const sc = xs + size_t(2) * QW_TP * LD;
+    __shared__ uint32_t mkey[2][6][QW_TP];           // per consumer wave and point: (orderable fp16 score << 16) | (0xFFFF - label)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t n_tiles = (n + QW_TP - 1) / QW_TP;
+    const int64_t t_first = blockIdx.x, t_step = gridDim.x;
+    const int64_t my_tiles = t_first < n_tiles ? (n_tiles - t_first + t_step - 1) / t_step : 0;
+    auto tile_of = [&](int64_t i) { return t_first + i * t_step; };
+
+    if (wave < NCW) {
+        // ------------------------------------------------------------------------------------------ consumers
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 tf[KSTEPS];
+        {
+            const int row = 32 * wave + (lane & 31);
+            const bool ok = row < c;
+            const _Float16* src = T + int64_t(ok ? row : 0) * D + 8 * (lane >> 5);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                uint4 v = *reinterpret_cast<const uint4*>(src + 16 * s);
+                if (!ok) v = make_uint4(0, 0, 0, 0);
+                tf[s] = __builtin_bit_cast(h8, v);
+            }
+        }
+        for (int64_t i = 0; i < my_tiles; ++i) {
+            __syncthreads();                                             // tile i is staged in buffer i & 1
+            const _Float16* a = xs + size_t(i & 1) * QW_TP * LD + (lane & 31) * LD + 8 * (lane >> 5);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // the A fragments of the NEXT pair of k-steps are read from LDS while the MFMAs of the current pair run (two register
+            // sets; the scheduling fences keep the compiler from sinking the reads back to their first use)
+            constexpr int G = 2, NG = KSTEPS / G;
+            h8 aa[2][G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) aa[0][j] = *reinterpret_cast<const h8*>(a + 16 * j);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < NG) {
+#pragma unroll
+                    for (int j = 0; j < G; ++j) aa[(g + 1) & 1][j] = *reinterpret_cast<const h8*>(a + 16 * ((g + 1) * G + j));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < G; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aa[g & 1][j], tf[g * G + j], acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // fp16 rounding (the reference's half GEMM output).  Row argmax over this wave's 32 labels WITHOUT the LDS crossbar: a
+            // score and its label become one unsigned key -- the fp16 bits made monotone, the label complemented so that the
+            // LOWER label wins a tie (torch.max) -- and the maximum over the 32 lanes that hold a point's labels is four
+            // row-rotation DPP steps per 16-lane row plus one row broadcast.  (The first version shuffled (value, index) pairs
+            // through ds_bpermute: 160 per tile and wave, half the kernel's time.)
+            const int col = 32 * wave + (lane & 31);
+            _Float16* dst = sc + size_t(i & 1) * QW_TP * LS + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const _Float16 hv = (_Float16)acc[r];
+                if (scores) dst[lrow * LS] = hv;
+                const uint32_t hb = uint32_t(__builtin_bit_cast(uint16_t, hv));
+                const uint32_t ord = (hb & 0x8000u) ? (~hb & 0xFFFFu) : (hb | 0x8000u);
+                uint32_t key = col < c ? ((ord << 16) | (0xFFFFu - uint32_t(col))) : 0u;
+#define QW_ROR(K_) key = max(key, uint32_t(__builtin_amdgcn_update_dpp(0, int(key), 0x120 + (K_), 0xF, 0xF, false)));
+                QW_ROR(8) QW_ROR(4) QW_ROR(2) QW_ROR(1)
+#undef QW_ROR
+                // lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast15, rows 1 and 3 written): lanes 16 .. 31 and 48 .. 63 then hold the
+                // maximum of their 32-lane half
+                const uint32_t up = uint32_t(__builtin_amdgcn_update_dpp(int(key), int(key), 0x142, 0xA, 0xF, false));
+                key = max(key, up);
+                if ((lane & 31) == 31) mkey[i & 1][wave][lrow] = key;
+            }
+        }
+        __syncthreads();                                                 // (the producers' last merge)
+    } else {
+        // ------------------------------------------------------------------------------------------ producers
+        const int pl = tid - 64 * NCW;                                   // producer lane 0 .. NPL - 1
+        // RING rows in flight per lane.  Row r of the workgroup's row stream lives in v[r % RING]; the loop below is unrolled over
+        // three tiles so that a ring of 1.5 tiles (48) has static register indices -- measured: 48 is no faster than 32 (0.329 vs
+        // 0.320 ms for 500 k points x 160 labels; with the MFMAs and the epilogue removed both run 0.265 ms = 5.8 TB/s, the pace of
+        // the 3 KB row gather itself, profiles/r05_s9_query_wide_ablation.txt), so one tile it is.
+        constexpr int RING = 32;
+        float4 v[RING];
+        // lane j < 32 of every producer wave holds point j's source-row byte offset (relative to X0) and divisor, for the tile being
+        // staged (den only) and the two tiles after it (requested ahead: a row load never waits for an index load)
+        int64_t off_a = 0, off_b = 0;            // offsets of tiles t + 1, t + 2 while tile t is staged
+        float den_t = 1.f, den_a = 1.f, den_b = 1.f;
+        auto offsets = [&](int64_t i, int64_t& off, float& den) {
+            int64_t p = tile_of(i < my_tiles ? i : my_tiles - 1) * QW_TP + (lane & 31);
+            if (p >= n) p = n - 1;
+            if (sel && sel[p])
+                off = int64_t(reinterpret_cast<uintptr_t>(X1) - reinterpret_cast<uintptr_t>(X0)) + (g1 ? g1[p] : p) * int64_t(D) * 4;
+            else
+                off = (g0 ? g0[p] : p) * int64_t(D) * 4;
+            den = rowdiv ? rowdiv[p] : 1.f;
+        };
+        const int qb = (pl < D4 ? pl : 0) * 16;
+        // point k's row: a wave-uniform base (the offset travels from lane k through an SGPR) + this lane's 16 bytes; lanes past
+        // the row width re-read its first float4 (never staged)
+        auto load_row = [&](int k, int64_t off_l) -> float4 {
+            const unsigned lo = unsigned(uint64_t(off_l)), hi = unsigned(uint64_t(off_l) >> 32);
+            const uint64_t off = (uint64_t(unsigned(__builtin_amdgcn_readlane(int(hi), k))) << 32) | unsigned(__builtin_amdgcn_readlane(int(lo), k));
+            return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X0) + off + qb);
+        };
+        // tile t (phase = t % 3, static): its 32 rows -> fp16 -> buffer t & 1; every freed register immediately requests the row
+        // RING places further down the stream (of tile t + 1, or t + 2 with a longer ring): the queue of loads never drains
+        auto stage_and_issue = [&](int64_t t, auto phase_c) {
+            constexpr int PH = decltype(phase_c)::value;
+            _Float16* dst = xs + size_t(t & 1) * QW_TP * LD + 4 * pl;
+#pragma unroll
+            for (int k = 0; k < QW_TP; ++k) {
+                const int reg = (QW_TP * PH + k) % RING;
+                float4 x = v[reg];
+                if (rowdiv) {
+                    const float den = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, den_t), k));
+                    x.x /= den; x.y /= den; x.z /= den; x.w /= den;
+                }
+                half4 h;
+                h[0] = (_Float16)x.x; h[1] = (_Float16)x.y; h[2] = (_Float16)x.z; h[3] = (_Float16)x.w;
+                if (pl < D4) *reinterpret_cast<half4*>(dst + k * LD) = h;
+                v[reg] = (k + RING) / QW_TP == 1 ? load_row((k + RING) % QW_TP, off_a) : load_row((k + RING) % QW_TP, off_b);   // (past the end: the last tile's rows again)
+            }
+            den_t = den_a;
+            den_a = den_b;
+            off_a = off_b;
+            offsets(t + 3, off_b, den_b);
+        };
+        // the consumers' score tile of tile i -> the outputs
+        auto merge = [&](int64_t i) {
+            const _Float16* src = sc + size_t(i & 1) * QW_TP * LS;
+            const int64_t row0 = tile_of(i) * QW_TP;
+            if (scores) {                                                // rows of c fp16: 16-byte chunks where the row width allows it
+                if ((c & 7) == 0) {
+                    const int cpr = c >> 3;
+                    for (int e = pl; e < QW_TP * cpr; e += NPL) {
+                        const int pt = e / cpr, ch = e - pt * cpr;
+                        if (row0 + pt < n)
+                            *reinterpret_cast<uint4*>(scores + (row0 + pt) * c + 8 * ch) = *reinterpret_cast<const uint4*>(src + pt * LS + 8 * ch);
+                    }
+                } else {
+                    for (int e = pl; e < QW_TP * c; e += NPL) {
+                        const int pt = e / c, col = e - pt * c;
+                        if (row0 + pt < n) scores[(row0 + pt) * c + col] = src[pt * LS + col];
+                    }
+                }
+            }
+            if (pl < QW_TP) {                                            // the consumers' keys of point pl: the largest wins
+                uint32_t key = 0u;
+#pragma unroll
+                for (int w = 0; w < NCW; ++w) key = max(key, mkey[i & 1][w][pl]);
+                const int64_t p = row0 + pl;
+                if (p < n) {
+                    if (argmax) argmax[p] = key ? int64_t(0xFFFFu - (key & 0xFFFFu)) : 0;
+                    if (rowmax) {
+                        const uint32_t ord = key >> 16;
+                        const uint16_t hb = uint16_t((ord & 0x8000u) ? (ord & 0x7FFFu) : (~ord & 0xFFFFu));
+                        rowmax[p] = key ? float(__builtin_bit_cast(_Float16, hb)) : -INFINITY;
+                    }
+                }
+            }
+        };
+        typedef std::integral_constant<int, 0> P0;
+        typedef std::integral_constant<int, 1> P1;
+        typedef std::integral_constant<int, 2> P2;
+        if (my_tiles > 0) {
+            int64_t off0;
+            offsets(0, off0, den_t);
+            offsets(1, off_a, den_a);
+            offsets(2, off_b, den_b);
+#pragma unroll
+            for (int k = 0; k < QW_TP; ++k) v[k] = load_row(k, off0);
+            if constexpr (RING > QW_TP) {
+#pragma unroll
+                for (int k = 0; k < RING - QW_TP; ++k) v[(QW_TP + k) % RING] = load_row(k, off_a);
+            }
+            stage_and_issue(0, P0());
+        }
+        for (int64_t i = 0; i < my_tiles; i += 3) {                      // tile i + u is multiplied while tile i + u + 1 is staged
+            __syncthreads();
+            if (i + 1 < my_tiles) stage_and_issue(i + 1, P1());
+            if (i > 0) merge(i - 1);
+            if (i + 1 >= my_tiles) break;
+            __syncthreads();
+            if (i + 2 < my_tiles) stage_and_issue(i + 2, P2());
+            merge(i);
+            if (i + 2 >= my_tiles) break;
+            __syncthreads();
+            if (i + 3 < my_tiles) stage_and_issue(i + 3, P0());
+            merge(i + 1);
+        }
+        __syncthreads();
+        if (my_tiles > 0) merge(my_tiles - 1);
+    }
+}
+
 // den[p] = ||X[g[p]]||_2 + eps   (one wave per point)
 __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ X, const int64_t* __restrict__ g,
                                                        int64_t n, int d, float eps, float* __restrict__ den) {
@@ -268,6 +505,41 @@ __global__ __launch_bounds__(256) void rows_argmax_kernel(const float* __restric
 static int launch_query(hipStream_t st, const float* X0, const int64_t* g0, const float* X1, const int64_t* g1,
                         const uint8_t* sel, const float* rowdiv, const _Float16* T, _Float16* scores, int64_t* argmax,
                         float* rowmax, int64_t n, int d, int c) {
+    // 65 .. 160 labels at the CLIP widths: the text matrix stays in registers, one persistent workgroup per CU
+    if (c > 64 && c <= 160 && (d == 768 || d == 512) && n >= 4096) {
+        int cus = 256;
+        {
+            int dev_id = 0;
+            hipDeviceProp_t pr;
+            if (hipGetDevice(&dev_id) == hipSuccess && hipGetDeviceProperties(&pr, dev_id) == hipSuccess && pr.multiProcessorCount > 0)
+                cus = pr.multiProcessorCount;
+        }
+        const int64_t tiles = cdiv(n, QW_TP);
+        const unsigned gx = unsigned(tiles < cus ? tiles : cus);
+        const int ncw = int(cdiv(c, 32));
+        const size_t lds = size_t(2) * QW_TP * size_t(d + 8) * 2 + size_t(2) * QW_TP * size_t(32 * ncw + 8) * 2;
+#define OSN_QW(D_, W_)                                                                                                      \
+    do {                                                                                                                   \
+        auto kern = query_wide_kernel<D_, W_>;                                                                             \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) { \
+            set_error("osn_cosine_query: cannot reserve %zu bytes of LDS", lds);                                           \
+            return OSN_E_HIP;                                                                                              \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, c); \
+    } while (0)
+        if (d == 768) {
+            if (ncw == 3) OSN_QW(768, 3);
+            else if (ncw == 4) OSN_QW(768, 4);
+            else OSN_QW(768, 5);
+        } else {
+            if (ncw == 3) OSN_QW(512, 3);
+            else if (ncw == 4) OSN_QW(512, 4);
+            else OSN_QW(512, 5);
+        }
+#undef OSN_QW
+        OSN_LAUNCH_CHECK();
+        return OSN_OK;
+    }
     const dim3 grid(cdiv(n, Q_BM)), block(256);
     const int ct = int(cdiv(c, 32));
 #define OSN_Q(CT, NB, WG) hipLaunchKernelGGL((query_kernel<CT, NB, WG>), grid, block, 0, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, d, c)

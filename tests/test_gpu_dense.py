@@ -385,6 +385,53 @@ def test_query_scores_and_argmax(n_vox, n_pts, d, c):
     assert s2 is None and a2.shape[0] == n_vox
 
 
+@pytest.mark.parametrize("n_vox,n_pts,d,c", [(3000, 4097, 768, 160), (5000, 10001, 768, 65), (4000, 8200, 512, 96),
+                                             (6000, 9000, 768, 128), (2000, 4096, 512, 160)])
+def test_query_many_labels_persistent_kernel(n_vox, n_pts, d, c):
+    """Round 5: 65 .. 160 labels at the CLIP widths and >= 4096 points take query_wide_kernel (text matrix resident in the consumer
+    waves' registers, producer waves streaming point rows; argmax on DPP keys).  Same contract as the narrow kernel: scores within
+    2e-3 of the reference expression, label = the FIRST maximiser of our own rounded scores (torch.max) -- checked on a text matrix
+    with duplicated rows, where exact ties are guaranteed -- and equal to the reference's off ties; ragged last tile, labels-only."""
+    from openscene_amd import ops
+    x, t, gather = _query_inputs(n_vox, n_pts, d, c, n_vox + c)
+    t[c - 1] = t[3]                                       # two exact ties per point: the lower label has to win
+    t[c // 2 + 1] = t[c // 2]
+    ref_scores, ref_arg = oq.query(x, t, gather)
+    scores, arg = ops.cosine_query(x.to(dev()), t.to(dev()), gather.to(dev()))
+    scores, arg = scores.cpu(), arg.cpu()
+    assert (scores.float() - ref_scores.float()).abs().max().item() <= 2e-3
+    assert torch.equal(scores[:, c - 1], scores[:, 3]) and torch.equal(scores[:, c // 2 + 1], scores[:, c // 2])
+    first_max = (scores == scores.max(1, keepdim=True)[0]).float().argmax(1)
+    assert torch.equal(arg, first_max)
+    assert not bool((arg == c - 1).any()) and not bool((arg == c // 2 + 1).any())
+    top3 = ref_scores.float().topk(3, dim=1)[0]
+    clear = (top3[:, 0] - top3[:, 2]) > 4e-3              # (third best: a duplicated row makes top-1 == top-2 exactly, in both engines)
+    assert clear.float().mean().item() > 0.3
+    assert torch.equal(arg[clear], ref_arg[clear])
+    s2, a2 = ops.cosine_query(x.to(dev()), t.to(dev()), gather.to(dev()), want_scores=False)
+    assert s2 is None and torch.equal(a2.cpu(), arg)
+
+
+def test_query_ensemble_many_labels():
+    """The three-pass ensemble (row norms, per-source best score, per-point source selection: run/evaluate.py:302-324) through the
+    persistent kernel's rowdiv / rowmax / sel paths (160 labels, 6000 points)."""
+    from openscene_amd import ops
+    xd, t, gather = _query_inputs(3000, 6000, 768, 160, 11)
+    xf, _, _ = _query_inputs(3000, 6000, 768, 160, 12)
+    ref_scores, ref_arg, ref_sel = cpu_backend.query_ensemble(xd, xf, t, gather, gather)
+    scores, arg, sel = ops.query_ensemble(xd.to(dev()), xf.to(dev()), t.to(dev()), gather.to(dev()), gather.to(dev()))
+    fd, ff = xd[gather], xf[gather]
+    pd = oq.half_matmul((fd / (fd.norm(dim=-1, keepdim=True) + 1e-5)).half(), t).float().max(1)[0]
+    pf = oq.half_matmul((ff / (ff.norm(dim=-1, keepdim=True) + 1e-5)).half(), t).float().max(1)[0]
+    clear = (pd - pf).abs() > 4e-3
+    assert torch.equal(sel.cpu()[clear], ref_sel[clear])
+    same = sel.cpu() == ref_sel
+    assert (scores.cpu().float()[same] - ref_scores.float()[same]).abs().max().item() <= 2e-3
+    assert same.float().mean().item() > 0.95
+    first_max = (scores.cpu() == scores.cpu().max(1, keepdim=True)[0]).float().argmax(1)
+    assert torch.equal(arg.cpu(), first_max)
+
+
 def test_fused_head_query_matches_the_unfused_path():
     """labels from features96 @ (W_final @ text^T) equal the labels of the reference expression
     (model output [inds_reverse].half() @ text^T, run/evaluate.py:288-292) wherever the reference's top-2 margin exceeds
