@@ -250,7 +250,6 @@ __global__ __launch_bounds__(512, 1) void query_wide_kernel(const float* __restr
     constexpr int NP = 8 - NCW;                  // producer waves
     constexpr int NPL = 64 * NP;                 // producer lanes
     constexpr int D4 = D / 4;                    // float4 per point row
-    constexpr int PER = QW_TP;                   // float4 per producer lane and tile: lane q < D4 holds float4 q of every point of the tile
     constexpr int KSTEPS = D / 16;
     constexpr int LD = D + 8;                    // padded LDS row (halfs): 16-byte aligned rows, conflict-free 16-byte reads
     constexpr int CP = 32 * NCW;                 // labels, padded to the consumers' 32
