@@ -9,6 +9,7 @@
 // contraction: v_mfma_f32_32x32x16_f16, A = 32 point rows x 16 k, B = text rows
 // (text is [C, D] row-major = the K-contiguous B operand, no transpose needed).
 #include "common.h"
+#include <atomic>
 #include <type_traits>
 
 namespace osn {
@@ -506,12 +507,15 @@ static int launch_query(hipStream_t st, const float* X0, const int64_t* g0, cons
                         float* rowmax, int64_t n, int d, int c) {
     // 65 .. 160 labels at the CLIP widths: the text matrix stays in registers, one persistent workgroup per CU
     if (c > 64 && c <= 160 && (d == 768 || d == 512) && n >= 4096) {
-        int cus = 256;
-        {
-            int dev_id = 0;
-            hipDeviceProp_t pr;
-            if (hipGetDevice(&dev_id) == hipSuccess && hipGetDeviceProperties(&pr, dev_id) == hipSuccess && pr.multiProcessorCount > 0)
-                cus = pr.multiProcessorCount;
+        // compute units of the current device (one persistent workgroup each), queried once per device
+        static std::atomic<int> cu_cache[64];
+        int dev_id = 0;
+        OSN_HIP(hipGetDevice(&dev_id));
+        int cus = (dev_id >= 0 && dev_id < 64) ? cu_cache[dev_id].load(std::memory_order_relaxed) : 0;
+        if (cus <= 0) {
+            OSN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id));
+            if (cus <= 0) cus = 256;
+            if (dev_id >= 0 && dev_id < 64) cu_cache[dev_id].store(cus, std::memory_order_relaxed);
         }
         const int64_t tiles = cdiv(n, QW_TP);
         const unsigned gx = unsigned(tiles < cus ? tiles : cus);
