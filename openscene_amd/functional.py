@@ -18,11 +18,11 @@ from . import ops
 #            six bf16 MFMAs per product block, fp32 accumulate: fp32-level accuracy
 #   "fp32"   the same kernel on v_mfma_f32_32x32x2_f32 (exact fp32 products, 157 TF peak)
 CONV_MODE = os.environ.get("OSN_CONV_MODE", "tl")
-TL_FWD_MIN_ROWS = int(os.environ.get("OSN_TL_FWD_MIN_ROWS", "65536"))
+TL_FWD_MIN_ROWS = 65536
 # ... and from this many rows on when both channel counts are at least 96 (measured with the per-width channel chunks of
 # round 3, profiles/r03_s8: 48 k rows 96 -> 96 121 us against 134 us, 128 -> 96 143 / 164; 12.9 k rows 128 -> 128 63 / 78,
 # 192 -> 128 88 / 104; narrower layers -- 64 -> 64: 39 / 34, 32 -> 32: 67 / 34 -- stay on the output-stationary kernel)
-TL_MID_MIN_ROWS = int(os.environ.get("OSN_TL_MID_MIN_ROWS", "8192"))
+TL_MID_MIN_ROWS = 8192
 
 
 # Weight-stationary kernel (spconv_ws.hip) for the launches that write at most this many rows (measured, profiles/r03_s9:
@@ -30,7 +30,7 @@ TL_MID_MIN_ROWS = int(os.environ.get("OSN_TL_MID_MIN_ROWS", "8192"))
 # 8192 against 4096 / 16384: L235k-34C step 25.5 / 26.2 / 25.6 ms, 8-scene batch 49.5 / 49.8 / 49.7, S100k 9.90 / 9.89 / 10.01), and --
 # without a row limit -- for the launches that write the fine side of a 2^3 stride-2 map, where every row has exactly one
 # pair and the result rows go straight to the output (100 k rows 96 -> 96: 32 us against 70; 48 k rows 128 -> 96: 20 / 62)
-WS_MAX_ROWS = int(os.environ.get("OSN_WS_MAX_ROWS", "8192"))
+WS_MAX_ROWS = 8192
 
 
 def ws_kernel(K, c_src, c_dst, n_src, n_dst, fine_unique, dst_fine):
@@ -53,7 +53,7 @@ def tl_rows_ok(n_rows, c_a, c_b):
 # returns, so nothing outside sees the second stream.  OFF by default (0): measured on S100k (tools/ab_wall.sh, 2 rounds)
 # 14.78 / 14.18 ms with 40000 against 14.31 / 14.29 ms without -- the deep levels are bound by the host's launch rate,
 # not by the GPU, so there is nothing to overlap; 70000 and 200000 are slower (15.0 ms).  Results are bitwise identical.
-WGRAD_OVERLAP_MAX_ROWS = int(os.environ.get("OSN_WGRAD_OVERLAP_MAX_ROWS", "0"))
+WGRAD_OVERLAP_MAX_ROWS = 0
 
 
 class SparseConvFunction(Function):

@@ -256,10 +256,10 @@ class CoordinateManager:
         for t in self.tensors():
             t.record_stream(stream)
 
-    SORT_MIN_ROWS = int(__import__("os").environ.get("OSN_SORT_MIN_ROWS", "8192"))   # below this the sort does not pay
+    SORT_MIN_ROWS = 8192   # below this the sort does not pay
     # 2^3 (strided / transposed) maps are never tile-ordered: measured per-step kernel time 14.81 ms with, 14.42 ms without
     # (tools/ab_kernel_time.sh): their eight sorts cost more than the convs of those maps gain
-    SORT_MIN_ROWS_K8 = int(__import__("os").environ.get("OSN_SORT_MIN_ROWS_K8", str(10 ** 9)))
+    SORT_MIN_ROWS_K8 = 10 ** 9
 
     def kmap_tiles(self, in_stride, out_stride, ksize, dilation=1):
         """Tile-ordered variants of kmap(): ((order, table) for the forward conv or None,
