@@ -88,7 +88,7 @@ def main():
                 row[key + "_us"] = t
                 row[key + "_bitwise"] = bool(torch.equal(out, ref))
                 if (R, GD, npw) == (2, 1, 1) and cin == 96 and os.environ.get("ABL", "1") == "1":
-                    for dbg, nm in ((1, "no_gathers"), (2, "no_B_reloads"), (3, "no_loads"), (7, "no_loads_no_tile_rmw"), (11, "no_loads_no_mfma"), (15, "no_loads_no_rmw_no_mfma")):
+                    for dbg, nm in ((1, "no_gathers"), (2, "no_B_reloads"), (3, "no_loads"), (7, "no_loads_no_tile_rmw"), (11, "no_loads_no_mfma"), (15, "no_loads_no_rmw_no_mfma"), (31, "skeleton_no_frag_reads"), (47, "skeleton_no_staging"), (63, "skeleton_control_only"), (127, "control_no_epilogue_stores"), (191, "control_static_tiles"), (255, "control_static_no_epilogue"), (639, "control_no_steps_no_epilogue")):
                         def run_d():
                             lib.osn_dbg_spconv_fwd_tr(x.data_ptr(), n_in, wf.data_ptr(), tl.buf.data_ptr(), rows.data_ptr(), out.data_ptr(), n_out, K,
                                                       cin, cout, bm_eff, counters.data_ptr(), R | (GD << 4) | (npw << 8) | (dbg << 12), wgs, st)

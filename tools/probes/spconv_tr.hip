@@ -72,6 +72,7 @@ __global__ __launch_bounds__(64 * (NW + NP)) __attribute__((amdgpu_waves_per_eu(
     if (tid < 2 * R) full_f[tid >> 1][tid & 1] = 0;
     if (tid < 4 * R) done_f[tid >> 2][tid & 3] = 0;
     int gstep = 0;                                          // steps this workgroup has started (same count in every wave)
+    int tile_iter = 0;
 
     // producer: staging coordinates of its quads
     int q_row[NQ], q_col[NQ];
@@ -93,7 +94,11 @@ __global__ __launch_bounds__(64 * (NW + NP)) __attribute__((amdgpu_waves_per_eu(
     __syncthreads();
 
     for (;;) {
-        if (tid == 0) tile_s = atomicAdd(&counter[blockIdx.y], 1);
+        if (!(DBG & 128)) {
+            if (tid == 0) tile_s = atomicAdd(&counter[blockIdx.y], 1);
+        } else if (tid == 0) {
+            tile_s = (tile_iter++) * int(gridDim.x) + int(blockIdx.x);
+        }
         __syncthreads();
         const int draw = __builtin_amdgcn_readfirstlane(tile_s);
         if (draw >= n_tiles) break;
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(64 * (NW + NP)) __attribute__((amdgpu_waves_per_eu(
                         stab[t] = make_uint4(uint32_t(l0 + 32 * g), uint32_t(min(32, np - 32 * g)) | (g == 0 ? 0x100u : 0u) | (uint32_t(c * KS) << 16),
                                              uint32_t((kk * ns + c * KS) * ncb), 0u);
             }
-            const int T = nchunk * (E >> 5);
+            const int T = (DBG & 512) ? 0 : nchunk * (E >> 5);
             __syncthreads();
 
             if (producer) {
@@ -215,6 +220,7 @@ __global__ __launch_bounds__(64 * (NW + NP)) __attribute__((amdgpu_waves_per_eu(
                             }
 #pragma unroll
                             for (int j = 0; j < NQ; ++j) {
+                                if (DBG & 32) continue;
                                 *reinterpret_cast<bf16x4*>(&ring[slot][0][q_row[j]][q_col[j]]) = p1[j];
                                 *reinterpret_cast<bf16x4*>(&ring[slot][1][q_row[j]][q_col[j]]) = p2[j];
                                 *reinterpret_cast<bf16x4*>(&ring[slot][2][q_row[j]][q_col[j]]) = p3[j];
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(64 * (NW + NP)) __attribute__((amdgpu_waves_per_eu(
                         for (int h = 0; h < 2; ++h)
 #pragma unroll
                             for (int pl = 0; pl < 3; ++pl)
-                                af[h][pl] = *reinterpret_cast<const bf16x8*>(&ring[slot][pl][(half1 ? h : 0) * 16 + (lane & 15)][ks * 32 + akq]);
+                                af[h][pl] = (DBG & 16) ? bf16x8{} : *reinterpret_cast<const bf16x8*>(&ring[slot][pl][(half1 ? h : 0) * 16 + (lane & 15)][ks * 32 + akq]);
 #define TR_MFMA(H0, H1, AP, BP)                                                                             \
     _Pragma("unroll") for (int h = H0; h < H1; ++h) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)          \
         if (!(DBG & 8)) acc[h][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ks][nb][BP], af[h][AP], acc[h][nb], 0, 0, 0);
@@ -338,6 +344,7 @@ __global__ __launch_bounds__(64 * (NW + NP)) __attribute__((amdgpu_waves_per_eu(
         __syncthreads();
 
         constexpr int V = CW / 4;
+        if (!(DBG & 64))
         for (int idx = tid; idx < rows * V; idx += NT) {
             const int j = idx / V, c4 = idx - j * V;
             const int col = col0 + 4 * c4;
@@ -384,7 +391,7 @@ extern "C" int osn_dbg_spconv_fwd_tr(const float* in, int64_t n_in, const void* 
     const unsigned gx = unsigned(n_tiles < int64_t(256) * per_cu ? n_tiles : int64_t(256) * per_cu);
     const dim3 grid(gx, unsigned(gy));
     const unsigned in_bytes = unsigned(uint64_t(n_in) * cin * 4);
-    const int dbg = (variant >> 12) & 15;
+    const int dbg = (variant >> 12) & 1023;
     const int R = variant & 15, GD = (variant >> 4) & 15, NPv = ((variant >> 8) & 3) ? ((variant >> 8) & 3) : 1;
     int rc_attr = OSN_OK;
 #define OSN_TR(NW_, KS_, R_, GD_, NP_) OSN_TRD(NW_, KS_, R_, GD_, NP_, 0)
@@ -407,6 +414,14 @@ extern "C" int osn_dbg_spconv_fwd_tr(const float* in, int64_t n_in, const void* 
         else if (R == 2 && GD == 1 && NPv == 1 && dbg == 7) OSN_TRD(3, 3, 2, 1, 1, 7);
         else if (R == 2 && GD == 1 && NPv == 1 && dbg == 11) OSN_TRD(3, 3, 2, 1, 1, 11);
         else if (R == 2 && GD == 1 && NPv == 1 && dbg == 15) OSN_TRD(3, 3, 2, 1, 1, 15);
+        else if (R == 2 && GD == 1 && NPv == 1 && dbg == 31) OSN_TRD(3, 3, 2, 1, 1, 31);
+        else if (R == 2 && GD == 1 && NPv == 1 && dbg == 47) OSN_TRD(3, 3, 2, 1, 1, 47);
+        else if (R == 2 && GD == 1 && NPv == 1 && dbg == 63) OSN_TRD(3, 3, 2, 1, 1, 63);
+        else if (R == 2 && GD == 1 && NPv == 1 && dbg == 127) OSN_TRD(3, 3, 2, 1, 1, 127);
+        else if (R == 2 && GD == 1 && NPv == 1 && dbg == 191) OSN_TRD(3, 3, 2, 1, 1, 191);
+        else if (R == 2 && GD == 1 && NPv == 1 && dbg == 255) OSN_TRD(3, 3, 2, 1, 1, 255);
+        else if (R == 2 && GD == 1 && NPv == 1 && dbg == 128) OSN_TRD(3, 3, 2, 1, 1, 128);
+        else if (R == 2 && GD == 1 && NPv == 1 && dbg == 639) OSN_TRD(3, 3, 2, 1, 1, 639);
         else if (R == 2 && GD == 2 && NPv == 2) OSN_TR(3, 3, 2, 2, 2);
         else if (R == 2 && GD == 3 && NPv == 2) OSN_TR(3, 3, 2, 3, 2);
         else if (R == 2 && GD == 4 && NPv == 2) OSN_TR(3, 3, 2, 4, 2);
