@@ -20,8 +20,7 @@ def main():
         x = torch.randn(n_vox, d, generator=g).to(dev)
         idx = torch.randint(0, n_vox, (n_pts,), generator=g).to(dev)
         t = torch.nn.functional.normalize(torch.randn(c, d, generator=g), dim=1).half().to(dev)
-        for variant in os.environ.get("VARIANTS", "0").split(","):
-            os.environ["OSN_QUERY_VARIANT"] = variant
+        for variant in ("-",):
             for _ in range(2):
                 query_distill(x, t, idx, return_scores=scores)
             torch.cuda.synchronize()
