@@ -13,9 +13,11 @@ from openscene_amd.query import query_distill  # noqa: E402
 def main():
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(5)
-    for n_pts, d, c, scores in ((150000, 768, 20, False), (150000, 512, 20, False), (500000, 768, 160, True),
-                                (500000, 768, 160, False), (1000000, 768, 160, False), (500000, 768, 40, False),
-                                (500000, 768, 80, False)):
+    shapes = ((150000, 768, 20, False), (150000, 512, 20, False), (500000, 768, 160, True), (500000, 768, 160, False),
+              (1000000, 768, 160, False), (500000, 768, 40, False), (500000, 768, 80, False))
+    if os.environ.get("SHAPES") == "wide":                               # only the shapes query_wide_kernel takes
+        shapes = tuple(s for s in shapes if s[2] > 64)
+    for n_pts, d, c, scores in shapes:
         n_vox = n_pts // 2
         x = torch.randn(n_vox, d, generator=g).to(dev)
         idx = torch.randint(0, n_vox, (n_pts,), generator=g).to(dev)
