@@ -13,7 +13,7 @@ def main():
     for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             name = row.get("Kernel_Name", "")
-            if not any(t in name for t in ("spconv", "query", "bn_", "wgrad_tl", "stem_")):
+            if not any(t in name for t in ("spconv", "query", "bn_", "wgrad_tl", "wgrad_w1", "stem_")):
                 continue
             short = name.split("(")[0].replace("void ", "").replace("osn::", "")
             grid = row.get("Grid_Size", row.get("Grid_Size_X", ""))
