@@ -149,6 +149,28 @@ def main():
                     first = np.zeros(K + 1, dtype=np.int32)
                     first[1:] = np.cumsum([len(l) for l in lists])
                     plans[PLAN] = (it, first, np.concatenate(lists).astype(np.int32), {"items": int(first[K])})
+                elif PLAN == 4:
+                    # the product's (balanced) items, re-indexed by the output row of their middle pair: the 1/8 of the items lowest in
+                    # the map on XCD 0 (indices 0, 8, 16, ...), the next eighth on XCD 1, ...
+                    it0 = pl_cpu.view(np.int32)[512:512 + 2048].reshape(512, 4)
+                    valid = [t for t in range(512) if it0[t, 0] >= 0]
+                    po_h, pout_h = poff.cpu().numpy(), pout.cpu().numpy()
+                    centre = [int(pout_h[po_h[it0[t, 0]] + (it0[t, 1] + it0[t, 2]) // 2]) for t in valid]
+                    order = [valid[i] for i in np.argsort(centre, kind="stable")]
+                    per_x = (len(order) + 7) // 8
+                    it = np.full((512, 4), -1, dtype=np.int32)
+                    lists = [[] for _ in range(K)]
+                    for r, t in enumerate(order):
+                        idx = (r // per_x) + 8 * (r % per_x)
+                        it[idx] = (it0[t, 0], it0[t, 1], it0[t, 2], 1 << 16)
+                    for idx in range(512):
+                        if it[idx, 0] >= 0:
+                            lists[it[idx, 0]].append(idx)
+                    for k in range(K):
+                        lists[k].sort(key=lambda i: it[i, 1])
+                    first = np.zeros(K + 1, dtype=np.int32)
+                    first[1:] = np.cumsum([len(l) for l in lists])
+                    plans[PLAN] = (it, first, np.array([i for l in lists for i in l], dtype=np.int32), {"items": len(order)})
                 else:
                     plans[PLAN] = plan_items(pl_cpu, K, n_out, tl.bm, 1 if PLAN == 3 else 8, PLAN != 2)
                 row["plan%d" % PLAN] = plans[PLAN][3]
