@@ -373,9 +373,17 @@ __global__ __launch_bounds__(256) void wgrad_tl_reduce_batch_kernel(const WgJobs
         const int k = int(e / per_k4);
         const int64_t r = e - int64_t(k) * per_k4;
         const int t0 = range ? range[k].x : 0, t1 = range ? range[k].y : jb.ident_items;
-        // item order, as osn_spconv_wgrad_tl sums: s = ((0 + p[t0]) + p[t0 + 1]) + ...; two loads in flight per round
+        // item order, as osn_spconv_wgrad_tl sums: s = ((0 + p[t0]) + p[t0 + 1]) + ...; eight loads in flight per round (the loop is a
+        // chain of dependent adds behind ~2 us loads: with two in flight the launch ran at 0.9 TB/s)
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         int t = t0;
+        for (; t + 7 < t1; t += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = partial[int64_t(t + q) * per_k4 + r];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { s.x += v[q].x; s.y += v[q].y; s.z += v[q].z; s.w += v[q].w; }
+        }
         for (; t + 1 < t1; t += 2) {
             const float4 a = partial[int64_t(t) * per_k4 + r], b = partial[int64_t(t + 1) * per_k4 + r];
             s.x = (s.x + a.x) + b.x; s.y = (s.y + a.y) + b.y; s.z = (s.z + a.z) + b.z; s.w = (s.w + a.w) + b.w;
