@@ -189,10 +189,12 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
             }
         }
         // ---- weight gradient
-        // pair-array kernel on every 3^3 / 2^3 map, and -- identity map -- for the 1x1 shortcut convs up to 128 x 128
-        // channels (their 512 partial tiles are summed by the pass's ONE batched reduction; the 96 -> 768 head stays on the
-        // table kernel: 188 us against 215 us measured)
-        const bool wg_tl = (o.K > 1 || (o.cin <= 128 && o.cout <= 128)) && tl_eligible(o.K, o.cin, o.cout, n_in) &&
+        // pair-array kernel on every 3^3 / 2^3 map, and -- identity map -- for the 1x1 shortcut convs up to 256 x 256
+        // channels (their partial tiles are summed by the pass's batched reductions; the 96 -> 768 head stays on the
+        // table kernel: 188 us against 215 us measured).  Round 6: the limit was 128 x 128, which left the three wide shortcuts of
+        // MinkUNet18A (128 -> 256 at 730 rows, 256 -> 128 at 3.3 k, 192 -> 128 at 13 k) on the first-generation table kernel:
+        // 78 - 85 us each for microseconds of work (profiles/r05_s20_bench_detail.json, ops 20 / 26 / 32).
+        const bool wg_tl = (o.K > 1 || (o.cin <= 256 && o.cout <= 256)) && tl_eligible(o.K, o.cin, o.cout, n_in) &&
                            !stem_eligible(o.K, o.cin, o.cout);
         if (stem_eligible(o.K, o.cin, o.cout)) {
             L.wgrad_k[i] = OSN_NET_K_WGRAD_STEM;

@@ -143,7 +143,7 @@ class SparseConvFunction(Function):
             if CONV_MODE == "tl" and ops.tl_eligible(K, cin, cout, ctx.n_in):
                 if K > 1 and tl is not None:
                     return ops.spconv_wgrad_tl(feats, gout, tl, K, swap=swap).reshape(kernel.shape)
-                if K == 1 and cin <= 128 and cout <= 128:
+                if K == 1 and cin <= 256 and cout <= 256:
                     # 1x1 shortcut convs: the pair-array kernel on the identity map (the 96 -> 768 head stays on the table
                     # kernel: 188 us against 215 us measured); same rule as the network executor (csrc/net.hip)
                     return ops.spconv_wgrad_tl(feats, gout, None, 1).reshape(kernel.shape)

@@ -85,7 +85,7 @@ def test_planned_kernels_are_the_per_module_choice():
         want_f = want(o, o["cin"], o["cout"], n_in, n_out, bool(o["transposed"]))
         want_d = want(o, o["cout"], o["cin"], n_out, n_in, not o["transposed"])
         assert (kf, kd) == (want_f, want_d), (i, o, kf, kd)
-        assert kw == ("wgrad_tl" if (o["K"] > 1 or max(o["cin"], o["cout"]) <= 128) else "wgrad")
+        assert kw == ("wgrad_tl" if (o["K"] > 1 or max(o["cin"], o["cout"]) <= 256) else "wgrad")
     # level 0 (101 k rows): every 3^3 conv; levels 1 and 2 (48 k / 13 k rows): the decoder's >= 96-channel 3^3 convs
     assert sum(k[1] == "tl" for k in ks) == 12 and sum(k[2] == "tl" for k in ks) >= 10
     # the four transposed convs forward, the four strided convs backward: direct; the 3^3 convs of the two deepest levels

@@ -78,6 +78,18 @@ def plan_items(pl_cpu, K, n_out, bm, regions, strided, slots=512):
     return items, first, ids, {"max_steps": worst, "mean_steps": round(mean, 1), "items": int(first[K])}
 
 
+def morton_order(coords4, stride):
+    """argsort of the rows by (batch, 3-D Morton code of the voxel coordinates divided by the level's tensor stride)."""
+    c = coords4.long()
+    xyz = (c[:, 1:] - c[:, 1:].min(0)[0]) // int(stride)
+    code = torch.zeros_like(xyz[:, 0])
+    for b in range(16):
+        for a in range(3):
+            code |= ((xyz[:, a] >> b) & 1) << (3 * b + a)
+    code |= c[:, 0] << 48
+    return torch.argsort(code, stable=True)
+
+
 def timed(fn, reps):
     fn()
     torch.cuda.synchronize()
@@ -117,7 +129,14 @@ def main():
         x = torch.randn(n_in, cin, device=dev)
         g = torch.randn(n_out, cout, device=dev)
         tiles = cm.kmap_tiles(si, so, ks)[0]
-        tl = ops.tile_lists(tiles[1], out_rows=tiles[0]) if tiles is not None else ops.tile_lists(cm.kmap(si, so, ks)[0])
+        if os.environ.get("ORDER", "tile") == "morton":
+            # round 6: the table's rows in Z-order of the OUTPUT coordinates (the weight gradient sums over all pairs: its order is
+            # free) -- a window of consecutive rows is then a spatial block whose 27 offsets gather the same few rows
+            perm = morton_order(cm.coords(so), so)
+            tl = ops.tile_lists(cm.kmap(si, so, ks)[0][:, perm.long()].contiguous(), out_rows=perm.int().contiguous(),
+                                bm=int(os.environ.get("BM", "64")))
+        else:
+            tl = ops.tile_lists(tiles[1], out_rows=tiles[0]) if tiles is not None else ops.tile_lists(cm.kmap(si, so, ks)[0])
         pl = ops.pair_lists(tl)
         poff, pin, pout = ops.pair_arrays(tl)
         pairs = int(poff[K])
