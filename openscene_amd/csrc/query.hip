@@ -318,7 +318,12 @@ __global__ __launch_bounds__(512, 1) void query_wide_kernel(const float* __restr
                 const int lrow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const _Float16 hv = (_Float16)acc[r];
                 if (scores) dst[lrow * LS] = hv;
-                const uint32_t hb = uint32_t(__builtin_bit_cast(uint16_t, hv));
+                // torch.max compares VALUES: -0.0 == +0.0 (the lower label wins the tie), so -0 is made +0 before the bits are ordered.
+                // NaN: the bit order puts a positive NaN above every number and a negative one below -- torch.max would return the
+                // first NaN; scores here are cosine products of finite features, a NaN score means NaN input rows (documented in
+                // labels of such points are unspecified in both kernels).
+                uint32_t hb = uint32_t(__builtin_bit_cast(uint16_t, hv));
+                hb = hb == 0x8000u ? 0u : hb;
                 const uint32_t ord = (hb & 0x8000u) ? (~hb & 0xFFFFu) : (hb | 0x8000u);
                 uint32_t key = col < c ? ((ord << 16) | (0xFFFFu - uint32_t(col))) : 0u;
 #define QW_ROR(K_) key = max(key, uint32_t(__builtin_amdgcn_update_dpp(0, int(key), 0x120 + (K_), 0xF, 0xF, false)));
@@ -521,13 +526,22 @@ static int launch_query(hipStream_t st, const float* X0, const int64_t* g0, cons
         const unsigned gx = unsigned(tiles < cus ? tiles : cus);
         const int ncw = int(cdiv(c, 32));
         const size_t lds = size_t(2) * QW_TP * size_t(d + 8) * 2 + size_t(2) * QW_TP * size_t(32 * ncw + 8) * 2;
+        // the ~120 KB dynamic-LDS opt-in: once per (instance, device), like the tile-list kernel's; if the runtime refuses it (a part
+        // with less LDS per workgroup) the launch falls through to query_kernel below, which takes every shape
+        bool wide_ok = true;
+        const bool dev_slot_ok = dev_id >= 0 && dev_id < 64;
 #define OSN_QW(D_, W_)                                                                                                      \
     do {                                                                                                                   \
         auto kern = query_wide_kernel<D_, W_>;                                                                             \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) { \
-            set_error("osn_cosine_query: cannot reserve %zu bytes of LDS", lds);                                           \
-            return OSN_E_HIP;                                                                                              \
+        static std::atomic<signed char> attr_state[64];          /* 0 unknown, 1 set, -1 refused */                        \
+        signed char stt = dev_slot_ok ? attr_state[dev_id].load(std::memory_order_relaxed) : 0;                            \
+        if (stt == 0) {                                                                                                    \
+            stt = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                      int(size_t(2) * QW_TP * size_t(D_ + 8) * 2 + size_t(2) * QW_TP * size_t(32 * W_ + 8) * 2)) == hipSuccess ? 1 : -1; \
+            if (stt < 0) (void)hipGetLastError();                /* the refusal is handled here: clear the sticky error */ \
+            if (dev_slot_ok) attr_state[dev_id].store(stt, std::memory_order_relaxed);                                     \
         }                                                                                                                  \
+        if (stt < 0) { wide_ok = false; break; }                                                                           \
         hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, st, X0, g0, X1, g1, sel, rowdiv, T, scores, argmax, rowmax, n, c); \
     } while (0)
         if (d == 768) {
@@ -540,8 +554,10 @@ static int launch_query(hipStream_t st, const float* X0, const int64_t* g0, cons
             else OSN_QW(512, 5);
         }
 #undef OSN_QW
-        OSN_LAUNCH_CHECK();
-        return OSN_OK;
+        if (wide_ok) {
+            OSN_LAUNCH_CHECK();
+            return OSN_OK;
+        }
     }
     const dim3 grid(cdiv(n, Q_BM)), block(256);
     const int ct = int(cdiv(c, 32));

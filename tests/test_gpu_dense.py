@@ -412,6 +412,42 @@ def test_query_many_labels_persistent_kernel(n_vox, n_pts, d, c):
     assert s2 is None and torch.equal(a2.cpu(), arg)
 
 
+@pytest.mark.parametrize("n_pts,d,c", [(5000, 768, 160), (4200, 512, 96), (3000, 768, 20)])
+def test_query_signed_zero_scores_tie_like_torch_max(n_pts, d, c):
+    """ADVICE r5: scores that round to +0.0 and -0.0 in fp16 are EQUAL for torch.max (run/evaluate.py:292: the lowest label wins);
+    the persistent kernel's argmax orders raw fp16 bits and used to rank +0 above -0.  One tiny feature against text rows of
+    alternating sign makes every fp16 score a signed zero, label 0's negative: the label must be 0 everywhere.  A second set adds one
+    clearly positive label per point."""
+    from openscene_amd import ops
+    g = torch.Generator().manual_seed(5)
+    t = torch.zeros(c, d)
+    t[:, 0] = 0.01 * torch.tensor([-1.0 if j % 2 == 0 else 1.0 for j in range(c)])
+    t = t.half()
+    x = torch.zeros(n_pts, d)
+    x[:, 0] = 1e-6 * (1 + torch.rand(n_pts, generator=g))                    # products of 1e-8: below half the smallest fp16 subnormal
+    ref_scores, ref_arg = oq.query(x, t, None)
+    assert bool((ref_scores == 0).all()) and bool(torch.signbit(ref_scores.float()[:, 0]).all()) and int(ref_arg.max()) == 0
+    scores, arg = ops.cosine_query(x.to(dev()), t.to(dev()), None)
+    sc = scores.cpu().float()
+    assert bool((sc == 0).all()) and bool(torch.signbit(sc[:, 0]).all()) and not bool(torch.signbit(sc[:, 1]).any())
+    assert int(arg.abs().max()) == 0, "signed zeros must tie: label 0 everywhere"
+    _, arg2 = ops.cosine_query(x.to(dev()), t.to(dev()), None, want_scores=False)
+    assert int(arg2.abs().max()) == 0
+    # one label with a real (positive) score per point among the signed zeros: that label wins wherever it is
+    t2 = t.clone().float()
+    t2[:, 1:] = torch.nn.functional.normalize(torch.randn(c, d - 1, generator=g), dim=1)
+    t2 = t2.half()
+    want = torch.randint(0, c, (n_pts,), generator=g)
+    x2 = x.clone()
+    x2[:, 1:] = t2.float()[want][:, 1:]
+    ref_scores, ref_arg = oq.query(x2, t2, None)
+    _, arg3 = ops.cosine_query(x2.to(dev()), t2.to(dev()), None)
+    top2 = ref_scores.float().topk(2, dim=1)[0]
+    clear = (top2[:, 0] - top2[:, 1]) > 4e-3
+    assert clear.float().mean().item() > 0.9
+    assert torch.equal(arg3.cpu()[clear], ref_arg[clear])
+
+
 def test_query_ensemble_many_labels():
     """The three-pass ensemble (row norms, per-source best score, per-point source selection: run/evaluate.py:302-324) through the
     persistent kernel's rowdiv / rowmax / sel paths (160 labels, 6000 points)."""
