@@ -184,34 +184,6 @@ int osn_spconv_fwd_tl(const float* in, int64_t n_in, const void* Wp, const void*
 int osn_spconv_fwd_tl_pc(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
                          float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm,
                          void* ws, size_t ws_bytes, int32_t* counters, osn_stream_t stream);
-/* Batch-norm statistics from the convolution's own epilogue (round 6).  In the reference every MinkowskiConvolution is followed
- * by a MinkowskiBatchNorm (models/mink_unet.py:47-113, models/resnet_base.py:92-118), whose training-mode forward needs the
- * column sums of the conv OUTPUT and whose backward needs two column sums of the gradient that arrives at ITS output -- the
- * input gradient of the next convolution (+ the residual branch's).  Both are passes over [rows, channels] matrices that the
- * tile-list kernel has in LDS anyway when it stores its tile:
- *   forward : osn_spconv_fwd_tl[_pc] with bn_partial -> per tile (sum x, sum x^2); osn_bn_forward_train_partials finishes them.
- *   backward: osn_spconv_fwd_tl_bnbwd -- an input-gradient launch that is the LAST writer of the gradient arriving at a batch
- *             norm.  With g = its own tile rows + extra[0] + extra[1] (the order osn_bn_backward_multi adds its sources in), and
- *             m = the norm's ReLU mask (y > 0, or recomputed from x when y is null and beta is given), it STORES g * m and emits
- *             per tile (sum g m, sum g m xhat), xhat = (x - mean) / sqrt(var + eps).  osn_bn_backward_partials finishes them.
- * osn_spconv_fwd_tl_stats_ok: 1 when a launch of this shape has the epilogue (input channels in whole 32-channel chunks, the
- * feature matrix below 2 GB, no offset split of small tables); otherwise bn_partial falls back to a plain column loop and
- * osn_spconv_fwd_tl_bnbwd is refused.                                                                                          */
-typedef struct osn_bn_fuse {
-    const float* x;              /* [n_out, cout] the batch norm's input (the conv output it normalised)                      */
-    const float* y;              /* [n_out, cout] its output (mask y > 0), or null: mask from x (needs gamma, beta)              */
-    const float* extra[2];       /* further gradient sources, row-aligned with `out`                                         */
-    int64_t extra_ld[2];         /* their row strides in floats (a column window of a wider matrix)                          */
-    const float* mean; const float* var; const float* gamma; const float* beta;
-    float eps;
-    int32_t relu;                /* 0: no mask                                                                               */
-    int32_t n_extra;             /* 0 .. 2                                                                                   */
-    int32_t reserved;
-} osn_bn_fuse;
-int osn_spconv_fwd_tl_stats_ok(int64_t n_in, int64_t n_out, int K, int cin, int cout, int bm);
-int osn_spconv_fwd_tl_bnbwd(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
-                            float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm,
-                            void* ws, size_t ws_bytes, int32_t* counters, const osn_bn_fuse* fuse_host, osn_stream_t stream);
 
 /* ---- every weight image of a model in one launch ----------------------------------------------- *
  * [ME] keeps one `kernel` parameter per MinkowskiConvolution / MinkowskiConvolutionTranspose
@@ -397,18 +369,6 @@ int osn_bn_backward_multi2(const float* x, const float* y, const float* const* g
                            const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
                            int training, float* gx, float* gres, float* ggamma, float* gbeta, int64_t n, int c, void* ws,
                            size_t ws_bytes, osn_stream_t stream);
-
-/* Training-mode batch norm whose column sums were produced by the convolution that wrote x (see osn_spconv_fwd_tl_bnbwd):
- * partial = double [n_parts][2][c].  forward: mean / var (+ running buffers) from (sum x, sum x^2), then osn_bn_apply2.
- * backward: gm = the gradient at the norm's output already summed over its consumers and masked by its ReLU (row stride gm_ld),
- * partial = (sum gm, sum gm xhat): ggamma / gbeta and gx = gamma invstd (gm - mean_rows(gm) - xhat mean_rows(gm xhat)).        */
-int osn_bn_forward_train_partials(const float* x, const double* partial, int n_parts, int64_t n, int c, const float* gamma,
-                                  const float* beta, float eps, const float* residual, int relu, float momentum, float* mean,
-                                  float* var, float* running_mean, float* running_var, float* y, float* y2, int64_t ld2,
-                                  osn_stream_t stream);
-int osn_bn_backward_partials(const float* x, const float* gm, int64_t gm_ld, const double* partial, int n_parts, const float* mean,
-                             const float* var, const float* gamma, float eps, int training, float* gx, float* ggamma,
-                             float* gbeta, int64_t n, int c, osn_stream_t stream);
 
 /* ---- distillation loss on the supervised rows ------------------------------- *
  * Replaces run/distill.py:322-328 and its autograd chain:

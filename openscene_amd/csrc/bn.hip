@@ -135,27 +135,23 @@ __device__ inline void finalize_sums(const double* __restrict__ partial, int n_r
     __shared__ double red[2][FIN_PARTS][FIN_COLS];
     const int cl = threadIdx.x & (FIN_COLS - 1), part = threadIdx.x / FIN_COLS;
     col = blockIdx.x * FIN_COLS + cl;
-    // all 2 x FIN_ITERS loads of a round are issued before the first add (clamped addresses, masked afterwards): the kernel is
-    // one memory round trip long instead of FIN_ITERS dependent ones (5 us -> 3 us per launch, 96 launches a step).  Round 6: more
-    // than CR_MAX_BLOCKS partial blocks (the per-TILE partials of a convolution's statistics epilogue: 1 578 at 100 k rows) take
-    // further rounds; up to CR_MAX_BLOCKS the order of the additions is what it always was.
+    // all 2 x FIN_ITERS loads are issued before the first add (clamped addresses, masked afterwards): the kernel is
+    // one memory round trip long instead of FIN_ITERS dependent ones (5 us -> 3 us per launch, 96 launches a step)
+    double va[FIN_ITERS], vb[FIN_ITERS];
     const int cc = col < c ? col : 0;
+#pragma unroll
+    for (int i = 0; i < FIN_ITERS; ++i) {
+        const int blk = part + FIN_PARTS * i;
+        const int bc = blk < n_rb ? blk : 0;
+        va[i] = partial[(int64_t(bc) * 2 + 0) * c + cc];
+        vb[i] = partial[(int64_t(bc) * 2 + 1) * c + cc];
+    }
     double a = 0, b = 0;
-    for (int base = 0; base < n_rb; base += CR_MAX_BLOCKS) {
-        double va[FIN_ITERS], vb[FIN_ITERS];
 #pragma unroll
-        for (int i = 0; i < FIN_ITERS; ++i) {
-            const int blk = base + part + FIN_PARTS * i;
-            const int bc = blk < n_rb ? blk : 0;
-            va[i] = partial[(int64_t(bc) * 2 + 0) * c + cc];
-            vb[i] = partial[(int64_t(bc) * 2 + 1) * c + cc];
-        }
-#pragma unroll
-        for (int i = 0; i < FIN_ITERS; ++i) {
-            const bool on = col < c && base + part + FIN_PARTS * i < n_rb;
-            a += on ? va[i] : 0.0;
-            b += on ? vb[i] : 0.0;
-        }
+    for (int i = 0; i < FIN_ITERS; ++i) {
+        const bool on = col < c && part + FIN_PARTS * i < n_rb;
+        a += on ? va[i] : 0.0;
+        b += on ? vb[i] : 0.0;
     }
     red[0][part][cl] = a;
     red[1][part][cl] = b;
@@ -526,42 +522,6 @@ extern "C" int osn_bn_backward_multi2(const float* x, const float* y, const floa
     const int64_t total4 = n * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, y, src, mean, var, gamma, eps,
                        relu, training, gbeta, ggamma, 1.f / float(n), gx, gres, total4, c / 4, beta);
-    OSN_LAUNCH_CHECK();
-    return OSN_OK;
-}
-
-// ---- round 6: the column sums come from the PRODUCING convolution's epilogue (osn_spconv_fwd_tl with bn_partial,
-// osn_spconv_fwd_tl_bnbwd): no col_reduce pass here, only the ordered final sum + the apply pass.
-extern "C" int osn_bn_forward_train_partials(const float* x, const double* partial, int n_parts, int64_t n, int c, const float* gamma,
-                                             const float* beta, float eps, const float* residual, int relu, float momentum, float* mean,
-                                             float* var, float* running_mean, float* running_var, float* y, float* y2, int64_t ld2,
-                                             osn_stream_t stream) {
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    OSN_REQUIRE(n >= 1 && c >= 4 && (c & 3) == 0 && n_parts >= 1, OSN_E_ARG, "osn_bn_forward_train_partials: n=%lld c=%d parts=%d", (long long)n, c, n_parts);
-    OSN_REQUIRE(x && partial && mean && var, OSN_E_ARG, "osn_bn_forward_train_partials: null pointer");
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(c, FIN_COLS)), dim3(FIN_COLS * FIN_PARTS), 0, st, partial, n_parts, n, c, mean, var,
-                       running_mean, running_var, momentum);
-    OSN_LAUNCH_CHECK();
-    return osn_bn_apply2(x, mean, var, gamma, beta, eps, residual, relu, y, y2, ld2, n, c, stream);
-}
-
-// gm: the gradient at the batch norm's output, already summed over its consumers and masked by its ReLU; partial = per-tile
-// (sum gm, sum gm * xhat).  gx = the input gradient, ggamma / gbeta as osn_bn_backward.
-extern "C" int osn_bn_backward_partials(const float* x, const float* gm, int64_t gm_ld, const double* partial, int n_parts, const float* mean,
-                                        const float* var, const float* gamma, float eps, int training, float* gx, float* ggamma,
-                                        float* gbeta, int64_t n, int c, osn_stream_t stream) {
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    OSN_REQUIRE(n >= 1 && c >= 4 && (c & 3) == 0 && n_parts >= 1, OSN_E_ARG, "osn_bn_backward_partials: n=%lld c=%d parts=%d", (long long)n, c, n_parts);
-    OSN_REQUIRE(x && gm && partial && mean && var && gamma && gx && ggamma && gbeta, OSN_E_ARG, "osn_bn_backward_partials: null pointer");
-    OSN_REQUIRE(aligned16(x) && aligned16(gm) && aligned16(gx) && aligned16(mean) && aligned16(var) && aligned16(gamma) && aligned16(ggamma) &&
-                    aligned16(gbeta) && gm_ld >= c && (gm_ld & 3) == 0, OSN_E_ARG, "osn_bn_backward_partials: pointers must be 16-byte aligned");
-    GySrc src{};
-    src.n = 1;
-    for (int i = 0; i < BN_MAX_SRC; ++i) { src.p[i] = gm; src.ld[i] = gm_ld; }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, FIN_COLS)), dim3(FIN_COLS * FIN_PARTS), 0, st, partial, n_parts, c, gbeta, ggamma);
-    const int64_t total4 = n * (c / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, (const float*)nullptr, src, mean, var, gamma, eps,
-                       0, training, gbeta, ggamma, 1.f / float(n), gx, (float*)nullptr, total4, c / 4, (const float*)nullptr);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
 }

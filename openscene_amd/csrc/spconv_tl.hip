@@ -126,29 +126,14 @@ __global__ void weight_prep_tl_kernel(const float* __restrict__ W, int K, int ci
 // chunk's first channel in the scalar offset -- instead of a 64-bit multiply-add, two 64-bit adds and a channel clamp per quad (8 -> 2 VALU;
 // round 5's A/B: step 8.80 -> 8.73 / 8.76 ms, bit-identical results, profiles/r05_s1_knobs_ab.txt).  Ragged chunks and matrices of 2 GB
 // and more keep the 64-bit addresses.
-// STATS (round 6, full-chunk BUFG instances): the epilogue also emits, per tile, the two column sums the NEXT batch-norm kernel
-// needs, so that no separate pass over the rows has to produce them (see the epilogue).
-struct TlFuse {                         // all null / 0: forward statistics (sum x, sum x^2)
-    const float* x;                     // [n_out, cout] input of the batch norm whose BACKWARD statistics are wanted
-    const float* y;                     // its output (ReLU mask y > 0), or null
-    const float* extra[2];              // further gradient sources added to the tile's rows first (row stride extra_ld)
-    long long extra_ld[2];
-    const float *mean, *var, *gamma, *beta;      // beta != null with relu and y == null: mask recomputed from x
-    float eps;
-    int relu, n_extra;
-};
-
-__device__ inline float tl_bn_val(float x, float mu, float is, float ga, float be) { return __fmaf_rn((x - mu) * is, ga, be); }   // = bn.hip:bn_val
-
-template <int NW, int KS, bool RAGGED, bool PROF = false, int OCC = 2, bool BUFG = false, int STATS = 0>
+template <int NW, int KS, bool RAGGED, bool PROF = false, int OCC = 2, bool BUFG = false>
 __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __restrict__ in, const bf16x8* __restrict__ Wp,
                                                                const int32_t* __restrict__ cnt, const int2* __restrict__ lst,
                                                                const int32_t* __restrict__ out_rows, float* __restrict__ out,
                                                                double* __restrict__ bn_partial, int32_t* __restrict__ counter,
                                                                float* __restrict__ partial, int nz, int n_out, int K, int cin,
                                                                int cout, int bm, int n_tiles, int ns, int ncb,
-                                                               int self_reset, long long* __restrict__ prof, unsigned in_bytes,
-                                                               const TlFuse fuse) {
+                                                               int self_reset, long long* __restrict__ prof, unsigned in_bytes) {
     static_assert(!(BUFG && RAGGED), "the buffer gather is for full channel chunks");
     constexpr int NT = 256;
     constexpr int CW = 32 * NW;               // output columns of the workgroup
@@ -200,6 +185,8 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
     const __amdgpu_buffer_rsrc_t insrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, int(BUFG ? in_bytes : 0u), 0x00020000);
     const unsigned cin4 = unsigned(cin) * 4u;
 
+    bf16x8 B[KS][2][3];
+    float4 P0[NQ], P1[NQ];
     // RAGGED = false: every channel chunk is full (every MinkUNet width) -- no channel masks, no fragment selects in the loop
     constexpr bool ragged = RAGGED;
     // a fragment load is ONE instruction: scalar base of (offset, chunk, k-step, plane) + this lane's byte offset inside the
@@ -214,11 +201,6 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(Wp), 0, int(3u * plane_bytes), 0x00020000);   // raw buffer, 32-bit offsets
 
     for (;;) {
-        // weight fragments and the two gather register sets: declared PER TILE (round 6) -- declared outside the persistent loop they
-        // counted as live across the epilogue (a step may reuse the fragments its predecessor loaded: the compiler cannot see that
-        // a tile's first step never does), i.e. ~100 registers that the epilogue could not use
-        bf16x8 B[KS][2][3];
-        float4 P0[NQ], P1[NQ];
         // ---- draw the next tile (densest first: a tile-ordered table has the rows with most neighbours last)
         if (tid == 0) tile_s = atomicAdd(&counter[blockIdx.y], 1);
         __syncthreads();
@@ -525,115 +507,6 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
 
         // ---- epilogue: tile rows -> out[out_rows[row]] (16-byte stores), optional batch-norm partial sums
         constexpr int V = CW / 4;
-        if constexpr (STATS != 0) {
-            // Round 6: the statistics of the batch norm on the other side of these rows come out of THIS pass over them.
-            //   forward (fuse.x == null):  per tile sum x, sum x^2 of the rows just computed  -> the training-mode mean / variance
-            //     without col_reduce_kernel<0>'s pass over the conv output;
-            //   backward (fuse.x != null): this launch is an INPUT-GRADIENT convolution and the LAST writer of the gradient that
-            //     arrives at a batch norm's output.  g = tile row (+ the other sources, same order as osn_bn_backward_multi adds
-            //     them), masked by the norm's ReLU (recomputed from its input x with the forward expression, or read from y);
-            //     the masked sum is what is STORED (the batch norm's apply pass and the residual branch read it as it is), and
-            //     sum g, sum g * xhat per tile replace col_reduce_kernel<1>'s pass over x, y and every source.
-            // Thread = (row lane, column quad): fp64 sums down its rows, then over the row lanes through LDS in a fixed order;
-            // one partial per TILE (not per workgroup): the result does not depend on which workgroup drew the tile.
-            constexpr int STAGE_BYTES = 3 * 32 * LDA * 2;
-            constexpr int RL = (NT / V) < (STAGE_BYTES / (CW * 16)) ? (NT / V) : (STAGE_BYTES / (CW * 16));     // row lanes
-            static_assert(RL >= 1, "the staging buffer holds at least one row of partial sums");
-            // STATS == 1: forward sums only (fuse unused); 2: the backward form.  Rows per thread whose operands are in flight together:
-            constexpr int RB = STATS == 2 ? 2 : 4;
-            // everything below depends on an OPAQUE copy of the thread index: the per-column constants and addresses are invariant
-            // across the persistent tile loop, and hoisted out of it they would be live through every step of the kernel's hot loop
-            // (which sits exactly at the register count of three workgroups per CU)
-            int tq = tid;
-            asm volatile("" : "+v"(tq));
-            const int c4 = tq % V, rl = tq / V;
-            const int col = col0 + 4 * c4;
-            const bool con = rl < RL && col < cout;
-            constexpr bool bwd = STATS == 2;
-            const bool from_x = bwd && fuse.relu && !fuse.y;
-            double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-            float4 mu = make_float4(0, 0, 0, 0), is = mu, ga = mu, be = mu;
-            if (bwd && con) {
-                mu = *reinterpret_cast<const float4*>(fuse.mean + col);
-                const float4 vv = *reinterpret_cast<const float4*>(fuse.var + col);
-                is = make_float4(1.f / sqrtf(vv.x + fuse.eps), 1.f / sqrtf(vv.y + fuse.eps), 1.f / sqrtf(vv.z + fuse.eps), 1.f / sqrtf(vv.w + fuse.eps));
-                if (from_x) {
-                    ga = *reinterpret_cast<const float4*>(fuse.gamma + col);
-                    be = *reinterpret_cast<const float4*>(fuse.beta + col);
-                }
-            }
-            if (con && nz == 1) {
-                for (int j0 = rl; j0 < rows; j0 += RB * RL) {
-                    unsigned orow[RB];                                                // (32-bit element offsets: the launch checks the sizes)
-                    float4 v[RB], xv[RB], yv[RB], e0[RB], e1[RB];
-#pragma unroll
-                    for (int q = 0; q < RB; ++q) {
-                        const int j = j0 + q * RL < rows ? j0 + q * RL : j0;          // (clamped: the loads are unconditional)
-                        orow[q] = unsigned(park ? orow_s[j] : (out_rows ? out_rows[row0 + j] : row0 + j));
-                        v[q] = *reinterpret_cast<const float4*>(&otile[j * S + 4 * c4]);
-                        if (bwd) {
-                            xv[q] = *reinterpret_cast<const float4*>(fuse.x + (orow[q] * unsigned(cout) + unsigned(col)));
-                            if (fuse.relu && fuse.y) yv[q] = *reinterpret_cast<const float4*>(fuse.y + (orow[q] * unsigned(cout) + unsigned(col)));
-                            if (fuse.n_extra > 0) e0[q] = *reinterpret_cast<const float4*>(fuse.extra[0] + (orow[q] * unsigned(fuse.extra_ld[0]) + unsigned(col)));
-                            if (fuse.n_extra > 1) e1[q] = *reinterpret_cast<const float4*>(fuse.extra[1] + (orow[q] * unsigned(fuse.extra_ld[1]) + unsigned(col)));
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < RB; ++q) {
-                        if (j0 + q * RL < rows) {
-                            float4 g = v[q];
-                            if (bwd) {
-                                if (fuse.n_extra > 0) { g.x += e0[q].x; g.y += e0[q].y; g.z += e0[q].z; g.w += e0[q].w; }
-                                if (fuse.n_extra > 1) { g.x += e1[q].x; g.y += e1[q].y; g.z += e1[q].z; g.w += e1[q].w; }
-                                if (from_x) {
-                                    g.x = tl_bn_val(xv[q].x, mu.x, is.x, ga.x, be.x) > 0.f ? g.x : 0.f;
-                                    g.y = tl_bn_val(xv[q].y, mu.y, is.y, ga.y, be.y) > 0.f ? g.y : 0.f;
-                                    g.z = tl_bn_val(xv[q].z, mu.z, is.z, ga.z, be.z) > 0.f ? g.z : 0.f;
-                                    g.w = tl_bn_val(xv[q].w, mu.w, is.w, ga.w, be.w) > 0.f ? g.w : 0.f;
-                                } else if (fuse.relu) {
-                                    g.x = yv[q].x > 0.f ? g.x : 0.f; g.y = yv[q].y > 0.f ? g.y : 0.f;
-                                    g.z = yv[q].z > 0.f ? g.z : 0.f; g.w = yv[q].w > 0.f ? g.w : 0.f;
-                                }
-                                s1[0] += g.x; s1[1] += g.y; s1[2] += g.z; s1[3] += g.w;
-                                s2[0] += double(g.x) * ((xv[q].x - mu.x) * is.x); s2[1] += double(g.y) * ((xv[q].y - mu.y) * is.y);
-                                s2[2] += double(g.z) * ((xv[q].z - mu.z) * is.z); s2[3] += double(g.w) * ((xv[q].w - mu.w) * is.w);
-                            } else {
-                                s1[0] += g.x; s1[1] += g.y; s1[2] += g.z; s1[3] += g.w;
-                                s2[0] += double(g.x) * g.x; s2[1] += double(g.y) * g.y; s2[2] += double(g.z) * g.z; s2[3] += double(g.w) * g.w;
-                            }
-                            *reinterpret_cast<float4*>(out + (orow[q] * unsigned(cout) + unsigned(col))) = g;
-                        }
-                    }
-                }
-            } else if (nz > 1) {                           // partial tile of part z (no statistics on split launches: the host never asks)
-                for (int idx = tid; idx < rows * V; idx += NT) {
-                    const int j = idx / V, q4 = idx - j * V;
-                    if (col0 + 4 * q4 < cout)
-                        *reinterpret_cast<float4*>(partial + (int64_t(zpart) * n_out + row0 + j) * cout + col0 + 4 * q4) =
-                            *reinterpret_cast<const float4*>(&otile[j * S + 4 * q4]);
-                }
-            }
-            if (bn_partial && nz == 1) {
-                double* red = reinterpret_cast<double*>(&stage[0][0][0]);      // (every wave is past its last fragment read: barrier above)
-                if (con) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        red[(rl * CW + 4 * c4 + q) * 2 + 0] = s1[q];
-                        red[(rl * CW + 4 * c4 + q) * 2 + 1] = s2[q];
-                    }
-                }
-                __syncthreads();
-                for (int e = tid; e < 2 * CW; e += NT) {
-                    const int c = e >> 1, which = e & 1;
-                    if (col0 + c < cout) {
-                        double t = 0;
-#pragma unroll
-                        for (int r = 0; r < RL; ++r) t += red[(r * CW + c) * 2 + which];
-                        bn_partial[(int64_t(tile) * 2 + which) * cout + col0 + c] = t;
-                    }
-                }
-            }
-        } else {
         for (int idx = tid; idx < rows * V; idx += NT) {
             const int j = idx / V, c4 = idx - j * V;
             const int col = col0 + 4 * c4;
@@ -660,7 +533,6 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
                     bn_partial[(int64_t(tile) * 2 + 1) * cout + col0 + c] = s2;
                 }
             }
-        }
         }
         __syncthreads();                                   // the tile buffer is free for the next draw
         TL_TICK(7)                                         // 7: epilogue
@@ -788,20 +660,9 @@ __global__ void tl_reduce_parts_kernel(const float4* __restrict__ partial, int S
     }
 }
 
-// Can a launch of this shape carry the statistics epilogue (STATS instances: full channel chunks, buffer gathers, no tile split)?
-extern "C" int osn_spconv_fwd_tl_stats_ok(int64_t n_in, int64_t n_out, int K, int cin, int cout, int bm) {
-    if (n_out <= 0 || n_in <= 0 || K < 1 || bm < 1 || (cin & 3) || (cout & 3)) return 0;
-    const int ns = (cin + 31) / 32;
-    const int ks = ns <= 4 ? ns : (ns % 4 == 0 ? 4 : (ns % 3 == 0 ? 3 : 4));
-    const bool ragged = (cin & 31) != 0 || ns % ks != 0;
-    return !ragged && uint64_t(n_in) * uint64_t(cin) * 4u < (uint64_t(1) << 31) && uint64_t(n_out) * uint64_t(cout) * 4u < (uint64_t(1) << 31) &&
-           tl_split(n_out, K, cout, bm) == 1;
-}
-
 static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
                               float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm, void* ws,
-                              size_t ws_bytes, int32_t* counters, long long* prof, osn_stream_t stream,
-                              const TlFuse* fuse_in = nullptr) {
+                              size_t ws_bytes, int32_t* counters, long long* prof, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_spconv_fwd_tl: n_out out of range");
     OSN_REQUIRE(K >= 1 && K <= TL_KMAX && cin >= 4 && (cin & 3) == 0 && cout >= 4 && (cout & 3) == 0, OSN_E_ARG,
@@ -857,16 +718,6 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
     //  later relaxation of either limit cannot silently corrupt addresses)
     const bool bufg = !prof && !ragged_host && in_bytes64 < (uint64_t(1) << 31) && n_in < (int64_t(1) << 24) && int64_t(4) * cin < (int64_t(1) << 24);
     const unsigned in_bytes = bufg ? unsigned(in_bytes64) : 0u;
-    // statistics epilogue: whenever partial sums are asked for and the launch has a STATS instance (else the plain column loop)
-    const bool stats = bn_partial && bufg && nz == 1 && uint64_t(n_out) * uint64_t(cout) * 4u < (uint64_t(1) << 31);
-    TlFuse fuse{};
-    if (fuse_in) {
-        OSN_REQUIRE(stats, OSN_E_ARG, "osn_spconv_fwd_tl_bnbwd: this launch shape has no statistics epilogue (osn_spconv_fwd_tl_stats_ok)");
-        for (int i = 0; i < fuse_in->n_extra; ++i)
-            OSN_REQUIRE(uint64_t(n_out) * uint64_t(fuse_in->extra_ld[i]) * 4u < (uint64_t(1) << 31), OSN_E_RANGE,
-                        "osn_spconv_fwd_tl_bnbwd: gradient source %d of 2 GB or more", i);
-        fuse = *fuse_in;
-    }
     int rc_attr = OSN_OK;
     int dev_id = 0;
     OSN_HIP(hipGetDevice(&dev_id));
@@ -876,16 +727,10 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
         gx = unsigned(units < TL_SLOTS / 2 * 3 ? units : TL_SLOTS / 2 * 3);
         grid = dim3(gx, unsigned(gy));
     }
-#define OSN_TL4(NW_, KS_, RG_, PF_, OC_) OSN_TL6(NW_, KS_, RG_, PF_, OC_, false, 0)
+#define OSN_TL4(NW_, KS_, RG_, PF_, OC_) OSN_TL5(NW_, KS_, RG_, PF_, OC_, false)
 #define OSN_TL5(NW_, KS_, RG_, PF_, OC_, BG_)                                                                              \
     do {                                                                                                                   \
-        if (stats && fuse_in) OSN_TL6(NW_, KS_, RG_, PF_, OC_, BG_, 2);                                                    \
-        else if (stats) OSN_TL6(NW_, KS_, RG_, PF_, OC_, BG_, 1);                                                          \
-        else OSN_TL6(NW_, KS_, RG_, PF_, OC_, BG_, 0);                                                                     \
-    } while (0)
-#define OSN_TL6(NW_, KS_, RG_, PF_, OC_, BG_, ST_)                                                                         \
-    do {                                                                                                                   \
-        auto kern = spconv_tl_kernel<NW_, KS_, RG_, PF_, OC_, BG_, ST_>;                                                   \
+        auto kern = spconv_tl_kernel<NW_, KS_, RG_, PF_, OC_, BG_>;                                                        \
         /* dynamic LDS beyond the default limit needs the opt-in attribute: once per (instance, DEVICE), the largest tile any   \
            launch can ask for; relaxed atomics: a racing second thread (autograd's, the map prefetcher's) sets it again */       \
         static std::atomic<unsigned char> attr_set[TL_MAX_DEVICES];                                                        \
@@ -898,7 +743,7 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
             if (dev_slot_ok) attr_set[dev_slot].store(1, std::memory_order_relaxed);                                       \
         }                                                                                                                  \
         hipLaunchKernelGGL(kern, grid, dim3(256), tile_bytes, st, in, wp, cnt, lst, out_rows, out, bn_partial, counter, partial, nz, \
-                           int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof, in_bytes, fuse);         \
+                           int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof, in_bytes);               \
     } while (0)
 #define OSN_TL3(NW_, KS_, RG_, PF_) OSN_TL4(NW_, KS_, RG_, PF_, 2)
 #define OSN_TL2(NW_, KS_)                                                                                                  \
@@ -936,7 +781,6 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
 #undef OSN_TL3
 #undef OSN_TL4
 #undef OSN_TL5
-#undef OSN_TL6
     OSN_REQUIRE(rc_attr == OSN_OK, OSN_E_HIP, "osn_spconv_fwd_tl: cannot reserve %zu bytes of LDS for the output tile", tile_bytes);
     OSN_LAUNCH_CHECK();
     if (nz > 1) {
@@ -963,30 +807,6 @@ extern "C" int osn_spconv_fwd_tl_pc(const float* in, int64_t n_in, const void* W
     OSN_REQUIRE(counters, OSN_E_ARG, "osn_spconv_fwd_tl_pc: null counters (128 int32, zero before the first call)");
     return spconv_fwd_tl_impl(in, n_in, Wp, tl, out_rows, out, bn_partial, n_out, K, cin, cout, bm, ws, ws_bytes, counters, nullptr,
                               stream);
-}
-
-// Input-gradient convolution that is the LAST writer of the gradient arriving at a batch norm: masked gradient sum stored, per-tile
-// (sum g, sum g xhat) emitted (include/openscene_amd.h: osn_bn_fuse).
-extern "C" int osn_spconv_fwd_tl_bnbwd(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
-                                       float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm, void* ws,
-                                       size_t ws_bytes, int32_t* counters, const osn_bn_fuse* f, osn_stream_t stream) {
-    OSN_REQUIRE(counters && f && bn_partial, OSN_E_ARG, "osn_spconv_fwd_tl_bnbwd: null counters / fuse descriptor / partial sums");
-    OSN_REQUIRE(f->x && f->mean && f->var && f->n_extra >= 0 && f->n_extra <= 2 && (!f->relu || f->y || (f->gamma && f->beta)), OSN_E_ARG,
-                "osn_spconv_fwd_tl_bnbwd: incomplete fuse descriptor");
-    TlFuse t{};
-    t.x = f->x; t.y = f->relu ? f->y : nullptr;
-    for (int i = 0; i < 2; ++i) {
-        const bool on = i < f->n_extra;
-        OSN_REQUIRE(!on || (f->extra[i] && aligned16(f->extra[i]) && f->extra_ld[i] >= cout && (f->extra_ld[i] & 3) == 0), OSN_E_ARG,
-                    "osn_spconv_fwd_tl_bnbwd: gradient source %d needs a 16-byte aligned pointer and a row stride >= cout, %% 4 == 0", i);
-        t.extra[i] = on ? f->extra[i] : nullptr;
-        t.extra_ld[i] = on ? f->extra_ld[i] : 0;
-    }
-    OSN_REQUIRE(aligned16(f->x) && (!t.y || aligned16(t.y)) && aligned16(f->mean) && aligned16(f->var) && (!f->gamma || aligned16(f->gamma)) &&
-                    (!f->beta || aligned16(f->beta)), OSN_E_ARG, "osn_spconv_fwd_tl_bnbwd: pointers must be 16-byte aligned");
-    t.mean = f->mean; t.var = f->var; t.gamma = f->gamma; t.beta = f->beta;
-    t.eps = f->eps; t.relu = f->relu; t.n_extra = f->n_extra;
-    return spconv_fwd_tl_impl(in, n_in, Wp, tl, out_rows, out, bn_partial, n_out, K, cin, cout, bm, ws, ws_bytes, counters, nullptr, stream, &t);
 }
 
 // Tools only (not part of include/openscene_amd.h): the same launch with the phase timers of wave 0 of every

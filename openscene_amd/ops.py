@@ -948,81 +948,6 @@ def spconv_fwd_plan(n_out, K, cin, cout):
 
 
 # ------------------------------------------------------------------ batch norm
-class _BnFuse(ctypes.Structure):
-    """include/openscene_amd.h: osn_bn_fuse"""
-    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("extra", ctypes.c_void_p * 2), ("extra_ld", ctypes.c_int64 * 2),
-                ("mean", ctypes.c_void_p), ("var", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
-                ("eps", ctypes.c_float), ("relu", ctypes.c_int32), ("n_extra", ctypes.c_int32), ("reserved", ctypes.c_int32)]
-
-
-def tl_stats_ok(n_in, n_out, K, cin, cout, bm=None):
-    """Does a tile-list launch of this shape carry the batch-norm statistics epilogue?"""
-    bm = tile_rows(n_out) if bm is None else int(bm)
-    return bool(_cached("osn_spconv_fwd_tl_stats_ok", int(n_in), int(n_out), int(K), int(cin), int(cout), bm))
-
-
-def spconv_fwd_tl_bnbwd(gout, wp, tl, n_out, K, cout, x, mean, var, eps, relu, y=None, gamma=None, beta=None, extra=()):
-    """Input-gradient convolution (osn_spconv_fwd_tl with the input-gradient image) that is the LAST writer of the gradient arriving
-    at a batch norm (input x, statistics mean / var): -> (gm, partial) with gm = relu-masked (conv rows + extra sources) and partial
-    float64 [n_tiles, 2, cout] = per-tile (sum gm, sum gm * xhat).  Mask: y > 0, or recomputed from x (y None: gamma, beta)."""
-    dev = gout.device
-    lib = _prep(dev)
-    gout = _f32c(gout, "grad_output")
-    cin = gout.shape[1]
-    if tl.n_out != n_out or tl.K != K:
-        raise ValueError("tile lists are for a [%d, %d] table, conv wants [%d, %d]" % (tl.K, tl.n_out, K, n_out))
-    f = _BnFuse()
-    f.x, f.y = _p(_f32c(x, "x")), _p(y) if (relu and y is not None) else None
-    views = [_row_view(e, cout, "extra[%d]" % i) for i, e in enumerate(extra)]
-    for i, (ptr, ld) in enumerate(views):
-        f.extra[i], f.extra_ld[i] = ptr, ld
-    f.mean, f.var, f.gamma, f.beta = _p(mean), _p(var), _p(gamma), _p(beta)
-    f.eps, f.relu, f.n_extra = float(eps), int(bool(relu)), len(views)
-    out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
-    part = torch.empty((tl.n_tiles, 2, cout), dtype=torch.float64, device=dev)
-    ws = _ws(_cached("osn_spconv_fwd_tl_ws_bytes", n_out, K, cout, tl.bm), dev)
-    counters = tl_counters(dev)
-    with _Dev(dev):
-        try:
-            check(lib.osn_spconv_fwd_tl_bnbwd(_p(gout), gout.shape[0], _p(wp), _p(tl.buf), _p(tl.out_rows), _p(out), _p(part), n_out, K, cin,
-                                              cout, tl.bm, _p(ws), ws.numel(), _p(counters), ctypes.addressof(f), _stream(dev)),
-                  "osn_spconv_fwd_tl_bnbwd")
-        except Exception:
-            _tl_counters.pop((_idx(dev), _stream(dev)), None)
-            raise
-    return out, part
-
-
-def bn_forward_train_partials(x, partial, gamma, beta, eps, residual, relu, running_mean, running_var, momentum):
-    """bn_forward_train whose column sums come from the producing convolution's epilogue (partial float64 [n_parts, 2, c])."""
-    dev = x.device
-    lib = _prep(dev)
-    x = _f32c(x, "x")
-    n, c = x.shape
-    mv = torch.empty((2, c), dtype=torch.float32, device=dev)
-    y = torch.empty_like(x)
-    with _Dev(dev):
-        check(lib.osn_bn_forward_train_partials(_p(x), _p(partial), partial.shape[0], n, c, _p(gamma), _p(beta), float(eps), _p(residual),
-                                                int(bool(relu)), float(momentum), _p(mv[0]), _p(mv[1]), _p(running_mean), _p(running_var),
-                                                _p(y), None, 0, _stream(dev)), "osn_bn_forward_train_partials")
-    return y, mv[0], mv[1]
-
-
-def bn_backward_partials(x, gm, partial, mean, var, gamma, eps, training=True):
-    """(gx, ggamma, gbeta) from the masked gradient sum gm and its per-tile partial sums (spconv_fwd_tl_bnbwd)."""
-    dev = x.device
-    lib = _prep(dev)
-    n, c = x.shape
-    ptr, ld = _row_view(gm, c, "gm")
-    gx = torch.empty_like(x)
-    ggamma = torch.empty(c, dtype=torch.float32, device=dev)
-    gbeta = torch.empty(c, dtype=torch.float32, device=dev)
-    with _Dev(dev):
-        check(lib.osn_bn_backward_partials(_p(x), ptr, ld, _p(partial), partial.shape[0], _p(mean), _p(var), _p(gamma), float(eps),
-                                           int(bool(training)), _p(gx), _p(ggamma), _p(gbeta), n, c, _stream(dev)), "osn_bn_backward_partials")
-    return gx, ggamma, gbeta
-
-
 def bn_stats(x, running_mean=None, running_var=None, momentum=0.1):
     dev = x.device
     lib = _prep(dev)
