@@ -700,6 +700,9 @@ def main():
                     "its kernel maps are built inside the step (the round-3 default until the maps came from one C call on one "
                     "stream: 11.10 ms against 10.57 ms per step with the maps ahead as well, profiles/r03_s10)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of openscene_amd.optim.FlatAdam")
+    ap.add_argument("--full-head", action="store_true", help="compute the final 1x1 convolution on every voxel and hand the loss the "
+                    "[N, 768] output (round 5's call site); default since round 6: model(sinput, rows=sel) -- the head, the loss "
+                    "and the head's gradients on the supervised rows only (run/distill.py:321-322 discards the others)")
     ap.add_argument("--torch-loss", action="store_true", help="cosine loss through torch's own operators (index_select, "
                     "CosineSimilarity, mean and their autograd chain) instead of openscene_amd.losses.distill_loss")
     ap.add_argument("--no-prefetch-pyramid", action="store_true", help="build the coordinate pyramid of a batch inside its own step "
@@ -860,11 +863,15 @@ def main():
             sel = mask.nonzero(as_tuple=False).squeeze(1)
             sinput = SparseTensor(feats, next_coords())            # builds every map (ME does per forward)
         t_ = seg("take", t_)
-        out = net(sinput)
+        rows_head = not args.full_head and not (dist_on and args.ddp)
+        out = net(sinput, rows=sel) if rows_head else net(sinput)
         t_ = seg("forward", t_)
         # (1 - cos(out[mask], feat_3d)).mean(), run/distill.py:322-326: one fused forward and one fused backward launch
         # (openscene_amd.losses, csrc/loss.hip); --torch-loss keeps torch's own ~25-launch chain
-        loss = distill_loss(out, sel, feat_3d) if LOSS_HIP else (1 - cos(out.index_select(0, sel), feat_3d)).mean()
+        if rows_head:
+            loss = distill_loss(out, None, feat_3d) if LOSS_HIP else (1 - cos(out, feat_3d)).mean()
+        else:
+            loss = distill_loss(out, sel, feat_3d) if LOSS_HIP else (1 - cos(out.index_select(0, sel), feat_3d)).mean()
         optim.zero_grad(set_to_none=True)
         t_ = seg("loss", t_)
         loss.backward()
@@ -1394,6 +1401,8 @@ def main():
         "optimizer": ("torch.optim.Adam(fused=True)" if (args.torch_adam or args.ddp) else
                       "openscene_amd.optim.FlatAdam (torch.optim.Adam's update rule over one flat buffer, one launch)"),
         "loss_path": "torch operators" if args.torch_loss else "openscene_amd.losses.distill_loss (csrc/loss.hip)",
+        "head": ("final 1x1 convolution on every voxel, [N, D] output" if (args.full_head or (dist_on and args.ddp)) else
+                 "model(sinput, rows=sel): final 1x1 convolution, loss and head gradients on the supervised rows only"),
         "input_pipeline": ("coordinate pyramid, kernel maps and pair arrays of step i+1 built on a side stream during step i" if full_prefetch else
                            "coordinate pyramid (+ mask rows) of step i+1 queued on a side stream during step i; kernel maps inside the step"
                            if prefetch else "pyramid and maps inside the step"),

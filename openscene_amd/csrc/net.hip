@@ -471,7 +471,10 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
         int64_t gld[4];
         int ng = 0;
         if (o.dst < 0) {
-            OSN_REQUIRE(run->goutput, OSN_E_ARG, "osn_net_backward: null output gradient");
+            // (the dense gradient may be absent when the caller hands over only the rows the loss saw -- round 6: the head itself ran
+            //  on those rows, there is no [N, cout] output -- ; the row-compacted path below then has to apply)
+            OSN_REQUIRE(run->goutput || (run->goutput_rows && run->grows_pos && run->grows_idx && run->n_grows > 0), OSN_E_ARG,
+                        "osn_net_backward: null output gradient");
             gsrc[ng] = run->goutput; gld[ng] = o.cout; ++ng;
         } else {
             // (every later op, not only those of this call's range: a backward pass may be played in segments, highest ops
@@ -529,6 +532,9 @@ extern "C" int osn_net_backward(const osn_net_desc* net, const osn_net_run* run,
                                  run->n_grows > 0 && run->n_grows < n_out && L.rows_in_off != NO_OFF &&
                                  (L.wgrad_k[i] == OSN_NET_K_WGRAD || L.wgrad_k[i] == OSN_NET_K_WGRAD_TL) &&
                                  (!o.need_dgrad || L.dgrad_k[i] == OSN_NET_K_DENSE);
+        OSN_REQUIRE(o.dst >= 0 || sparse_rows || run->goutput, OSN_E_ARG,
+                    "osn_net_backward: op %d: only the supervised rows of the output gradient were given, but the row-compacted head "
+                    "backward does not apply to this configuration", i);
         // ---- weight gradient (fork: the side stream sees everything the main stream has queued up to gx)
         OSN_REQUIRE(w.gW, OSN_E_ARG, "osn_net_backward: op %d: null weight-gradient pointer", i);
         // the stem is the LAST weight gradient of a pass and nothing is left to hide it behind: the reduction of the pair-array

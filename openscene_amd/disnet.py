@@ -27,8 +27,10 @@ class DisNet(nn.Module):
             raise NotImplementedError
         self.net3d = mink_unet(in_channels=3, out_channels=last_dim, D=3, arch=cfg.arch_3d)
 
-    def forward(self, sparse_3d):
-        return self.net3d(sparse_3d)
+    def forward(self, sparse_3d, rows=None):
+        """rows: see MinkUNetBase.forward (only the supervised rows of the output; models/disnet.py:38-40 has no such argument --
+        an opt-in of the edited call site)."""
+        return self.net3d(sparse_3d) if rows is None else self.net3d(sparse_3d, rows=rows)
 
     def forward_features(self, sparse_3d):
         """Penultimate features + the head weight, for the fused-head query (openscene_amd.query.query_distill_fused)."""

@@ -311,16 +311,50 @@ class UNetExecutor:
         return arr
 
     # -------------------------------------------------------------------------------------------- passes
-    def forward(self, model, x, features_only=False):
-        """-> the network output [N_0, out_channels] (or, features_only, the input of the final 1x1 conv)."""
+    def forward(self, model, x, features_only=False, rows=None):
+        """-> the network output [N_0, out_channels] (or, features_only, the input of the final 1x1 conv).
+        rows (int64 indices, distinct, in range): -> output[rows] only, [len(rows), out_channels] -- the final 1x1 convolution and, in
+        training, both of its gradients run on those rows (run/distill.py:321-322 indexes the output with the supervision mask before
+        anything reads it: the other rows of the [N, 768] matrix are never used)."""
         p = self.program
         grad = torch.is_grad_enabled() and (x.F.requires_grad or any(q.requires_grad for q in p.params))
         if grad and features_only:
             return None                                          # training through the folded head: module path
+        if rows is not None:
+            if rows.dtype != torch.int64 or rows.dim() != 1 or rows.device != x.F.device:
+                raise ValueError("rows must be an int64 vector of row indices on the features' device")
+            sparse = ROW_SPARSE_HEAD and 0 < rows.shape[0] < x.F.shape[0] and self._head_rows_ok()
+            if not sparse:
+                return self.forward(model, x).index_select(0, rows)
+            if grad:
+                return _UNetRowsFunction.apply(self, model, x, rows.contiguous(), *p.params)
+            with torch.no_grad():
+                feat, st = self._run_forward(model, x, True)
+                return self._head_rows(st, feat, rows.contiguous())
         if grad:
             return _UNetFunction.apply(self, model, x, *p.params)
         with torch.no_grad():
             out, st = self._run_forward(model, x, features_only)
+        return out
+
+    def _head_rows_ok(self):
+        """The final stage is a 1x1 convolution without a batch norm on the 1x1 kernel (every MinkUNet's `final`)."""
+        o = self.program.ops[-1]
+        return o["K"] == 1 and o["bn"] < 0 and o["dst"] < 0 and ops.dense_eligible(o["cin"], o["cout"]) and ops.dense_eligible(o["cout"], o["cin"])
+
+    def _head_rows(self, st, feat, rows):
+        """output[rows] = feat[rows] @ W_final: a row gather and the 1x1 kernel on len(rows) rows."""
+        p = self.program
+        dev = feat.device
+        lib = ops._prep(dev)
+        cin, cout = int(p.ops[-1]["cin"]), int(p.ops[-1]["cout"])
+        n_sel = int(rows.shape[0])
+        in_rows = torch.empty((n_sel, cin), dtype=torch.float32, device=dev)
+        out = torch.empty((n_sel, cout), dtype=torch.float32, device=dev)
+        image = int(st.weights[len(p.convs) - 1]["tl_fwd"])
+        with ops._Dev(dev):
+            check(lib.osn_rows_gather(feat.data_ptr(), rows.data_ptr(), n_sel, cin, in_rows.data_ptr(), ops._stream(dev)), "osn_rows_gather")
+            check(lib.osn_dense_fwd(in_rows.data_ptr(), image, out.data_ptr(), n_sel, cin, cout, ops._stream(dev)), "osn_dense_fwd")
         return out
 
     def _run_forward(self, model, x, features_only=False, grad=False):
@@ -359,6 +393,8 @@ class UNetExecutor:
         n_ops = len(p.ops)
         end = n_ops - 1 if features_only else n_ops
         out = None if features_only else torch.empty((rows[0], p.convs[-1].out_channels), dtype=torch.float32, device=dev)
+        # (features_only with grad: the rows path -- the plan, the weight images and the arena are the full training pass's, the
+        #  final stage is played by _head_rows on the selected rows)
         side, ws2, events = self._side(lib, dev)
         run = _Run(_ptr(self._rows), _ptr(st.maps), _ptr(st.weights), _ptr(st.bns), feats.data_ptr(),
                    out.data_ptr() if out is not None else None, None, st.arena.data_ptr(), st.arena.numel(), None, 0,
@@ -403,12 +439,14 @@ class UNetExecutor:
         off = int(self._y_off[buf])
         return st.arena[off:off + n * ch * 4].view(torch.float32).view(n, ch)
 
-    def _run_backward(self, st, gout):
+    def _run_backward(self, st, gout, rows_direct=None):
+        """rows_direct = (pos int32 [N], idx int64 [n_sel], gradient rows float32 [n_sel, cout]): the output gradient exists only on
+        those rows (the forward pass ran the head on them: forward(rows=...)); gout is then None."""
         p = self.program
-        dev = gout.device
+        dev = gout.device if gout is not None else rows_direct[2].device
         lib = ops._prep(dev)
         gout_in = gout
-        gout = ops._f32c(gout, "grad_output")
+        gout = ops._f32c(gout, "grad_output") if gout is not None else None
         self._plan_query(lib, st.rows, True)
         if int(self._plan.fwd_arena_bytes) != st.plan_fwd_bytes:
             raise RuntimeError("the executor's arena layout changed between a forward pass and its backward pass")
@@ -429,13 +467,17 @@ class UNetExecutor:
         # gradient in place moves its version counter: the compacted rows would be stale, the dense gradient is used).
         rows_pos = rows_idx = rows_g = None
         n_rows = 0
-        hint = getattr(gout_in, "_osn_rows", None)
-        if (ROW_SPARSE_HEAD and hint is not None and hint["ptr"] == gout.data_ptr() and hint["shape"] == tuple(gout.shape)
+        hint = getattr(gout_in, "_osn_rows", None) if gout_in is not None else None
+        if rows_direct is not None:
+            rows_pos, rows_idx, rows_g = rows_direct[0].data_ptr(), rows_direct[1].data_ptr(), rows_direct[2].data_ptr()
+            n_rows = int(rows_direct[1].shape[0])
+        elif (ROW_SPARSE_HEAD and hint is not None and hint["ptr"] == gout.data_ptr() and hint["shape"] == tuple(gout.shape)
                 and hint.get("version") == gout_in._version and 0 < hint["idx"].shape[0] < gout.shape[0] and hint["rows"].device == dev):
             rows_pos, rows_idx, rows_g = hint["pos_ptr"], hint["idx"].data_ptr(), hint["rows"].data_ptr()
             n_rows = int(hint["idx"].shape[0])
             keep_hint = hint                      # (the tensors stay referenced until the launches are queued)
-        run = _Run(_ptr(self._rows), _ptr(st.maps), _ptr(st.weights), _ptr(st.bns), st.feats.data_ptr(), None, gout.data_ptr(),
+        run = _Run(_ptr(self._rows), _ptr(st.maps), _ptr(st.weights), _ptr(st.bns), st.feats.data_ptr(), None,
+                   gout.data_ptr() if gout is not None else None,
                    st.arena.data_ptr(), st.arena.numel(), barena.data_ptr(), barena.numel(), ws.data_ptr(), ws.numel(),
                    ops.tl_counters(dev).data_ptr(), int(st.training), 0, len(p.ops), 0, self.prof,
                    side if events else None, ws2.data_ptr() if (events and ws2 is not None) else None,
@@ -509,6 +551,32 @@ class _UNetFunction(Function):
         grads = ctx.ex._run_backward(ctx.st, gout)
         ctx.st = None
         return (None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:]))
+
+
+class _UNetRowsFunction(Function):
+    """The U-Net with its final 1x1 convolution on SELECTED rows only: forward = osn_net_forward up to the head's input + the head on
+    feat[rows]; backward = osn_net_backward with the row-compacted head gradients (in[rows]^T @ g, scatter(g @ W^T))."""
+
+    @staticmethod
+    def forward(ctx, ex, model, x, rows, *params):
+        feat, st = ex._run_forward(model, x, True, grad=True)
+        out = ex._head_rows(st, feat, rows)
+        n = feat.shape[0]
+        pos = torch.full((n,), -1, dtype=torch.int32, device=feat.device)
+        pos[rows] = torch.arange(rows.shape[0], dtype=torch.int32, device=feat.device)
+        ctx.ex, ctx.st, ctx.rows, ctx.pos = ex, st, rows, pos
+        ctx.save_for_backward(*params)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout_rows):
+        _ = ctx.saved_tensors
+        if ctx.st is None:
+            raise RuntimeError("the network executor's node was backpropagated a second time (retain_graph is not supported here)")
+        g = ops._f32c(gout_rows, "grad_output")
+        grads = ctx.ex._run_backward(ctx.st, None, rows_direct=(ctx.pos, ctx.rows, g))
+        ctx.st = None
+        return (None, None, None, None) + tuple(gr if need else None for gr, need in zip(grads, ctx.needs_input_grad[4:]))
 
 
 _EXECUTORS = weakref.WeakKeyDictionary()       # model -> UNetExecutor | None.  NOT stored on the module: the executor holds ctypes

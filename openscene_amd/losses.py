@@ -68,6 +68,19 @@ class _DistillLoss(Function):
         return gout, None, None, None, None
 
 
+_ident = {}
+
+
+def _identity(n, dev):
+    key = (n, str(dev))
+    t = _ident.get(key)
+    if t is None:
+        if len(_ident) > 8:
+            _ident.clear()
+        t = _ident[key] = torch.arange(n, dtype=torch.int64, device=dev)
+    return t
+
+
 def distill_loss(output, sel, target, loss_type="cosine", validate=False):
     """Scalar loss of run/distill.py:322-328 over `output[sel]` against `target` (feat_3d).
     output float32 [N, D] (the network output, input row order); sel: the supervised rows -- int64 indices (CONTRACT: distinct and
@@ -77,6 +90,9 @@ def distill_loss(output, sel, target, loss_type="cosine", validate=False):
     validate: check the indices on the device and raise on an index out of range or a duplicate (synchronises)."""
     if loss_type not in KINDS:
         raise ValueError("loss_type %r (the reference has 'cosine' and 'l1')" % (loss_type,))
+    if sel is None:
+        # `output` already IS output[sel] (model(sinput, rows=sel)): every row is supervised
+        sel = _identity(output.shape[0], output.device)
     if sel.dtype == torch.bool:
         sel = sel.nonzero(as_tuple=False).squeeze(1)
     return _DistillLoss.apply(output, sel, target, KINDS[loss_type], bool(validate))

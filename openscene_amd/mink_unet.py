@@ -85,14 +85,18 @@ class MinkUNetBase(nn.Module):
         y = conv(x)
         return y._like(F_.batch_norm_act(y.F, norm.bn, relu=True))
 
-    def forward(self, x):
+    def forward(self, x, rows=None):
+        """rows (optional, int64 row indices): return only output[rows] -- what run/distill.py:321-322 keeps of the output
+        (`output_3d = model(sinput); output_3d = output_3d[mask]`).  With the executor the final 1x1 convolution then runs on those
+        rows only (forward and both gradients); without it the full output is computed and indexed."""
         # one C call per pass (openscene_amd/executor.py) when the configuration allows it; otherwise -- and for the
         # reference's own models/mink_unet.py running through the MinkowskiEngine alias -- module by module
         ex = executor.for_model(self)
         if ex is not None and ex.usable(x, self):
-            return ex.forward(self, x)
+            return ex.forward(self, x, rows=rows)
         with F_.deferred_bn_counters():
-            return self.final(self._forward(x)).F
+            out = self.final(self._forward(x)).F
+        return out if rows is None else out.index_select(0, rows)
 
     def forward_features(self, x):
         """The input of the final 1x1 convolution (float32 [N_0, PLANES[7]], input row order): what

@@ -147,6 +147,52 @@ def test_disnet_distill_step_and_row_order():
     assert sum(float(g.abs().sum()) for g in grads) > 0
 
 
+def test_head_on_selected_rows_equals_the_indexed_full_output():
+    """Round 6: model(sinput, rows=sel) runs the final 1x1 convolution (and, in training, both of its gradients) on the supervised
+    rows only -- run/distill.py:321-322 indexes the output with the mask before anything reads it.  Forward rows bitwise the indexed
+    full output (same kernel, same row-wise product); every parameter gradient equal to the full-output path's to fp32 round-off;
+    eval mode; all rows / empty selection fall back to indexing."""
+    from openscene_amd import losses
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import SparseTensor
+    torch.manual_seed(11)
+    model = mink_unet(3, 768, 3, "MinkUNet14A").to(dev()).train()
+    coords = torch.from_numpy(scene_coords(5, 9000, 0.05)).to(dev())
+    n = coords.shape[0]
+    feats = torch.rand(n, 3, device=dev())
+    g = torch.Generator().manual_seed(3)
+    sel = torch.randperm(n, generator=g)[: n // 5].sort()[0].to(dev())
+    target = torch.nn.functional.normalize(torch.randn(sel.shape[0], 768, device=dev()), dim=1)
+    res = []
+    for rows in (True, False):
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.reset_running_stats()
+        model.zero_grad(set_to_none=True)
+        if rows:
+            out = model(SparseTensor(feats, coords), rows=sel)
+            loss = losses.distill_loss(out, None, target)
+        else:
+            full = model(SparseTensor(feats, coords))
+            out = full.index_select(0, sel)
+            loss = losses.distill_loss(full, sel, target)
+        loss.backward()
+        res.append((out.detach().clone(), float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0]), "head on the selected rows differs from the indexed full output"
+    assert abs(res[0][1] - res[1][1]) <= 1e-6 * abs(res[1][1])
+    for k in res[0][2]:
+        assert rel_l2(res[0][2][k], res[1][2][k]) <= 2e-6, k
+    model.eval()
+    with torch.no_grad():
+        a = model(SparseTensor(feats, coords), rows=sel)
+        b = model(SparseTensor(feats, coords)).index_select(0, sel)
+        every = torch.arange(n, device=dev())
+        c = model(SparseTensor(feats, coords), rows=every)
+    assert torch.equal(a, b) and c.shape == (n, 768)
+    with pytest.raises(ValueError):
+        model(SparseTensor(feats, coords), rows=sel.int())
+
+
 def test_row_sparse_head_with_a_narrow_head(monkeypatch):
     """A head of <= 128 channels plans the pair-array weight gradient; the row-compacted path runs the table kernel instead
     and needs its scratch (the executor's plan reserves it)."""
