@@ -506,13 +506,32 @@ def cpu_baseline(seed, arch, out_dim):
         # "same inputs" -- when the full S100k scene fits the time bound IT is the headline value (ONE step, to keep
         # the baseline leg at ~30 s of CPU work; the thread pool and BLAS are warm from the runs above), the 1/8-size median stays
         # beside it
-        n, dt = _cpu_step(seed, 120000, arch, out_dim)
+        # (the ladder ran on the 1/8-size scene, and a 101 k-voxel step has eight times the rows per BLAS call: the full
+        # scene is timed at the ladder's thread count AND at twice / four times that -- as long as it keeps getting faster and the
+        # leg stays within ~30 s -- and the fastest is the headline; every run is kept in the line's detail)
+        full_runs = {}
+        t_try, spent = threads, 0.0
+        while True:
+            torch.set_num_threads(t_try)
+            n, dt = _cpu_step(seed, 120000, arch, out_dim)
+            full_runs[t_try] = (n, dt)
+            spent += dt
+            best_t = min(full_runs, key=lambda k: full_runs[k][1])
+            if t_try != best_t or 2 * t_try > cores or t_try >= 4 * threads or spent + dt > 30.0:
+                break
+            t_try *= 2
+        best_t = min(full_runs, key=lambda k: full_runs[k][1])
+        n, dt = full_runs[best_t]
+        torch.set_num_threads(threads)
         res["eighth_scene"] = {"value": res["value"], "voxels": n_small, "seconds": dt_small}
-        res["full_scene"] = {"value": n / dt, "voxels": n, "seconds": dt, "threads": threads}
+        res["full_scene"] = {"value": n / dt, "voxels": n, "seconds": dt, "threads": best_t,
+                             "runs_voxels_per_s_by_threads": {str(k): v[0] / v[1] for k, v in full_runs.items()}}
         res["value"] = n / dt
+        res["cores"] = res["threads"] = best_t
         res["sample"] = ("one step (maps + fwd + loss + bwd, fp32, no optimizer) of %s on the SAME S100k scene "
-                         "the GPU line is quoted on: %d voxels in %.2f s with %d threads (fastest of a 1..64 thread ladder on a 1/8-size "
-                         "scene; %d cores visible)" % (arch, n, dt, threads, cores))
+                         "the GPU line is quoted on: %d voxels in %.2f s with %d threads (fastest of %s threads on this scene, starting "
+                         "from the best of a 1..64 thread ladder on a 1/8-size scene; %d cores visible)"
+                         % (arch, n, dt, best_t, "/".join(str(k) for k in sorted(full_runs)), cores))
     from oracle import voxelize as ov
     from openscene_amd import synthetic as syn
     pts = syn.room_points(7, n_pts=200000)
@@ -598,6 +617,14 @@ def headline(detail, detail_path=None):
         # the step), beside ms_per_step (which has the three call-site edits of INTEGRATION.md section 1)
         line["ms_per_step_call_sites_unchanged"] = _num(di["ms"])
         line["value_call_sites_unchanged"] = _num(di.get("voxels_per_s"))
+    b8 = (ph or {}).get("batch8_step")
+    if isinstance(b8, dict) and b8.get("ms"):
+        # the reference's own 1-GPU configuration (8 scenes per step) per scene, beside the one-scene step of `ms_per_step`
+        line["batch8_per_scene_ms"] = _num(b8["ms"] / 8.0)
+    sr = detail.get("scaling_reference")
+    if isinstance(sr, dict) and sr.get("speedup_vs_same_batch_on_one_gpu"):
+        line["speedup_vs_same_batch_on_one_gpu"] = _num(sr["speedup_vs_same_batch_on_one_gpu"])
+        line["one_gpu_batch_of_n_scenes_ms"] = _num(sr["one_gpu_batch_of_n_scenes_ms"])
     line["loss"] = detail.get("loss")
     line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
     s = json.dumps(line, separators=(",", ":"))
@@ -1302,6 +1329,25 @@ def main():
 
     step_bytes, step_flops = step_algorithmic_bytes(model, sizes, pair_counts)
     ms_per_step = dt_max * 1e3 / args.steps
+    # The OTHER scaling definition.  The line's `value` is weak scaling: one S100k-shaped scene per rank.  The
+    # reference splits a FIXED batch (run/distill.py:146 `batch_size //= ngpus`; config/scannet/ours_openseg.yaml: batch_size 8):
+    # its N-GPU step is the SAME N scenes that one GPU would take as one batch.  Rank 0 therefore also times that one-GPU batch of N
+    # scenes (untimed region, after the other ranks have left) and the line carries  speedup_vs_same_batch_on_one_gpu =
+    # t(N scenes on 1 GPU) / t(1 scene on each of N GPUs).  No multi-GPU number exists in this repository until SCALE runs.
+    scaling_ref = None
+    if world > 1 and not args.dist_single and os.environ.get("OSN_BENCH_SCALING_REF", "1") != "0":
+        try:
+            from openscene_amd import synthetic as syn
+            rooms_n = [syn.shuffled(syn.grid_voxels(syn.room_points(sd, n_pts=args.scene_points), 0.02), sd) for sd in range(world)]
+            coords_n = torch.from_numpy(syn.batch_coords(rooms_n)).to(device)
+            ms_n = variant_step_ms(device, args.arch, args.feature, coords_n, steps=3, warmup=2, n_sup=20000 * world)
+            scaling_ref = {"one_gpu_batch_of_n_scenes_ms": ms_n, "n_scenes": world,
+                           "speedup_vs_same_batch_on_one_gpu": ms_n / ms_per_step,
+                           "what": "run/distill.py:146 batch_size //= ngpus: %d scenes as ONE batch on one GPU (%.2f ms) against one scene "
+                                   "on each of %d GPUs (%.2f ms per step incl. the gradient exchange)" % (world, ms_n, world, ms_per_step)}
+            del coords_n
+        except Exception as e:                                   # (never let the reference leg cost the line)
+            scaling_ref = {"error": repr(e)[:200]}
     roofline = None
     kernels = {}
     n_sv = N_SURVEY if survey_shapes else 1
@@ -1396,7 +1442,7 @@ def main():
                    "level_sizes": sizes, "parallelism": "dp%d" % world,
                    "step_algorithmic_GB": step_bytes / 1e9, "step_GFLOP": step_flops / 1e9},
         "query": qres, "voxelizer": vox_res, "phases": extra, "roofline": roofline, "cpu_baseline": cpu, "comm": comm,
-        "kernels": kernels, "stages": stages, "loss": float(loss.detach()),
+        "kernels": kernels, "stages": stages, "loss": float(loss.detach()), "scaling_reference": scaling_ref,
         "host_path": "network executor (one C call per forward / backward pass)" if ex is not None else "per-module (Python autograd)",
         "optimizer": ("torch.optim.Adam(fused=True)" if (args.torch_adam or args.ddp) else
                       "openscene_amd.optim.FlatAdam (torch.optim.Adam's update rule over one flat buffer, one launch)"),

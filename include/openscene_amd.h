@@ -277,6 +277,19 @@ int osn_wgrad_tl_reduce_batch(const osn_wgrad_job* jobs_host, int n_jobs, osn_st
  * osn_spconv_fwd_tl; no workspace.  Needs cin % 4 == 0, cin >= 8, cout % 4 == 0.                                    */
 int osn_dense_fwd(const float* in, const void* Wp, float* out, int64_t n, int cin, int cout, osn_stream_t stream);
 
+/* Convolution of a NARROW layer (32 or 64 channels on both sides) straight from the neighbour table ([ME]
+ * MinkowskiConvolution forward, models/mink_unet.py:59-93: conv1p1s2 .. block2 -- the 32- and 64-channel stages of the encoder --
+ * and, with the input-gradient image and the mirrored table, their backward): every lane of a wave gathers the 32 bytes of the
+ * fp32 row that ARE its MFMA operand (two 16-byte loads through nbr; an absent neighbour reads zeros and moves no data), splits
+ * them in registers and multiplies -- no staging through LDS, no barrier in the loop.  A workgroup owns 64 table rows, its four
+ * waves take the offsets w, w + 4, ..., partial tiles are summed in wave order (bitwise reproducible).  Same arithmetic and
+ * weight image as osn_spconv_fwd_tl (osn_weight_prep_tl).  nbr: int32 [K, n_out], plain or osn_kmap_sort-ordered (then out_rows =
+ * its permutation: table row j is written to out[out_rows[j]]).  osn_spconv_fwd_rg_ok: 1 for the shapes it takes (K > 1, cin and
+ * cout in {32, 64}, n_in < 2^24, the feature matrix below 2 GB).                                                           */
+int osn_spconv_fwd_rg_ok(int64_t n_in, int K, int cin, int cout);
+int osn_spconv_fwd_rg(const float* in, int64_t n_in, const void* Wp, const int32_t* nbr, const int32_t* out_rows, float* out,
+                      int64_t n_out, int K, int cin, int cout, osn_stream_t stream);
+
 /* Convolution of a SMALL map (<= 16 k rows) from its per-offset pair arrays, weight-stationary ([ME]
  * MinkowskiConvolution[Transpose] forward, models/mink_unet.py:51-113 on the 1/4 .. 1/16 levels; with the input-gradient
  * weight image also their backward):  a workgroup keeps W[k] of ONE offset in registers and multiplies a chunk of that
@@ -540,7 +553,7 @@ typedef struct osn_net_desc {
     const osn_net_buf* bufs;
 } osn_net_desc;
 enum { OSN_NET_K_NONE = 0, OSN_NET_K_STEM = 1, OSN_NET_K_TL = 2, OSN_NET_K_X6 = 3, OSN_NET_K_WGRAD_TL = 4, OSN_NET_K_WGRAD = 5,
-       OSN_NET_K_WS = 6, OSN_NET_K_WS_DIRECT = 7, OSN_NET_K_WGRAD_STEM = 8, OSN_NET_K_DENSE = 9 };
+       OSN_NET_K_WS = 6, OSN_NET_K_WS_DIRECT = 7, OSN_NET_K_WGRAD_STEM = 8, OSN_NET_K_DENSE = 9, OSN_NET_K_RG = 10 };
 enum { OSN_NET_IMG_X6_FWD = 1, OSN_NET_IMG_X6_DGRAD = 2, OSN_NET_IMG_TL_FWD = 4, OSN_NET_IMG_TL_DGRAD = 8 };
 typedef struct osn_net_plan {                 /* every array is caller-provided HOST memory                       */
     uint64_t fwd_arena_bytes, bwd_arena_bytes, ws_bytes;

@@ -78,6 +78,8 @@ PROTOTYPES = {
     "osn_bn_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32,
                                _vp, _sz, _vp]),
     "osn_bn_apply2": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "osn_spconv_fwd_rg_ok": (_i32, [_i64, _i32, _i32, _i32]),
+    "osn_spconv_fwd_rg": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "osn_bn_forward_train2": (_i32, [_vp, _i64, _i32, _vp, _vp, _f32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "osn_bn_backward_multi": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32,
                                      _vp, _sz, _vp]),

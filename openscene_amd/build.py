@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libopenscene_amd.so")
 ARCH = "gfx950"
-SOURCES = ["lib.hip", "coords.hip", "kmap_sort.hip", "spconv.hip", "spconv_tl.hip", "spconv_ws.hip", "dense.hip", "weight_prep.hip", "wgrad_tl.hip", "stem.hip", "bn.hip", "elementwise.hip", "loss.hip", "optim.hip", "query.hip", "voxelize.hip", "loader.hip", "fusion.hip", "net.hip", "maps.hip"]
+SOURCES = ["lib.hip", "coords.hip", "kmap_sort.hip", "spconv.hip", "spconv_tl.hip", "spconv_ws.hip", "spconv_rg.hip", "dense.hip", "weight_prep.hip", "wgrad_tl.hip", "stem.hip", "bn.hip", "elementwise.hip", "loss.hip", "optim.hip", "query.hip", "voxelize.hip", "loader.hip", "fusion.hip", "net.hip", "maps.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-deprecated-declarations", "-DNDEBUG"]
 

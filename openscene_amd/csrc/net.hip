@@ -52,6 +52,9 @@ static int ws_kernel(const osn_net_desc* net, const osn_net_op& o, int ca, int c
     return 0;
 }
 static bool dense_eligible(int cin, int cout) { return (cin & 3) == 0 && cin >= 8 && (cout & 3) == 0; }
+// functional.rg_kernel: the register-gather kernel for the narrow layers (32 / 64 channels on both sides) that neither the tile-list
+// kernel nor a direct weight-stationary launch takes -- before the partial-row weight-stationary kernel and the first-generation one
+static bool rg_eligible(int K, int ca, int cb, int64_t n_src) { return osn_spconv_fwd_rg_ok(n_src > 0 ? n_src : 1, K, ca, cb) != 0; }
 static bool x6_eligible(int K, int cin, int cout, int64_t n_out) {
     if ((cin & 3) || cin < 8) return false;
     if (int64_t(3) * K * cout * ((cin + 31) / 32 * 32) >= (int64_t(1) << 30)) return false;
@@ -150,6 +153,9 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
             L.fwd_k[i] = OSN_NET_K_TL;
             L.images[i] |= OSN_NET_IMG_TL_FWD;
             need_ws(osn_spconv_fwd_tl_ws_bytes(n_out, o.K, o.cout, osn_tile_rows(n_out)));
+        } else if (rg_eligible(o.K, o.cin, o.cout, n_in)) {
+            L.fwd_k[i] = OSN_NET_K_RG;
+            L.images[i] |= OSN_NET_IMG_TL_FWD;
         } else if (ws_kernel(net, o, o.cin, o.cout, n_in, n_out, o.transposed != 0) == OSN_NET_K_WS) {
             L.fwd_k[i] = OSN_NET_K_WS;
             L.images[i] |= OSN_NET_IMG_TL_FWD;
@@ -176,6 +182,9 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
                 L.dgrad_k[i] = OSN_NET_K_TL;
                 L.images[i] |= OSN_NET_IMG_TL_DGRAD;
                 need_ws(osn_spconv_fwd_tl_ws_bytes(n_in, o.K, o.cin, osn_tile_rows(n_in)));
+            } else if (rg_eligible(o.K, o.cout, o.cin, n_out)) {
+                L.dgrad_k[i] = OSN_NET_K_RG;
+                L.images[i] |= OSN_NET_IMG_TL_DGRAD;
             } else if (wsk == OSN_NET_K_WS) {
                 L.dgrad_k[i] = OSN_NET_K_WS;
                 L.images[i] |= OSN_NET_IMG_TL_DGRAD;
@@ -291,6 +300,9 @@ static int run_conv(int kernel, const float* in, int64_t n_in, float* out, int64
             OSN_REQUIRE(pl && img_tl && nbr, OSN_E_ARG, "osn_net: op %d: pair arrays / tile-list weight image / destination table missing", op);
             return osn_spconv_fwd_ws(in, n_in, img_tl, pl, pl_rows, pl_swap, kernel == OSN_NET_K_WS_DIRECT ? 1 : 0, nbr, out, n_out, K,
                                      cin, cout, run->ws, size_t(run->ws_bytes), stream);
+        case OSN_NET_K_RG:
+            OSN_REQUIRE(img_tl && nbr, OSN_E_ARG, "osn_net: op %d: the register-gather kernel needs the tile-list weight image and the table", op);
+            return osn_spconv_fwd_rg(in, n_in, img_tl, t_tbl ? t_tbl : nbr, t_tbl ? t_rows : nullptr, out, n_out, K, cin, cout, stream);
         case OSN_NET_K_STEM:
             OSN_REQUIRE(nbr && W, OSN_E_ARG, "osn_net: op %d: the stem kernel needs the plain table and the fp32 weight", op);
             return osn_stem_conv_fwd(in, W, nbr, out, n_out, K, cin, cout, stream);

@@ -48,7 +48,7 @@ _BN = np.dtype([(n, "<u8") for n in ("gamma", "beta", "running_mean", "running_v
 assert _OP.itemsize == 72 and _MAP.itemsize == 128 and _WEIGHT.itemsize == 48 and _BN.itemsize == 56
 
 IMG_X6_FWD, IMG_X6_DGRAD, IMG_TL_FWD, IMG_TL_DGRAD = 1, 2, 4, 8
-K_NAMES = {0: "none", 1: "stem", 2: "tl", 3: "x6", 4: "wgrad_tl", 5: "wgrad", 6: "ws", 7: "ws_direct", 8: "wgrad_stem", 9: "dense"}
+K_NAMES = {0: "none", 1: "stem", 2: "tl", 3: "x6", 4: "wgrad_tl", 5: "wgrad", 6: "ws", 7: "ws_direct", 8: "wgrad_stem", 9: "dense", 10: "rg"}
 K_WS = (6, 7)
 
 

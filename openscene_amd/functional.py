@@ -76,6 +76,7 @@ class SparseConvFunction(Function):
         ctx.tl_bwd = None
         ctx.ws_bwd = None
         ctx.dense_bwd = None
+        ctx.rg_bwd = None
         # the cached weight images are shared and refreshed in place: remember which version of the kernel the image kept
         # for the backward pass belongs to (a weight changed through .data between forward and backward bypasses autograd's
         # own saved-tensor check)
@@ -102,6 +103,19 @@ class SparseConvFunction(Function):
             fwd_ok = lists_fwd is not None and tl_rows_ok(n_out, cin, cout) and ws_f != "ws_direct"
             bwd_ok = (ctx.needs_input_grad[0] and ops.tl_eligible(K, cout, cin, n_out) and lists_bwd is not None
                       and tl_rows_ok(ctx.n_in, cin, cout) and ws_b != "ws_direct")
+            # narrow layers (32 / 64 channels on both sides): the register-gather kernel where neither the tile-list kernel nor a
+            # direct weight-stationary launch applies (same rule as csrc/net.hip) -- forward here, input gradient decided here
+            rg_f = not fwd_ok and ws_f != "ws_direct" and ops.rg_eligible(K, cin, cout, ctx.n_in)
+            rg_b = (ctx.needs_input_grad[0] and not bwd_ok and ws_b != "ws_direct" and ops.rg_eligible(K, cout, cin, n_out))
+            if rg_b:
+                ctx.rg_bwd = ops.weight_image(kernel, flip, True, ops.PREP_TL)
+                ws_b = None
+            if rg_f:
+                if bwd_ok:
+                    ctx.wp_dgrad, ctx.tl_bwd = ops.weight_image(kernel, flip, True, ops.PREP_TL), lists_bwd
+                elif ws_b is not None:
+                    ctx.ws_bwd = (ops.weight_image(kernel, flip, True, ops.PREP_TL), pl, swap_f if flip else not swap_f, ws_b == "ws_direct")
+                return ops.spconv_fwd_rg(feats, ops.weight_image(kernel, False, False, ops.PREP_TL), tbl, n_out, cout, out_rows=rows)
             if ws_b is not None and not bwd_ok:
                 ctx.ws_bwd = (ops.weight_image(kernel, flip, True, ops.PREP_TL), pl, swap_f if flip else not swap_f,
                               ws_b == "ws_direct")
@@ -119,7 +133,8 @@ class SparseConvFunction(Function):
                 return ops.spconv_fwd_tl(feats, wf, lists_fwd, n_out, K, cout)
         if mode == "bf16x6" and ops.x6_eligible(K, cin, cout, n_out):
             wp = ops.weight_image(kernel, False, False, ops.PREP_X6)
-            if ctx.needs_input_grad[0] and ctx.tl_bwd is None and ctx.ws_bwd is None and ops.x6_eligible(K, cout, cin, ctx.n_in):
+            if (ctx.needs_input_grad[0] and ctx.tl_bwd is None and ctx.ws_bwd is None and ctx.rg_bwd is None
+                    and ops.x6_eligible(K, cout, cin, ctx.n_in)):
                 ctx.wp_dgrad = ops.weight_image(kernel, flip, True, ops.PREP_X6)
             return ops.spconv_fwd_x6(feats, wp, tbl, n_out, out_rows=rows, gmask=gm)
         return ops.spconv_fwd(feats, kernel, tbl, n_out, out_rows=rows, gmask=gm)
@@ -131,7 +146,7 @@ class SparseConvFunction(Function):
         gout = gout.contiguous()
         gin = gk = None
         K = 1 if kernel.dim() == 2 else kernel.shape[0]
-        if (ctx.wp_dgrad is not None or ctx.ws_bwd is not None or ctx.dense_bwd is not None) and ctx.kver != (kernel._version, kernel.data_ptr()):
+        if (ctx.wp_dgrad is not None or ctx.ws_bwd is not None or ctx.dense_bwd is not None or ctx.rg_bwd is not None) and ctx.kver != (kernel._version, kernel.data_ptr()):
             raise RuntimeError("a convolution kernel changed between its forward and its backward pass (version %d -> %d): "
                                "the input-gradient weight image kept from the forward is stale" % (ctx.kver[0], kernel._version))
 
@@ -167,6 +182,9 @@ class SparseConvFunction(Function):
             if ctx.dense_bwd is not None:
                 gin = ops.dense_fwd(gout, ctx.dense_bwd, cin)
                 ctx.dense_bwd = None
+            elif ctx.rg_bwd is not None:
+                gin = ops.spconv_fwd_rg(gout, ctx.rg_bwd, tbl, ctx.n_in, cin, out_rows=rows)
+                ctx.rg_bwd = None
             elif ctx.tl_bwd is not None:
                 gin = ops.spconv_fwd_tl(gout, ctx.wp_dgrad, ctx.tl_bwd, ctx.n_in, K, cin)
                 ctx.wp_dgrad = ctx.tl_bwd = None
@@ -175,6 +193,7 @@ class SparseConvFunction(Function):
                 gin = ops.spconv_fwd_ws(gout, wb, pl, nbr_bwd, ctx.n_in, K, cin, swap=swap_b, direct=direct)
                 ctx.ws_bwd = None
             elif mode == "bf16x6" and ops.x6_eligible(K, cout, cin, ctx.n_in):
+                # (reached only when the forward pass planned this kernel: rg_bwd / tl_bwd / ws_bwd are set otherwise)
                 wp = ctx.wp_dgrad if ctx.wp_dgrad is not None else ops.weight_image(kernel, flip, True, ops.PREP_X6)
                 ctx.wp_dgrad = None
                 gin = ops.spconv_fwd_x6(gout, wp, tbl, ctx.n_in, out_rows=rows, gmask=gm)

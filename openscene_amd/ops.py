@@ -840,6 +840,28 @@ def spconv_fwd_ws(feats, wp, tl, nbr_dst, n_dst, K, cout, swap=False, direct=Fal
     return out
 
 
+def rg_eligible(K, cin, cout, n_in):
+    """Shapes the register-gather kernel takes (csrc/spconv_rg.hip): 32 / 64 channels on both sides, K > 1."""
+    return bool(_cached("osn_spconv_fwd_rg_ok", int(max(n_in, 1)), int(K), int(cin), int(cout)))
+
+
+def spconv_fwd_rg(feats, wp, nbr, n_out, cout, out_rows=None):
+    """out[o] = sum_k feats[nbr[k, o]] @ B[k], B given as a weight_prep_tl image (forward or input-gradient image); nbr plain or
+    tile-ordered (then out_rows = its permutation)."""
+    dev = feats.device
+    lib = _prep(dev)
+    feats = _f32c(feats, "features")
+    nbr = nbr.contiguous()
+    K = nbr.shape[0]
+    if nbr.shape[1] != n_out:
+        raise ValueError("table is [%d, %d], conv wants %d output rows" % (K, nbr.shape[1], n_out))
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    with _Dev(dev):
+        check(lib.osn_spconv_fwd_rg(_p(feats), feats.shape[0], _p(wp), _p(nbr), _p(out_rows), _p(out), n_out, K, feats.shape[1], cout,
+                                    _stream(dev)), "osn_spconv_fwd_rg")
+    return out
+
+
 def stem_eligible(K, cin, cout):
     """The dedicated kernels of the U-Net's 3-channel stem conv (any conv with <= 4 input and 32 output channels)."""
     return cin <= 4 and cout == 32 and 1 < K <= 125

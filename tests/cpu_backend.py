@@ -256,6 +256,16 @@ def spconv_fwd_ws(feats, wp, tl, nbr_dst, n_dst, K, cout, swap=False, direct=Fal
     return out
 
 
+def rg_eligible(K, cin, cout, n_in):
+    """Spec of osn_spconv_fwd_rg_ok."""
+    return 1 < K <= 128 and cin in (32, 64) and cout in (32, 64) and 1 <= max(n_in, 1) < (1 << 24) and max(n_in, 1) * cin * 4 < (1 << 31)
+
+
+def spconv_fwd_rg(feats, wp, nbr, n_out, cout, out_rows=None):
+    """Spec of osn_spconv_fwd_rg: the table convolution (B given as a fragment-order image = the [K, c, n] matrix here)."""
+    return spconv_fwd(feats, wp[1], nbr, n_out, out_rows=out_rows)
+
+
 def stem_eligible(K, cin, cout):
     return cin <= 4 and cout == 32 and 1 < K <= 125
 
@@ -441,7 +451,7 @@ def cat2_bwd(gout, ca, cb):
     return gout[:, :ca].contiguous(), gout[:, ca:ca + cb].contiguous()
 
 
-_NAMES = ["relu_fwd", "relu_bwd", "add", "cat2", "cat2_bwd", "fusion_project", "fusion_accumulate", "fusion_finish", "weight_image", "stem_eligible", "stem_conv_fwd", "stem_conv_wgrad", "dense_eligible", "dense_fwd", "rows_argmax", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "spconv_fwd_ws", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "coords_pyramid", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose",
+_NAMES = ["relu_fwd", "relu_bwd", "add", "cat2", "cat2_bwd", "fusion_project", "fusion_accumulate", "fusion_finish", "weight_image", "stem_eligible", "stem_conv_fwd", "stem_conv_wgrad", "dense_eligible", "dense_fwd", "rows_argmax", "TileLists", "tile_rows", "tile_lists", "pair_lists", "pair_arrays", "spconv_wgrad_tl", "spconv_fwd_ws", "tl_eligible", "weight_prep_tl", "spconv_fwd_tl", "HashTable", "coords_unique", "coords_pyramid", "kmap_build", "kmap_transpose", "kmap_sort", "kmap_count", "spconv_fwd", "weight_prep_x6", "weight_prep_x6_pair", "spconv_fwd_x6", "x6_eligible", "weight_transpose", "rg_eligible", "spconv_fwd_rg",
           "spconv_wgrad", "bn_stats", "bn_forward_train", "bn_apply", "bn_backward", "cosine_query", "query_ensemble", "voxelize_fnv",
           "fnv_hash", "ravel_hash", "feature_remap", "batch_coords"]
 

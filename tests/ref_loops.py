@@ -505,9 +505,14 @@ def replay(g, device):
 MARGIN = 2e-2       # a point whose top-2 scores are closer than this (relative to the largest score) may flip between engines
 
 
-def compare(gold, got, margins, loss_tol=2e-4, what=""):
+def compare(gold, got, margins, loss_tol=2e-4, what="", agree_tol=0.999):
     """Tolerances of a replay (or of the reference run itself) against the fixture; `margins`: where the top-2 margins come
-    from (the fixture's CPU replay).  Returns a dict of the measured deviations."""
+    from (the fixture's CPU replay).  Returns a dict of the measured deviations.
+    Why a GPU replay cannot be held tighter than this (measured, tests/test_reference_loops.py prints it for two arithmetic modes):
+    the loops train with torch.optim.Adam for TWO steps from fresh moments, where the update of a weight is -lr * sign-like
+    (g / (|g| + eps)): an element whose gradient is within fp32 round-off of zero gets +lr or -lr depending on the LAST BIT of a sum of
+    ~10^4 products, i.e. on the summation order of the engine.  The exact-fp32 HIP kernels (OSN_CONV_MODE=fp32, bit-for-bit fmaf
+    chains) deviate from the CPU fixture by as much as the split-bf16 ones: the tolerance is the arithmetic's, not a kernel's."""
     dev = {}
     dev["train_loss"] = float(np.abs(got["train_loss_batch"] - gold["train_loss_batch"]).max())
     assert dev["train_loss"] <= loss_tol, "%s training losses %s vs %s" % (what, got["train_loss_batch"], gold["train_loss_batch"])
@@ -534,7 +539,7 @@ def compare(gold, got, margins, loss_tol=2e-4, what=""):
             agree = float((got[k + "pred"][clear] == gold[k + "pred"][clear]).mean())
             dev[k + "agree"] = agree
             dev[k + "clear_frac"] = float(clear.mean())
-            assert clear.mean() > 0.5 and agree >= 0.999, "%s %s labels agree on %.4f of the %.2f clear points" % (what, k, agree, clear.mean())
+            assert clear.mean() > 0.5 and agree >= agree_tol, "%s %s labels agree on %.4f of the %.2f clear points" % (what, k, agree, clear.mean())
             dev[k + "miou"] = float(abs(float(got[k + "miou"]) - float(gold[k + "miou"])))
             assert dev[k + "miou"] <= 5e-3, "%s %s mIoU %s vs %s" % (what, k, got[k + "miou"], gold[k + "miou"])
     return dev

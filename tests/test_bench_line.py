@@ -52,6 +52,21 @@ def test_headline_drops_side_blocks_rather_than_outgrow_the_limit():
     assert "phases_ms" not in back and all(k in back for k in REQUIRED)
 
 
+def test_headline_carries_both_scaling_definitions():
+    """at N = 1 the reference's own 1-GPU configuration (8 scenes per step) per scene at top level; at N > 1 the
+    one-GPU batch of N scenes and the speed-up against it (run/distill.py:146 `batch_size //= ngpus`) beside the weak-scaling value."""
+    b = _bench()
+    detail = json.loads(open(os.path.join(ROOT, "profiles", "r03_s20_bench_head.json")).read().strip().splitlines()[-1])
+    detail.setdefault("phases", {})["batch8_step"] = {"ms": 43.12, "voxels": 809000, "scenes": 8}
+    line = b.headline(detail, None)
+    assert abs(line["batch8_per_scene_ms"] - 43.12 / 8) < 1e-3 and "speedup_vs_same_batch_on_one_gpu" not in line
+    detail["n_gpus"] = 8
+    detail["scaling_reference"] = {"one_gpu_batch_of_n_scenes_ms": 43.0, "n_scenes": 8, "speedup_vs_same_batch_on_one_gpu": 4.8}
+    line = b.headline(detail, None)
+    assert line["speedup_vs_same_batch_on_one_gpu"] == 4.8 and line["one_gpu_batch_of_n_scenes_ms"] == 43.0
+    assert len(json.dumps(line, separators=(",", ":"))) <= b.MAX_LINE_BYTES
+
+
 def test_headline_carries_the_round5_fields():
     """VERDICT r4 'next' #4: the line says what SURVEY 8(d) defines -- roofline fraction over ALL launches of the dominant shape with
     the forward-pass-only figure beside it, the step with the reference's call sites unchanged next to ms_per_step, the CPU

@@ -84,6 +84,45 @@ def test_oracle_network_equals_reference_file_on_dense_operators(gold):
         assert abs(proj - rp) <= 1e-10 * float(b.norm()) * np.sqrt(b.numel()), name
 
 
+def fp32_cpu_deviation(gold):
+    """The float64 oracle's OWN network evaluated in plain fp32 on the CPU (torch mm / index_add, fp32 accumulate), against the float64
+    fixture: (output rel-L2 eval, train, input-gradient rel-L2, worst parameter-gradient norm error).  This is what "fp32 through
+    40 - 60 layers + ReLU decisions at round-off" costs with NO kernel of this repository involved."""
+    shapes = {n: tuple(s) for n, s in zip(gold["pnames"].tolist(), gold["pshapes"])} if "pshapes" in gold.g.files else None
+    if shapes is None:
+        shapes = {k: tuple(v.shape) for k, v in so.init_params(gold.arch, R.IN_CH, R.OUT_CH).items()}
+    p = {k: v.float() for k, v in recipe_params(shapes.items()).items()}
+    coords, feats = gold.coords, torch.from_numpy(gold.feats).float()
+    e_eval = rel(gold.rows(so.unet_forward({k: v.clone() for k, v in p.items()}, feats, coords, gold.arch, train=False)), gold["out_eval"])
+    for k, v in p.items():
+        if "running" not in k:
+            v.requires_grad_(True)
+    x = feats.clone().requires_grad_(True)
+    out = so.unet_forward(p, x, coords, gold.arch, train=True)
+    e_train = rel(gold.rows(out), gold["out_train"])
+    (out * torch.from_numpy(R.output_weights(coords.shape[0])).float()).sum().backward()
+    e_gin = rel(gold.rows(x.grad), gold["gfeats"])
+    worst = 0.0
+    for name, gn in zip(gold["names"].tolist(), gold["gnorm"]):
+        worst = max(worst, abs(float(p[name].grad.double().norm()) - gn) / gn)
+    return e_eval, e_train, e_gin, worst
+
+
+def test_plain_fp32_cpu_evaluation_deviates_like_the_hip_path(gold):
+    """Pins the tolerances of the GPU test below to the ARITHMETIC (the input-gradient bound of MinkUNet34C was raised
+    from 1e-3 to 2.5e-3 after a measured 1.2e-3): the same network in plain fp32 on the CPU -- no HIP kernel, no bf16 split -- deviates
+    from the float64 fixture by MORE than the HIP path does.  Measured (printed): 18A  outputs 4e-7 / 1.2e-6, input gradient 7.4e-6,
+    worst parameter-gradient norm 3.2e-6;  34C  outputs 7e-7 / 1.3e-6, input gradient 2.26e-3, worst parameter-gradient norm 1.39e-3
+    (HIP, both host paths: 1.2e-3 / 2.4e-4, profiles/r05_s3_*).  The gradient that crosses every one of 34C's 60 layers twice meets
+    ReLUs whose pre-activation is within fp32 round-off of zero: they flip between precisions, each flip moves the gradient by
+    ~1 / sqrt(#elements).  The bounds asserted for the HIP path (input gradient 2.5e-3, gradient norms 2e-3) are what plain fp32
+    needs, not numbers fitted to the HIP kernels."""
+    e_eval, e_train, e_gin, worst = fp32_cpu_deviation(gold)
+    print("plain fp32 CPU evaluation vs the float64 fixture (%s): output rel-L2 eval %.2e train %.2e, input gradient %.2e, worst "
+          "parameter-gradient norm error %.2e" % (gold.arch, e_eval, e_train, e_gin, worst))
+    assert e_eval <= 2e-4 and e_train <= 2e-4 and e_gin <= 2.5e-3 and worst <= 2e-3
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", ["executor", "modules"])
 def test_hip_network_equals_reference_file_on_dense_operators(gold, path, monkeypatch):

@@ -73,22 +73,33 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "tl", "ws"])
-@pytest.mark.parametrize("kind,key,cin,cout", CASES)
+RG_CASES = [("big", (1, 1, 3), 32, 32), ("big", (1, 1, 3), 64, 32), ("big", (1, 2, 2), 32, 32), ("mid", (1, 1, 3), 64, 64), ("mid", (1, 1, 3), 32, 64),
+            ("mid", (1, 2, 2), 64, 64), ("small", (1, 1, 3), 64, 64), ("small", (1, 1, 5), 32, 64), ("small", (4, 4, 3), 64, 32)]
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "tl", "ws", "rg"])
+@pytest.mark.parametrize("kind,key,cin,cout", CASES + [c for c in RG_CASES if c not in CASES])
 def test_forward_and_gradients(kind, key, cin, cout, mode, monkeypatch):
     """All kernel generations / arithmetic modes of the forward / input-gradient convolution meet the SAME
     tolerance: the split-bf16 arithmetic (three bf16 pieces per operand, six MFMAs per product block) is
     fp32-accurate.  "tl" = the tile-list kernel (spconv_tl.hip), fed with lists built from the oracle's table;
     "ws" = the weight-stationary kernel (spconv_ws.hip) on every map size, from the pair arrays of those lists, the
-    2^3 stride-2 maps declared as such (=> direct mode for the launches that write their fine side)."""
+    2^3 stride-2 maps declared as such (=> direct mode for the launches that write their fine side).
+    "rg" (round 6) = the register-gather kernel (spconv_rg.hip) on the narrow layers, forward and input gradient, straight from the
+    neighbour table (the module path hands it the table it has: plain here)."""
     from openscene_amd import functional as F_
     from openscene_amd import ops
     ws = mode == "ws"
-    monkeypatch.setattr(F_, "CONV_MODE", "tl" if ws else mode)
-    monkeypatch.setattr(F_, "TL_FWD_MIN_ROWS", (1 << 30) if ws else 0)   # "tl": every map size goes through the tile-list kernel (split launches on small maps)
-    if ws:
+    rg = mode == "rg"
+    monkeypatch.setattr(F_, "CONV_MODE", "tl" if (ws or rg) else mode)
+    monkeypatch.setattr(F_, "TL_FWD_MIN_ROWS", (1 << 30) if (ws or rg) else 0)   # "tl": every map size goes through the tile-list kernel (split launches on small maps)
+    if ws or rg:
         monkeypatch.setattr(F_, "TL_MID_MIN_ROWS", 1 << 30)
-        monkeypatch.setattr(F_, "WS_MAX_ROWS", 1 << 30)
+        monkeypatch.setattr(F_, "WS_MAX_ROWS", (1 << 30) if ws else 0)
+    if ws:
+        monkeypatch.setattr(ops, "rg_eligible", lambda *a: False)        # (the narrow layers too: this mode is about spconv_ws.hip)
+    if rg and not ((kind, key, cin, cout) in RG_CASES and ops.rg_eligible(key[2] ** 3, cin, cout, 1) and ops.rg_eligible(key[2] ** 3, cout, cin, 1)):
+        pytest.skip("shape outside the register-gather kernel")
     if mode in ("tl", "ws") and not ops.tl_eligible(key[2] ** 3, cin, cout):
         pytest.skip("shape outside the tile-list kernel (takes the bf16x6 path, tested above)")
     if ws and key[2] == 1:
@@ -121,7 +132,11 @@ def test_forward_and_gradients(kind, key, cin, cout, mode, monkeypatch):
     fg = feats.to(d).requires_grad_(True)
     wg = w.to(d).requires_grad_(True)
     lists = None
-    if mode in ("tl", "ws") and K > 1:
+    rg_calls = []
+    if rg:
+        real_rg = ops.spconv_fwd_rg
+        monkeypatch.setattr(ops, "spconv_fwd_rg", lambda *a, **kw: (rg_calls.append(1), real_rg(*a, **kw))[1])
+    if mode in ("tl", "ws", "rg") and K > 1:
         lists = (ops.tile_lists(maps[0]), ops.tile_lists(maps[1]) if maps[1] is not maps[0] else None)
         if lists[1] is None:
             lists = (lists[0], lists[0])
@@ -137,6 +152,8 @@ def test_forward_and_gradients(kind, key, cin, cout, mode, monkeypatch):
     close(wg.grad, w64.grad, "weight gradient")
     if ws:      # forward and input gradient both ran on the weight-stationary kernel; direct where the fine side is written
         assert launches == ([si > so_, si < so_] if k == 2 else [False, False]), launches
+    if rg:      # forward and input gradient both ran on the register-gather kernel
+        assert len(rg_calls) == 2, rg_calls
 
 
 def test_out_rows_indirection_and_determinism():
