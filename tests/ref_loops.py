@@ -505,7 +505,7 @@ def replay(g, device):
 MARGIN = 2e-2       # a point whose top-2 scores are closer than this (relative to the largest score) may flip between engines
 
 
-def compare(gold, got, margins, loss_tol=2e-4, what="", agree_tol=0.999):
+def compare(gold, got, margins, loss_tol=2e-4, what="", agree_tol=0.999, update_tol=5e-2):
     """Tolerances of a replay (or of the reference run itself) against the fixture; `margins`: where the top-2 margins come
     from (the fixture's CPU replay).  Returns a dict of the measured deviations.
     Why a GPU replay cannot be held tighter than this (measured, tests/test_reference_loops.py prints it for two arithmetic modes):
@@ -527,7 +527,7 @@ def compare(gold, got, margins, loss_tol=2e-4, what="", agree_tol=0.999):
             if "init:" + key[5:] in got and "running" not in key:
                 w0 = got["init:" + key[5:]].astype(np.float64)        # two Adam steps: compare the UPDATE, not the weights
                 e = np.linalg.norm((a - w0) - (b - w0)) / max(np.linalg.norm(b - w0), 1e-30)
-                assert e <= 5e-2, "%s %s: update off by %.3e" % (what, key, e)
+                assert e <= update_tol, "%s %s: update off by %.3e" % (what, key, e)
             else:
                 e = np.linalg.norm(a - b) / np.linalg.norm(b)
                 assert e <= 1e-3, "%s %s off by %.3e" % (what, key, e)
