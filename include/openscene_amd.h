@@ -602,7 +602,8 @@ typedef struct osn_net_run {
     const osn_net_bn* bns;
     const float* input;          /* [rows(level of op 0), cin of op 0]                                            */
     float* output;               /* forward: [rows, cout] of the op with dst == -1 (may be null if not run)       */
-    const float* goutput;        /* backward: gradient of `output`                                                */
+    const float* goutput;        /* backward: gradient of `output`; may be null when goutput_rows (below) carries every
+                                  * non-zero row of it -- the head then ran on those rows only (round 6)               */
     void* fwd_arena; uint64_t fwd_arena_bytes;
     void* bwd_arena; uint64_t bwd_arena_bytes;
     void* ws; uint64_t ws_bytes;
