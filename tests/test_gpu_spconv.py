@@ -156,6 +156,39 @@ def test_forward_and_gradients(kind, key, cin, cout, mode, monkeypatch):
         assert len(rg_calls) == 2, rg_calls
 
 
+@pytest.mark.parametrize("n_in,n_out,K,cin,cout", [(1, 1, 8, 32, 32), (63, 63, 27, 32, 64), (65, 130, 8, 64, 32), (1000, 257, 27, 64, 64),
+                                                   (300, 300, 125, 32, 32), (5000, 4097, 27, 32, 32)])
+def test_register_gather_kernel_edge_cases(n_in, n_out, K, cin, cout):
+    """spconv_rg.hip on hand-made tables: row counts that are not multiples of the 64-row workgroup, more / fewer input than output rows,
+    offsets whose count is not a multiple of the four waves, rows without any neighbour (zeros), an arbitrary row permutation through
+    out_rows, bitwise reproducibility; against a float64 product through the same table (3e-5 of the tensor max: the bound of every
+    convolution kernel here)."""
+    from openscene_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(n_in * 7 + n_out + K)
+    nbr = torch.randint(0, n_in, (K, n_out), generator=g, dtype=torch.int32)
+    nbr[torch.rand(K, n_out, generator=g) < 0.7] = -1                # ~30 % occupancy
+    if n_out > 3:
+        nbr[:, 2] = -1                                                # a row without any neighbour
+    feats = torch.randn(n_in, cin, generator=g)
+    w = torch.randn(K, cin, cout, generator=g) / np.sqrt(cin * K * 0.3)
+    ref = torch.zeros(n_out, cout, dtype=torch.float64)
+    for k in range(K):
+        on = nbr[k] >= 0
+        ref[on] += feats[nbr[k][on].long()].double() @ w[k].double()
+    assert ops.rg_eligible(K, cin, cout, n_in) and not ops.rg_eligible(K, 96, cout, n_in) and not ops.rg_eligible(1, cin, cout, n_in)
+    wf, _ = ops.weight_prep_tl(w.to(d), want_dgrad=False)
+    out = ops.spconv_fwd_rg(feats.to(d), wf, nbr.to(d), n_out, cout)
+    scale = float(ref.abs().max())
+    assert float((out.cpu().double() - ref).abs().max()) <= 3e-5 * scale
+    if n_out > 3:
+        assert float(out[2].abs().max()) == 0.0
+    assert torch.equal(out, ops.spconv_fwd_rg(feats.to(d), wf, nbr.to(d), n_out, cout)), "not bitwise reproducible"
+    perm = torch.randperm(n_out, generator=g).int()
+    out_p = ops.spconv_fwd_rg(feats.to(d), wf, nbr[:, perm.long()].contiguous().to(d), n_out, cout, out_rows=perm.to(d))
+    assert torch.equal(out, out_p), "the table's row order changed the result"
+
+
 def test_out_rows_indirection_and_determinism():
     from openscene_amd import ops
     cm = cloud("mid")
