@@ -55,6 +55,9 @@ static bool dense_eligible(int cin, int cout) { return (cin & 3) == 0 && cin >= 
 // functional.rg_kernel: the register-gather kernel for the narrow layers (32 / 64 channels on both sides) that neither the tile-list
 // kernel nor a direct weight-stationary launch takes -- before the partial-row weight-stationary kernel and the first-generation one
 static bool rg_eligible(int K, int ca, int cb, int64_t n_src) { return osn_spconv_fwd_rg_ok(n_src > 0 ? n_src : 1, K, ca, cb) != 0; }
+// ... and AHEAD of the tile-list kernel when one side has 32 channels (measured at 101 k rows, tools/micro_rg.py: 32 -> 32 38.8 us against
+// 49.3, 32 -> 64 49.6 / 53.7; 64 -> 64 stays with the tile-list kernel there: 72 against 112)
+static bool rg_first(int K, int ca, int cb, int64_t n_src) { return (ca == 32 || cb == 32) && rg_eligible(K, ca, cb, n_src); }
 static bool x6_eligible(int K, int cin, int cout, int64_t n_out) {
     if ((cin & 3) || cin < 8) return false;
     if (int64_t(3) * K * cout * ((cin + 31) / 32 * 32) >= (int64_t(1) << 30)) return false;
@@ -149,7 +152,7 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
             L.fwd_k[i] = OSN_NET_K_WS_DIRECT;
             L.images[i] |= OSN_NET_IMG_TL_FWD;
             need_ws(osn_spconv_fwd_ws_ws_bytes(n_out, o.K, o.cout, 1));
-        } else if (o.K > 1 && tl_eligible(o.K, o.cin, o.cout, n_in) && tl_rows_ok(net, n_out, o.cin, o.cout)) {
+        } else if (o.K > 1 && tl_eligible(o.K, o.cin, o.cout, n_in) && tl_rows_ok(net, n_out, o.cin, o.cout) && !rg_first(o.K, o.cin, o.cout, n_in)) {
             L.fwd_k[i] = OSN_NET_K_TL;
             L.images[i] |= OSN_NET_IMG_TL_FWD;
             need_ws(osn_spconv_fwd_tl_ws_bytes(n_out, o.K, o.cout, osn_tile_rows(n_out)));
@@ -178,7 +181,8 @@ static int make_layout(const osn_net_desc* net, const int64_t* rows, int trainin
                 L.dgrad_k[i] = OSN_NET_K_WS_DIRECT;
                 L.images[i] |= OSN_NET_IMG_TL_DGRAD;
                 need_ws(osn_spconv_fwd_ws_ws_bytes(n_in, o.K, o.cin, 1));
-            } else if (o.K > 1 && tl_eligible(o.K, o.cout, o.cin, n_out) && tl_eligible(o.K, o.cin, o.cout, n_in) && tl_rows_ok(net, n_in, o.cin, o.cout)) {
+            } else if (o.K > 1 && tl_eligible(o.K, o.cout, o.cin, n_out) && tl_eligible(o.K, o.cin, o.cout, n_in) && tl_rows_ok(net, n_in, o.cin, o.cout) &&
+                       !rg_first(o.K, o.cout, o.cin, n_out)) {
                 L.dgrad_k[i] = OSN_NET_K_TL;
                 L.images[i] |= OSN_NET_IMG_TL_DGRAD;
                 need_ws(osn_spconv_fwd_tl_ws_bytes(n_in, o.K, o.cin, osn_tile_rows(n_in)));

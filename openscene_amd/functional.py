@@ -100,9 +100,12 @@ class SparseConvFunction(Function):
                     if pl is not None and ctx.needs_input_grad[0] and ops.tl_eligible(K, cout, cin, n_out) else None)
             # forward / input gradient: only on maps of at least TL_FWD_MIN_ROWS rows (measured: 20-30 % faster on the
             # 100 k-row maps, a tie at 48 k rows, slower below); 1x1 convs stay on the first-generation kernel
-            fwd_ok = lists_fwd is not None and tl_rows_ok(n_out, cin, cout) and ws_f != "ws_direct"
+            # (a layer with 32 channels on one side goes to the register-gather kernel on ANY map size: rg_first, same rule as csrc/net.hip)
+            rg_first_f = min(cin, cout) == 32 and ops.rg_eligible(K, cin, cout, ctx.n_in)
+            rg_first_b = min(cin, cout) == 32 and ops.rg_eligible(K, cout, cin, n_out)
+            fwd_ok = lists_fwd is not None and tl_rows_ok(n_out, cin, cout) and ws_f != "ws_direct" and not rg_first_f
             bwd_ok = (ctx.needs_input_grad[0] and ops.tl_eligible(K, cout, cin, n_out) and lists_bwd is not None
-                      and tl_rows_ok(ctx.n_in, cin, cout) and ws_b != "ws_direct")
+                      and tl_rows_ok(ctx.n_in, cin, cout) and ws_b != "ws_direct" and not rg_first_b)
             # narrow layers (32 / 64 channels on both sides): the register-gather kernel where neither the tile-list kernel nor a
             # direct weight-stationary launch applies (same rule as csrc/net.hip) -- forward here, input gradient decided here
             rg_f = not fwd_ok and ws_f != "ws_direct" and ops.rg_eligible(K, cin, cout, ctx.n_in)

@@ -74,9 +74,10 @@ def test_planned_kernels_are_the_per_module_choice():
         ws = F_.ws_kernel(o["K"], c_src, c_dst, n_src, n_dst, bool(o["fine_unique"]), dst_fine)
         if ws == "ws_direct":
             return ws
-        if F_.tl_rows_ok(n_dst, o["cin"], o["cout"]):
+        narrow = c_src in (32, 64) and c_dst in (32, 64)
+        if F_.tl_rows_ok(n_dst, o["cin"], o["cout"]) and not (narrow and min(c_src, c_dst) == 32):
             return "tl"
-        if c_src in (32, 64) and c_dst in (32, 64):
+        if narrow:
             return "rg"                             # round 6: the narrow layers, before the partial-row weight-stationary kernel
         return ws or "x6"
     for (i, kf, kd, kw), o in zip(ks, ex.program.ops):

@@ -96,8 +96,8 @@ def test_forward_and_gradients(kind, key, cin, cout, mode, monkeypatch):
     if ws or rg:
         monkeypatch.setattr(F_, "TL_MID_MIN_ROWS", 1 << 30)
         monkeypatch.setattr(F_, "WS_MAX_ROWS", (1 << 30) if ws else 0)
-    if ws:
-        monkeypatch.setattr(ops, "rg_eligible", lambda *a: False)        # (the narrow layers too: this mode is about spconv_ws.hip)
+    if ws or mode == "tl":
+        monkeypatch.setattr(ops, "rg_eligible", lambda *a: False)        # (the narrow layers too: these modes are about spconv_ws.hip / spconv_tl.hip)
     if rg and not ((kind, key, cin, cout) in RG_CASES and ops.rg_eligible(key[2] ** 3, cin, cout, 1) and ops.rg_eligible(key[2] ** 3, cout, cin, 1)):
         pytest.skip("shape outside the register-gather kernel")
     if mode in ("tl", "ws") and not ops.tl_eligible(key[2] ** 3, cin, cout):

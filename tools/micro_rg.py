@@ -31,7 +31,7 @@ def main():
     vox = syn.shuffled(syn.grid_voxels(syn.room_points(0), 0.02), 0)
     cm = CoordinateManager(torch.from_numpy(syn.batch_coords([vox])).to(dev))
     for si, so, ks, cin, cout in ((2, 2, 3, 32, 32), (4, 4, 3, 32, 64), (4, 4, 3, 64, 32), (4, 4, 3, 64, 64), (1, 2, 2, 32, 32), (2, 4, 2, 32, 32),
-                                  (1, 1, 3, 32, 32), (1, 1, 3, 64, 64)):
+                                  (1, 1, 3, 32, 32), (1, 1, 3, 64, 64), (2, 2, 3, 64, 64), (2, 2, 3, 32, 64), (2, 2, 3, 64, 32), (1, 1, 3, 32, 64)):
         K = ks ** 3
         n_in, n_out = cm.size(si), cm.size(so)
         x = torch.randn(n_in, cin, device=dev)
