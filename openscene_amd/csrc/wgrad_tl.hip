@@ -168,11 +168,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_tl_kernel(const float* __restric
     const int a0 = (blockIdx.x / n_cgb) * CA_T;          // first input channel of the workgroup's block
     const int g0 = (blockIdx.x % n_cgb) * CG_T;
     int k, p0, p1, base;
+    int pstep = 32;                                      // pairs between this item's consecutive 32-pair steps
     if (idx_a) {
         const int4 it = items[blockIdx.y];
         k = it.x; p0 = it.y; p1 = it.z;
         if (k < 0) return;
         base = poff[k];
+        // item.w = j | n << 16 (0 = the whole range): the item takes the steps j, j + n, ... of [p0, p1) -- strided items of one row
+        // region walk its rows together (round 6: Z-ordered pair arrays, tools/micro_crowd.py)
+        const int n_it = it.w >> 16;
+        if (n_it > 1) { p0 += 32 * (it.w & 0xFFFF); pstep = 32 * n_it; }
+        if (p0 >= p1) p1 = p0;                           // (an item past the range's last step: nothing to add, zeros are stored)
     } else {
         k = 0; base = 0;
         p0 = blockIdx.y * ident_quota;
@@ -254,9 +260,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tl_kernel(const float* __restric
     };
     valid_now();
     fetch(0);
-    ireg = load_idx(p0 + 32);
+    ireg = load_idx(p0 + pstep);
 
-    for (int p = p0; p < p1; p += 32) {
+    for (int p = p0; p < p1; p += pstep) {
         // ---- split the rows of this step (registers)
         bf16x4 a1[MB], a2[MB], a3[MB], g1[NB], g2[NB], g3[NB];
 #pragma unroll
@@ -278,10 +284,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tl_kernel(const float* __restric
         }
         if (tid < 64) idxbuf[tid >> 5][tid & 31] = ireg;  // indices of the next step
         __syncthreads();
-        if (p + 32 < p1) {
+        if (p + pstep < p1) {
             valid_now();
             fetch(0);                                      // rows of the next step: in flight during the MFMAs
-            ireg = load_idx(p + 64);
+            ireg = load_idx(p + 2 * pstep);
         }
         // ---- fragments by transpose reads: lane i of a 16-lane group points at (pair 8 g + (i >> 2), channels
         // 4 (i & 3) .. + 3) of a 16-channel block and receives channel i of pairs 8 g .. 8 g + 3 (then + 4)

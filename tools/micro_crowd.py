@@ -53,6 +53,12 @@ def main():
             tl = ops.tile_lists(tiles[1], out_rows=tiles[0])
         pl = ops.pair_lists(tl)
         pl_cpu = pl.cpu().numpy()
+        if plan == -2:
+            # the PRODUCT kernel with the probe's region plan: 8 row regions pinned to the 8 XCDs, strided items (item.w = j | n << 16),
+            # written over the pair-list buffer's own item table (the reduction's per-offset ranges no longer apply: timing only)
+            items = W.plan_items(pl_cpu, K, n, tl.bm, 8, True)[0]
+            pl[2048:2048 + 512 * 16].view(torch.int32).copy_(torch.from_numpy(items.reshape(-1)).to(dev))
+            return tl, pl, "partial", None, None
         if plan < 0:
             return tl, pl, None, None, None
         if plan == 0:
@@ -84,33 +90,44 @@ def main():
     workloads["ws_conv_L3_128"] = lambda: ops.spconv_fwd_ws(x3, wf3, tl3, nbr3, n3, K, 128)
     workloads["bn_small_L3_128"] = lambda: ops.bn_forward_train(x3, g3, b3, 1e-5, None, True, rm3, rv3, 0.1)
     res = {}
-    for tag, order, plan in (("alone", None, None), ("beside_PRODUCT_kernel", "tile", -1), ("beside_probe_product_order", "tile", 0),
-                             ("beside_probe_zorder_xcd", "morton", 1)):
+    cases = [("alone", None, None), ("beside_PRODUCT_kernel", "tile", -1), ("beside_PRODUCT_kernel_zorder_xcd_strided", "morton", -2)]
+    if os.environ.get("PROBE", "0") == "1":
+        cases += [("beside_probe_product_order", "tile", 0), ("beside_probe_zorder_xcd", "morton", 1)]
+    lib2 = _lib.load()
+    job = ctypes.create_string_buffer(64)
+    for tag, order, plan in cases:
         cfg = side_setup(order, plan) if order else None
         for name, fn in workloads.items():
             fn()
             torch.cuda.synchronize()
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             if cfg:
                 tl, pl, it_d, first_d, ids_d = cfg
-                if it_d is None:                      # the product's own kernel (158 VGPRs, 2 workgroups per CU) + its reduction
+                s0.record(side)
+                if isinstance(it_d, str):             # the product kernel alone (no reduction) on the strided region items
+                    for _ in range(side_n):
+                        rc = lib2.osn_spconv_wgrad_tl_partial(xs.data_ptr(), gs.data_ptr(), pl.data_ptr(), 0, gw.data_ptr(), n, n, K, c, c,
+                                                              ws.data_ptr(), ws.numel() * 4, ctypes.addressof(job), side.cuda_stream)
+                        assert rc == 0
+                elif it_d is None:                    # the product's own kernel (158 VGPRs, 2 workgroups per CU) + its reduction
                     with torch.cuda.stream(side):
                         for _ in range(side_n):
                             ops.spconv_wgrad_tl(xs, gs, tl, K)
-                for _ in range(side_n if it_d is not None else 0):
+                for _ in range(side_n if (it_d is not None and not isinstance(it_d, str)) else 0):
                     rc = lib.osn_dbg_wgrad_w1(xs.data_ptr(), gs.data_ptr(), pl.data_ptr(), gw.data_ptr(), n, n, K, c, c, ws.data_ptr(),
                                               2 | (1 << 4), 0, it_d.data_ptr(), first_d.data_ptr(), ids_d.data_ptr(), side.cuda_stream)
                     assert rc == 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if cfg:
+                s1.record(side)
             e0.record()
             for _ in range(reps):
                 fn()
             e1.record()
-            s1.record(side)
             torch.cuda.synchronize()
             res["%s/%s_us" % (name, tag)] = round(e0.elapsed_time(e1) / reps * 1e3, 2)
             if cfg:
-                res["%s/%s_side_still_busy_ms_after" % (name, tag)] = round(e1.elapsed_time(s1), 2)
+                res["%s/%s_side_us_per_launch" % (name, tag)] = round(s0.elapsed_time(s1) * 1e3 / side_n, 1)
     print(json.dumps(res, indent=1))
 
 
