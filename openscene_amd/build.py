@@ -45,6 +45,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
+    flags = FLAGS + (["-DOSN_BUILD_TOOLS"] if os.environ.get("OSN_BUILD_TOOLS") == "1" else [])   # tools-only entry points (tools/prof_tl.py)
     cc = hipcc()
     hdrs = _headers()
     jobs = []
@@ -58,7 +59,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         s, o = job
-        cmd = [cc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [cc] + flags + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return job, r
 

@@ -809,10 +809,12 @@ extern "C" int osn_spconv_fwd_tl_pc(const float* in, int64_t n_in, const void* W
                               stream);
 }
 
-// Tools only (not part of include/openscene_amd.h): the same launch with the phase timers of wave 0 of every
-// workgroup written to prof[512][10] (s_memtime ticks; tools/prof_tl.py).
+// Tools only (not part of include/openscene_amd.h, NOT in the product library: built with OSN_BUILD_TOOLS=1 python -m openscene_amd.build):
+// the same launch with the phase timers of wave 0 of every workgroup written to prof[512][10] (s_memtime ticks; tools/prof_tl.py).
+#ifdef OSN_BUILD_TOOLS
 extern "C" int osn_dbg_spconv_fwd_tl_prof(const float* in, int64_t n_in, const void* Wp, const void* tl,
                                           const int32_t* out_rows, float* out, int64_t n_out, int K, int cin, int cout,
                                           int bm, void* ws, size_t ws_bytes, long long* prof, osn_stream_t stream) {
     return spconv_fwd_tl_impl(in, n_in, Wp, tl, out_rows, out, nullptr, n_out, K, cin, cout, bm, ws, ws_bytes, nullptr, prof, stream);
 }
+#endif

@@ -21,6 +21,8 @@ PHASES2 = ["prologue", "list load", "counted wait (DMA landed)", "barrier", "tai
 def main():
     dev = torch.device("cuda", 0)
     lib = _lib.load()
+    if not hasattr(lib, "osn_dbg_spconv_fwd_tl_prof"):
+        raise SystemExit("the product library has no phase-timer entry point: rebuild with  OSN_BUILD_TOOLS=1 python -m openscene_amd.build --force")
     fn = lib.osn_dbg_spconv_fwd_tl_prof
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
     fn.restype = i32
