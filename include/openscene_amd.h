@@ -656,9 +656,7 @@ typedef struct osn_map_level {               /* one pyramid level (osn_coords_un
 typedef struct osn_map_job {
     int32_t lvl_in, lvl_out;     /* table of lvl_in probed at the coordinates of lvl_out                          */
     int32_t ksize, scale;        /* kernel size, offset scale (dilation x tensor stride of the input map)         */
-    int32_t self_map;            /* bit 0: odd kernel over the table's own rows (osn_kmap_build_self; no nbr_bwd);
-                                  * bit 1 (round 6): nbr_fwd / nbr_bwd / counts EXIST already (an earlier job built them):
-                                  * only the tile order, tile lists and pair lists are built                        */
+    int32_t self_map;            /* 1: odd kernel over the table's own rows (osn_kmap_build_self; no nbr_bwd)     */
     int32_t stream;              /* index into `streams`                                                          */
     int32_t bm_fwd, bm_bwd;      /* tile rows of the lists (osn_tile_rows)                                        */
     int32_t* nbr_fwd; int32_t* nbr_bwd; int64_t* counts;

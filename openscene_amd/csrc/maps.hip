@@ -41,11 +41,7 @@ extern "C" int osn_maps_build(const osn_map_level* levels, int n_levels, const o
         const int K = q.ksize * q.ksize * q.ksize;
         OSN_REQUIRE(q.nbr_fwd && li.rows >= 1 && lo.rows >= 1, OSN_E_ARG, "osn_maps_build: job %d: null table or empty level", j);
         int rc;
-        if (q.self_map & 2) {
-            // the tables of this map were built by an earlier job (round 6: the tables the encoder's first stages read are queued in
-            // front of the forward pass, everything else beside it): only tile order / lists / pair lists here
-            rc = OSN_OK;
-        } else if (q.self_map & 1) {
+        if (q.self_map) {
             OSN_REQUIRE(q.lvl_in == q.lvl_out && (q.ksize & 1), OSN_E_ARG, "osn_maps_build: job %d: a self map needs one level and an odd kernel", j);
             rc = osn_kmap_build_self(li.keys, li.vals, li.cap, li.coords4, li.rows, q.ksize, q.scale, q.nbr_fwd, q.counts, st);
         } else {

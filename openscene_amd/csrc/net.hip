@@ -306,9 +306,7 @@ static int run_conv(int kernel, const float* in, int64_t n_in, float* out, int64
                                      cin, cout, run->ws, size_t(run->ws_bytes), stream);
         case OSN_NET_K_RG:
             OSN_REQUIRE(img_tl && nbr, OSN_E_ARG, "osn_net: op %d: the register-gather kernel needs the tile-list weight image and the table", op);
-            // (the PLAIN table, also where a tile-ordered copy exists: 22.0 against 21.4 us on it -- and the launch then depends on
-            //  nothing but the table itself, so the copy can still be sorting beside the first stages of an inference forward pass)
-            return osn_spconv_fwd_rg(in, n_in, img_tl, nbr, nullptr, out, n_out, K, cin, cout, stream);
+            return osn_spconv_fwd_rg(in, n_in, img_tl, t_tbl ? t_tbl : nbr, t_tbl ? t_rows : nullptr, out, n_out, K, cin, cout, stream);
         case OSN_NET_K_STEM:
             OSN_REQUIRE(nbr && W, OSN_E_ARG, "osn_net: op %d: the stem kernel needs the plain table and the fp32 weight", op);
             return osn_stem_conv_fwd(in, W, nbr, out, n_out, K, cin, cout, stream);

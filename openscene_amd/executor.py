@@ -33,8 +33,6 @@ ROW_SPARSE_HEAD = os.environ.get("OSN_ROW_SPARSE_HEAD", "1") != "0"
 # convolution that follows reads the fp32 kernel itself, no image.  The refresh is queued on the side stream and the forward pass is
 # played as ops [0, 1) -> wait for the refresh -> ops [1, n): refresh and stem run side by side (round 5's A/B: -0.03 ms alone,
 # -0.08 ms with the buffer-resource gathers, same loss bits; profiles/r05_s1_knobs_ab.txt).
-# Inference: the tables the first stages read in front of the pass, the other map products beside those stages (see _run_forward)
-EARLY_MAPS = os.environ.get("OSN_EARLY_MAPS", "1") != "0"
 _DRY_RUN = False        # tools/dryrun only: accept host tensors (a null HIP runtime logs the launches instead of running them)
 
 _OP = np.dtype([(n, "<i4") for n in ("K", "cin", "cout", "lvl_in", "lvl_out", "map", "transposed", "src", "dst", "bn", "relu",
@@ -366,6 +364,7 @@ class UNetExecutor:
         dev = feats.device
         lib = ops._prep(dev)
         training = bool(model.training)
+        cm.prebuild(pairs=True if grad else "ws")
         rows = [cm.size(s) for s in p.STRIDES]
         if feats.shape[0] != rows[0]:
             raise ValueError("%d feature rows for %d voxels" % (feats.shape[0], rows[0]))
@@ -373,27 +372,6 @@ class UNetExecutor:
         # backward kernels' scratch -- a training-mode forward under no_grad (grad False, training True) asked for the inference
         # plan's smaller workspace and failed the run's size check whenever the pooled buffer had not already grown
         self._plan_query(lib, rows, grad or training)
-        # Inference builds its maps inside the pass (maps_only: ~1 ms in front of a 2.7 ms forward pass).  The first stages -- the stem
-        # and the 32 / 64-channel encoder layers on the register-gather kernel -- read nothing but plain neighbour tables: those tables
-        # are queued first, every other map product (tile orders, tile lists, pair arrays, the remaining tables) on a second stream
-        # beside the stages [0, n_early), and the rest of the pass waits for that stream.  Same tensors, same launches, same results.
-        n_early, maps_late = 0, None
-        if EARLY_MAPS and not grad and not _DRY_RUN and feats.is_cuda:
-            early = set()
-            while n_early < len(p.ops):
-                o, kind = p.ops[n_early], K_NAMES[int(self._kf[n_early])]
-                if not (kind in ("stem", "rg") or (kind == "dense" and o["map"] < 0)):
-                    break
-                if o["map"] >= 0:
-                    if o["transposed"]:
-                        break
-                    early.add(tuple(p.map_keys[o["map"]][:3]))
-                n_early += 1
-            if n_early >= 2:
-                maps_late = cm.prebuild(pairs="ws", early=early)
-        if maps_late is None:
-            n_early = 0
-            cm.prebuild(pairs=True if grad else "ws")
         st = _PassState()
         st.rows, st.training, st.feats, st.cm = rows, training, feats, cm
         st.maps, keep_m = self._maps(cm, grad)
@@ -424,13 +402,6 @@ class UNetExecutor:
                    side if events else None, ws2.data_ptr() if (events and ws2 is not None) else None,
                    ws2.numel() if (events and ws2 is not None) else 0, events, None, None, None, 0)
         with ops._Dev(dev):
-            if maps_late is not None and 0 < n_early < end:
-                run.first_op, run.end_op = 0, n_early
-                check(lib.osn_net_forward(ctypes.addressof(self.desc), ctypes.addressof(run), ops._stream(dev)), "osn_net_forward")
-                torch.cuda.current_stream(dev).wait_event(maps_late)
-                run.first_op, run.end_op = n_early, end
-            elif maps_late is not None:
-                torch.cuda.current_stream(dev).wait_event(maps_late)
             if prep_done is not None and end > 1:
                 run.first_op, run.end_op = 0, 1                  # the stem (fp32 kernel, no image) beside the refresh ...
                 check(lib.osn_net_forward(ctypes.addressof(self.desc), ctypes.addressof(run), ops._stream(dev)), "osn_net_forward")

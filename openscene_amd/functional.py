@@ -118,7 +118,7 @@ class SparseConvFunction(Function):
                     ctx.wp_dgrad, ctx.tl_bwd = ops.weight_image(kernel, flip, True, ops.PREP_TL), lists_bwd
                 elif ws_b is not None:
                     ctx.ws_bwd = (ops.weight_image(kernel, flip, True, ops.PREP_TL), pl, swap_f if flip else not swap_f, ws_b == "ws_direct")
-                return ops.spconv_fwd_rg(feats, ops.weight_image(kernel, False, False, ops.PREP_TL), nbr_fwd, n_out, cout)      # (plain table: csrc/net.hip)
+                return ops.spconv_fwd_rg(feats, ops.weight_image(kernel, False, False, ops.PREP_TL), tbl, n_out, cout, out_rows=rows)
             if ws_b is not None and not bwd_ok:
                 ctx.ws_bwd = (ops.weight_image(kernel, flip, True, ops.PREP_TL), pl, swap_f if flip else not swap_f,
                               ws_b == "ws_direct")
@@ -186,7 +186,7 @@ class SparseConvFunction(Function):
                 gin = ops.dense_fwd(gout, ctx.dense_bwd, cin)
                 ctx.dense_bwd = None
             elif ctx.rg_bwd is not None:
-                gin = ops.spconv_fwd_rg(gout, ctx.rg_bwd, nbr_bwd, ctx.n_in, cin)
+                gin = ops.spconv_fwd_rg(gout, ctx.rg_bwd, tbl, ctx.n_in, cin, out_rows=rows)
                 ctx.rg_bwd = None
             elif ctx.tl_bwd is not None:
                 gin = ops.spconv_fwd_tl(gout, ctx.wp_dgrad, ctx.tl_bwd, ctx.n_in, K, cin)

@@ -339,18 +339,6 @@ def _addr(v):
     return 0 if v is None else (int(v) if isinstance(v, int) else v.data_ptr())
 
 
-_maps_side = {}
-
-
-def maps_stream(dev):
-    """The stream the LATE part of a split map build runs on (sparse.CoordinateManager.prebuild(early=...)), one per device."""
-    i = _idx(dev)
-    s = _maps_side.get(i)
-    if s is None:
-        s = _maps_side[i] = torch.cuda.Stream(device=i)
-    return s
-
-
 def maps_build(levels, jobs, dev, sort_rows):
     """levels: [(coords4, HashTable, rows)]; jobs: list of dicts with the fields of osn_map_job (tensors, device addresses
     or None for the pointers, `stream` = 0 .. MAPS_STREAMS - 1); sort_rows: rows of the largest table that gets tile-ordered (scratch

@@ -113,7 +113,7 @@ class CoordinateManager:
                 self._kmaps[key] = ops.kmap_count(fwd) if fwd is not None else None
         return self._kmaps[key]
 
-    def prebuild(self, strides=(2, 4, 8, 16), kernel_sizes=(3,), stem_kernel=5, pairs=False, early=None):
+    def prebuild(self, strides=(2, 4, 8, 16), kernel_sizes=(3,), stem_kernel=5, pairs=False):
         """Build every kernel map (and any level of the pyramid the constructor did not create) up front, before any
         heavy kernel is queued: the host then runs ahead of the GPU for the rest of the forward/backward pass instead of
         stopping at every first use of a map.  (The pyramid's levels 1 ... 16 were built by the constructor with one
@@ -124,11 +124,8 @@ class CoordinateManager:
         for s in strides:
             self.coords(s)
         levels = (1,) + tuple(strides)
-        late = None
         if self.device.type == "cuda" and all(self.size(s) > 0 for s in levels):
-            late = self._prebuild_fast(levels, kernel_sizes, stem_kernel, pairs, early)
-        if early is not None:
-            return late             # (an event, or None when there was nothing to build: the caches were filled before)
+            self._prebuild_fast(levels, kernel_sizes, stem_kernel, pairs)
         if stem_kernel:
             self.kmap(1, 1, stem_kernel)
             self.kmap_tiles(1, 1, stem_kernel)
@@ -149,15 +146,11 @@ class CoordinateManager:
         """kmap_tiles' rule: which tables get a tile-ordered copy."""
         return K <= 32 and rows >= self.SORT_MIN_ROWS and not (K <= 8 and rows < self.SORT_MIN_ROWS_K8)
 
-    def _prebuild_fast(self, levels, kernel_sizes, stem_kernel, pairs, early=None):
+    def _prebuild_fast(self, levels, kernel_sizes, stem_kernel, pairs):
         """The maps prebuild() asks for, not cached yet, as jobs of one ops.maps_build call; results land in the caches
         kmap() / kmap_counts() / kmap_tiles() / kmap_lists() read -- the same tensors the per-map path would create.
         The GPU is idle when this runs (the pyramid's size read-back has just returned), so the launches go out first:
-        ONE allocation, addresses by arithmetic, the C call -- and only then the tensor views over the allocation.
-        early (round 6; a set of (in stride, out stride, kernel size)): the TABLES of these maps are queued on the current stream, every
-        other product -- the other maps, and the tile order / lists / pair arrays of the early ones -- on a second stream behind them;
-        returns the event that second stream records at its end (the caller -- the network executor's forward pass -- waits for it in
-        front of the first stage that reads anything but an early table).  Same tensors, same contents."""
+        ONE allocation, addresses by arithmetic, the C call -- and only then the tensor views over the allocation."""
         dev = self.device
         index = {s: i for i, s in enumerate(levels)}
         specs = ([(1, 1, stem_kernel)] if stem_kernel else []) + [(s, s, k) for s in levels for k in kernel_sizes] + \
@@ -209,35 +202,7 @@ class CoordinateManager:
                 if f in e:
                     q[f] = base + e[f][0]
             jobs.append(q)
-        late_event = None
-        lv = [(self._coords[s], self._tables[s], self.size(s)) for s in levels]
-        if early:
-            first, rest = [], []
-            for e, q in zip(plan, jobs):
-                si, so, k, _d = e["key"]
-                if (si, so, k) in early:
-                    first.append({n: v for n, v in q.items() if n in ("lvl_in", "lvl_out", "ksize", "scale", "self_map", "stream", "nbr_fwd", "nbr_bwd", "counts")})
-                    if any(n in q for n in ("sorted_fwd", "sorted_bwd", "tl_fwd", "tl_bwd", "pl_fwd")):
-                        more = dict(q)
-                        more["self_map"] = int(q["self_map"]) | 2          # tables exist: tile order / lists / pair arrays only
-                        rest.append(more)
-                else:
-                    rest.append(q)
-            main = torch.cuda.current_stream(dev)
-            if first:
-                ops.maps_build(lv, first, dev, 0)
-            if rest:
-                side = ops.maps_stream(dev)
-                side.wait_stream(main)                          # the pyramid and the early tables are in the main stream's past
-                arena.record_stream(side)
-                for c, t, _n in lv:
-                    c.record_stream(side); t.keys.record_stream(side); t.vals.record_stream(side)
-                with torch.cuda.stream(side):
-                    ops.maps_build(lv, rest, dev, sort_rows)
-                    late_event = torch.cuda.Event()
-                    late_event.record(side)
-        else:
-            ops.maps_build(lv, jobs, dev, sort_rows)
+        ops.maps_build([(self._coords[s], self._tables[s], self.size(s)) for s in levels], jobs, dev, sort_rows)
 
         # ---- the launches are queued; now the views the rest of the library works with
         def view(e, f, dtype, shape):
@@ -265,7 +230,6 @@ class CoordinateManager:
                 if "pl_fwd" in e:
                     lf.pairs = view(e, "pl_fwd", torch.uint8, (e["pl_fwd"][1],))
                 self._kmaps[("lists",) + key] = (lf, lb)
-        return late_event
 
     def tensors(self):
         """Every device tensor this manager owns (coordinates, hash tables, parent maps, kernel maps, tile
