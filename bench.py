@@ -1158,6 +1158,27 @@ def main():
         same = float((torch_call_site() == query_distill(pred, text, inds_reverse)).float().mean())
         qres["torch_call_site"] = {"ms": qt_ms, "speedup_of_query_distill": qt_ms / q_ms, "labels_equal_frac": same,
                                    "what": "predictions[inds_reverse].half() @ text.t(); torch.max(.., 1)[1] through torch (run/evaluate.py:290-292 unchanged)"}
+        # round 6: the SAME three lines on the output of an accelerated foreign class (drop_in.py wraps inference outputs): the row gather
+        # stays lazy and the matmul is osn_cosine_query with the score matrix (openscene_amd/lazy_rows.py) -- no edit to evaluate.py
+        from openscene_amd.lazy_rows import wrap_output
+
+        def lazy_call_site():
+            with torch.no_grad():
+                predictions = wrap_output(pred)[inds_reverse, :]
+                sc = predictions.half() @ text.t()
+                return torch.max(sc, 1)[1]
+        for _ in range(3):
+            lazy_call_site()
+        torch.cuda.synchronize(device)
+        e0.record()
+        for _ in range(reps):
+            lazy_call_site()
+        e1.record()
+        torch.cuda.synchronize(device)
+        ql_ms = e0.elapsed_time(e1) / reps
+        qres["call_site_unchanged"] = {"ms": ql_ms, "labels_equal_query_distill": bool(torch.equal(lazy_call_site(), query_distill(pred, text, inds_reverse))),
+                                       "what": "the same three lines on an accelerated model's inference output (lazy row gather -> osn_cosine_query with scores "
+                                               "+ torch.max): what an UNCHANGED run/evaluate.py:290-292 runs behind the MinkowskiEngine alias"}
         # Matterport-160-shaped query (configs[3]): 500 k points x 160 labels, with the fp16 score matrix
         n2, c2 = 500000, 160
         x2 = torch.randn(n2 // 4, out_dim, generator=gq).to(device)

@@ -77,6 +77,17 @@ int osn_coords_unique_async(const int32_t* coords4, int64_t n_max, const int32_t
                             int32_t* inverse, int32_t* first, int32_t* count_dev, int32_t* err_dev,
                             void* ws, size_t ws_bytes, osn_stream_t stream);
 
+/* The whole coordinate pyramid of a scene from ONE call (models/mink_unet.py:52-74: conv1p1s2 ... conv4p8s2 create four stride-2
+ * levels below the input's): level i = the unique rows of level i - 1 quantised to strides[i], queued back to back with the row
+ * counts in device memory -- osn_coords_unique_async per level, with one preset launch for all tables and counters and the flag pass
+ * folded into the scan (31 instead of 45 dependent launches for five levels).  Every per-level array is sized for n0 rows / `cap`
+ * slots; counts_dev[0 .. n_levels) receive the unique rows per level, counts_dev[n_levels] the sticky range-error flag (all zeroed
+ * here); the caller reads them back ONCE.  Pointer arrays are HOST arrays of device pointers.  Results: bit for bit the per-level calls'. */
+int osn_coords_pyramid_async(const int32_t* coords4, int64_t n0, const int32_t* strides, int n_levels,
+                             uint64_t* const* table_keys, int32_t* const* table_vals, int64_t cap,
+                             int32_t* const* out_coords4, int32_t* const* inverse, int32_t* const* first,
+                             int32_t* counts_dev, void* ws, size_t ws_bytes, osn_stream_t stream);
+
 /* Replaces [ME] CoordinateManager.kernel_map (HYPER_CUBE region).  Offsets
  * enumerate with x fastest; odd ksize centred, even ksize spans [0,ksize); all
  * multiplied by `offset_scale` (= dilation * tensor stride of the INPUT map).  */
@@ -595,6 +606,10 @@ typedef struct osn_events osn_events_t;       /* pool of HIP events for the fork
  * plays the last segment (flags 0) joins everything.  Input gradients a later segment reads are joined by their own events
  * either way.                                                                                                      */
 #define OSN_NET_RUN_NO_JOIN 1
+/* osn_net_forward, evaluation mode: by default a stage's batch norm (+ residual) (+ ReLU) (+ cat store) is applied in the EPILOGUE of
+ * the kernel that finishes the stage's convolution (csrc/epilogue.h: same expression, bitwise the separate launch); this flag keeps
+ * the separate osn_bn_apply2 launch (A/B, tests).                                                                         */
+#define OSN_NET_RUN_NO_BN_EPILOGUE 2
 typedef struct osn_net_run {
     const int64_t* level_rows;   /* [n_levels] rows of every pyramid level                                        */
     const osn_net_map* maps;

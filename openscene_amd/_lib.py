@@ -22,6 +22,7 @@ PROTOTYPES = {
     "osn_coords_unique_ws_bytes": (_sz, [_i64]),
     "osn_coords_unique": (_i32, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_i64), _vp, _sz, _vp]),
     "osn_coords_unique_async": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "osn_coords_pyramid_async": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "osn_kmap_build": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "osn_kmap_build_self": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "osn_kmap_transpose": (_i32, [_vp, _i64, _i32, _i64, _vp, _vp]),

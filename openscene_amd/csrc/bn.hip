@@ -6,6 +6,7 @@
 // Function parity with torch.nn.BatchNorm1d as wrapped by MinkowskiBatchNorm,
 // MinkowskiReLU and the BasicBlock residual add.
 #include "common.h"
+#include "epilogue.h"
 
 namespace osn {
 
@@ -35,8 +36,6 @@ __device__ inline float4 gy_load(const GySrc& s, int64_t r, int col) {
     return g;
 }
 
-__device__ inline float bn_val(float x, float mu, float is, float ga, float be);
-__device__ inline float bn_is(float var, float eps);
 
 struct ColReducePlan {
     int n_rb;            // row blocks
@@ -209,10 +208,7 @@ __global__ __launch_bounds__(FIN_COLS * FIN_PARTS) void bn_bwd_finalize_kernel(c
 
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-// The normalised value, ONE definition for the forward kernels and for the backward kernels that recompute the ReLU mask
-// from x instead of reading y (round 4): explicit fma so that both sides round identically whatever the surrounding code.
-__device__ inline float bn_val(float x, float mu, float is, float ga, float be) { return __fmaf_rn((x - mu) * is, ga, be); }
-__device__ inline float bn_is(float var, float eps) { return 1.f / sqrtf(var + eps); }
+// (bn_val / bn_is: epilogue.h -- one definition shared with the convolution kernels' evaluation-mode epilogues)
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ var, const float* __restrict__ gamma,

@@ -7,6 +7,7 @@
 // atomicMin on the row index followed by a prefix scan (no order-dependent
 // atomics on the numbering itself).
 #include "common.h"
+#include "coords_impl.h"
 
 namespace osn {
 
@@ -28,9 +29,13 @@ __device__ inline int wave_incl_scan(int v, int lane) {
 // (every kernel of the unique pipeline takes the row count either from the host (n) or, when n_dev is given, from device
 // memory: a level of the coordinate pyramid can then be queued before the previous level's count has reached the host;
 // the grid is sized by an upper bound and the surplus threads leave)
+// FLAG (the pyramid's batched builder): `in` is not read -- the unique flag of row i (its table slot holds i: the first
+// occurrence) is computed here from (vals, slot_of) and written to flag_out: unique_flag_kernel and its launch folded in
+template <bool FLAG>
 __global__ __launch_bounds__(SCAN_TPB) void scan_block_kernel(const int* __restrict__ in, int* __restrict__ out,
                                                               int* __restrict__ sums, int64_t n,
-                                                              const int32_t* __restrict__ n_dev) {
+                                                              const int32_t* __restrict__ n_dev, const int32_t* __restrict__ vals,
+                                                              const int32_t* __restrict__ slot_of, int* __restrict__ flag_out) {
     if (n_dev) n = *n_dev;
     __shared__ int wave_tot[SCAN_TPB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -39,7 +44,16 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_block_kernel(const int* __restr
     int s = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_IPT; ++j) {
-        v[j] = (base + j < n) ? in[base + j] : 0;
+        if constexpr (FLAG) {
+            v[j] = 0;
+            if (base + j < n) {
+                const int sl = slot_of[base + j];
+                v[j] = (sl >= 0 && vals[sl] == int(base + j)) ? 1 : 0;
+                flag_out[base + j] = v[j];
+            }
+        } else {
+            v[j] = (base + j < n) ? in[base + j] : 0;
+        }
         s += v[j];
     }
     int incl = wave_incl_scan(s, lane);
@@ -101,10 +115,15 @@ size_t exclusive_scan_sums_count(int64_t n) { return size_t(cdiv(n > 0 ? n : 1, 
 
 // n = (upper bound of) the element count; n_dev (nullable) the actual count in device memory; total_out (nullable) also
 // receives the total
+// flag_vals / flag_slot_of (both or neither): scan the unique flags computed from them on the fly; they are also written to `in`
 int exclusive_scan_i32_dev(const int* in, int* out, int* sums, int64_t n, hipStream_t st, const int32_t* n_dev,
-                           int32_t* total_out) {
+                           int32_t* total_out, const int32_t* flag_vals = nullptr, const int32_t* flag_slot_of = nullptr) {
     const int nb = int(cdiv(n, SCAN_BLOCK));
-    hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(SCAN_TPB), 0, st, in, out, sums, n, n_dev);
+    if (flag_vals)
+        hipLaunchKernelGGL(scan_block_kernel<true>, dim3(nb), dim3(SCAN_TPB), 0, st, in, out, sums, n, n_dev, flag_vals, flag_slot_of,
+                           const_cast<int*>(in));
+    else
+        hipLaunchKernelGGL(scan_block_kernel<false>, dim3(nb), dim3(SCAN_TPB), 0, st, in, out, sums, n, n_dev, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nb, total_out);
     hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(SCAN_TPB), 0, st, out, sums, n, n_dev);
     OSN_LAUNCH_CHECK();
@@ -273,6 +292,48 @@ __global__ void kmap_count_kernel(const int32_t* __restrict__ nbr, int64_t n_out
     }
 }
 
+// ---- presets of many regions in one launch (the map builder's ~20 hipMemsetAsync calls per scene were 3 - 8 us launches each)
+__global__ __launch_bounds__(256) void fill_batch_kernel(const FillJobs jobs) {
+    const FillJob& jb = jobs.j[blockIdx.y];
+    char* p = static_cast<char*>(jb.ptr);
+    const uint64_t bytes = jb.bytes;
+    const uint32_t v = jb.value;
+    // head up to the first 16-byte boundary and tail behind the last one: 4-byte stores by the first threads of block 0
+    const uint64_t head = (16u - (reinterpret_cast<uintptr_t>(p) & 15u)) & 15u;
+    const uint64_t h = head < bytes ? head : bytes;
+    const uint64_t mid = (bytes - h) & ~uint64_t(15);
+    const uint64_t tail = bytes - h - mid;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < h / 4) reinterpret_cast<uint32_t*>(p)[threadIdx.x] = v;
+        if (threadIdx.x >= 64 && threadIdx.x - 64 < tail / 4) reinterpret_cast<uint32_t*>(p + h + mid)[threadIdx.x - 64] = v;
+    }
+    uint4* q = reinterpret_cast<uint4*>(p + h);
+    const uint4 vv = make_uint4(v, v, v, v);
+    const uint64_t n16 = mid >> 4;
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n16; i += uint64_t(gridDim.x) * 256) q[i] = vv;
+}
+
+int fill_batch(const FillJob* jobs, int n, hipStream_t st) {
+    for (int b0 = 0; b0 < n; b0 += FILL_BATCH) {
+        FillJobs fj;
+        const int nb = n - b0 < FILL_BATCH ? n - b0 : FILL_BATCH;
+        uint64_t big = 0;
+        for (int i = 0; i < nb; ++i) {
+            fj.j[i] = jobs[b0 + i];
+            OSN_REQUIRE((reinterpret_cast<uintptr_t>(fj.j[i].ptr) & 3u) == 0 && (fj.j[i].bytes & 3u) == 0, OSN_E_ARG,
+                        "fill_batch: region %d is not 4-byte aligned", b0 + i);
+            if (fj.j[i].bytes > big) big = fj.j[i].bytes;
+        }
+        for (int i = nb; i < FILL_BATCH; ++i) fj.j[i] = FillJob{nullptr, 0, 0, 0};
+        int64_t gx = cdiv(int64_t(big >> 4), 256 * 8);
+        if (gx < 1) gx = 1;
+        if (gx > 2048) gx = 2048;
+        hipLaunchKernelGGL(fill_batch_kernel, dim3(unsigned(gx), unsigned(nb)), dim3(256), 0, st, fj);
+        OSN_LAUNCH_CHECK();
+    }
+    return OSN_OK;
+}
+
 }  // namespace osn
 
 using namespace osn;
@@ -316,17 +377,21 @@ namespace {
 // device flag (set to 1 on a coordinate outside the packable range; zeroed by the caller).
 int queue_unique(const int32_t* coords4, int64_t n, const int32_t* n_dev, int stride, uint64_t* table_keys,
                  int32_t* table_vals, int64_t cap, int32_t* out_coords4, int32_t* inverse, int32_t* first,
-                 const UniqueWs& w, int* err, int32_t* count_out, hipStream_t st) {
-    OSN_HIP(hipMemsetAsync(table_keys, 0xFF, size_t(cap) * 8, st));
-    OSN_HIP(hipMemsetAsync(table_vals, 0x7F, size_t(cap) * 4, st));
+                 const UniqueWs& w, int* err, int32_t* count_out, hipStream_t st, bool batched = false) {
+    // batched (osn_coords_pyramid_async): the tables were preset by the caller's one fill launch, the flag pass rides in the scan
+    if (!batched) {
+        OSN_HIP(hipMemsetAsync(table_keys, 0xFF, size_t(cap) * 8, st));
+        OSN_HIP(hipMemsetAsync(table_vals, 0x7F, size_t(cap) * 4, st));
+    }
     const int T = 256;
     const dim3 grid(cdiv(n, T));
     const int4* c4 = reinterpret_cast<const int4*>(coords4);
     hipLaunchKernelGGL(hash_insert_kernel, grid, dim3(T), 0, st, c4, n, stride, table_keys, table_vals,
                        uint32_t(cap - 1), w.slot_of, err, n_dev);
-    hipLaunchKernelGGL(unique_flag_kernel, grid, dim3(T), 0, st, table_vals, w.slot_of, w.flag, n, n_dev);
+    if (!batched) hipLaunchKernelGGL(unique_flag_kernel, grid, dim3(T), 0, st, table_vals, w.slot_of, w.flag, n, n_dev);
     OSN_LAUNCH_CHECK();
-    int rc = exclusive_scan_i32_dev(w.flag, w.rank, w.sums, n, st, n_dev, count_out);
+    int rc = batched ? exclusive_scan_i32_dev(w.flag, w.rank, w.sums, n, st, n_dev, count_out, table_vals, w.slot_of)
+                     : exclusive_scan_i32_dev(w.flag, w.rank, w.sums, n, st, n_dev, count_out);
     if (rc) return rc;
     hipLaunchKernelGGL(unique_emit_kernel, grid, dim3(T), 0, st, c4, n, stride, table_vals, w.slot_of, w.flag, w.rank,
                        reinterpret_cast<int4*>(out_coords4), inverse, first, n_dev);
@@ -394,14 +459,57 @@ extern "C" int osn_coords_unique_async(const int32_t* coords4, int64_t n_max, co
                         count_dev, st);
 }
 
+// The whole pyramid from one call (round 6): what coords_pyramid() issued as one osn_coords_unique_async per level -- per level two
+// memsets and seven launches, 45 dependent launches of 2 - 9 us for five levels -- with ONE preset launch for every table and the
+// counters, and the unique-flag pass folded into the scan: 1 + 6 per level.  Level i is built from level i - 1's output with its row
+// count still in device memory; results are bit for bit those of the per-level calls.
+extern "C" int osn_coords_pyramid_async(const int32_t* coords4, int64_t n0, const int32_t* strides, int n_levels,
+                                        uint64_t* const* table_keys, int32_t* const* table_vals, int64_t cap,
+                                        int32_t* const* out_coords4, int32_t* const* inverse, int32_t* const* first,
+                                        int32_t* counts_dev, void* ws, size_t ws_bytes, osn_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OSN_REQUIRE(n0 >= 1 && n0 < (int64_t(1) << 31) && n_levels >= 1 && n_levels <= 16, OSN_E_ARG, "osn_coords_pyramid_async: n0=%lld, %d levels", (long long)n0, n_levels);
+    OSN_REQUIRE(cap >= 2 * n0 && (cap & (cap - 1)) == 0, OSN_E_ARG, "osn_coords_pyramid_async: cap=%lld must be a power of two >= 2 n0", (long long)cap);
+    OSN_REQUIRE(coords4 && strides && table_keys && table_vals && out_coords4 && inverse && first && counts_dev, OSN_E_ARG, "osn_coords_pyramid_async: null pointer");
+    UniqueWs w = carve_unique(ws, n0);
+    OSN_REQUIRE(ws && ws_bytes >= w.bytes, OSN_E_WS, "osn_coords_pyramid_async: workspace %zu < %zu", ws_bytes, w.bytes);
+    FillJob fills[2 * 16 + 1];
+    int nf = 0;
+    fills[nf++] = FillJob{counts_dev, uint64_t(n_levels + 1) * 4u, 0u, 0u};
+    for (int i = 0; i < n_levels; ++i) {
+        OSN_REQUIRE(strides[i] >= 1 && table_keys[i] && table_vals[i] && out_coords4[i] && inverse[i] && first[i] && aligned16(out_coords4[i]), OSN_E_ARG,
+                    "osn_coords_pyramid_async: level %d: null / unaligned pointer or stride < 1", i);
+        fills[nf++] = FillJob{table_keys[i], uint64_t(cap) * 8u, 0xFFFFFFFFu, 0u};
+        fills[nf++] = FillJob{table_vals[i], uint64_t(cap) * 4u, 0x7F7F7F7Fu, 0u};
+    }
+    OSN_REQUIRE(aligned16(coords4), OSN_E_ARG, "osn_coords_pyramid_async: coords must be 16-byte aligned");
+    int rc = fill_batch(fills, nf, st);
+    if (rc) return rc;
+    const int32_t* prev = coords4;
+    const int32_t* n_dev = nullptr;
+    for (int i = 0; i < n_levels; ++i) {
+        rc = queue_unique(prev, n0, n_dev, strides[i], table_keys[i], table_vals[i], cap, out_coords4[i], inverse[i], first[i], w,
+                          counts_dev + n_levels, counts_dev + i, st, true);
+        if (rc) return rc;
+        prev = out_coords4[i];
+        n_dev = counts_dev + i;
+    }
+    return OSN_OK;
+}
+
 extern "C" int osn_kmap_build(const uint64_t* in_table_keys, const int32_t* in_table_vals, int64_t cap,
                               const int32_t* out_coords4, int64_t n_out, int ksize, int offset_scale, int32_t* nbr,
                               int64_t* counts, osn_stream_t stream) {
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    return kmap_build_impl(in_table_keys, in_table_vals, cap, out_coords4, n_out, ksize, offset_scale, nbr, counts, false,
+                           static_cast<hipStream_t>(stream));
+}
+
+int osn::kmap_build_impl(const uint64_t* in_table_keys, const int32_t* in_table_vals, int64_t cap, const int32_t* out_coords4,
+                         int64_t n_out, int ksize, int offset_scale, int32_t* nbr, int64_t* counts, bool prefilled, hipStream_t st) {
     OSN_REQUIRE(ksize >= 1 && ksize <= 7, OSN_E_ARG, "osn_kmap_build: ksize=%d unsupported", ksize);
     OSN_REQUIRE(cap >= 2 && (cap & (cap - 1)) == 0, OSN_E_ARG, "osn_kmap_build: cap must be a power of two");
     OSN_REQUIRE(n_out >= 0, OSN_E_ARG, "osn_kmap_build: n_out < 0");
-    if (counts) OSN_HIP(hipMemsetAsync(counts, 0, size_t(ksize) * ksize * ksize * 8, st));
+    if (counts && !prefilled) OSN_HIP(hipMemsetAsync(counts, 0, size_t(ksize) * ksize * ksize * 8, st));
     if (n_out == 0) return OSN_OK;
     OSN_REQUIRE(in_table_keys && in_table_vals && out_coords4 && nbr, OSN_E_ARG, "osn_kmap_build: null pointer");
     OSN_REQUIRE(aligned16(out_coords4), OSN_E_ARG, "osn_kmap_build: out_coords4 must be 16-byte aligned");
@@ -417,16 +525,20 @@ extern "C" int osn_kmap_build(const uint64_t* in_table_keys, const int32_t* in_t
 extern "C" int osn_kmap_build_self(const uint64_t* table_keys, const int32_t* table_vals, int64_t cap,
                                    const int32_t* coords4, int64_t n, int ksize, int offset_scale, int32_t* nbr,
                                    int64_t* counts, osn_stream_t stream) {
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    return kmap_build_self_impl(table_keys, table_vals, cap, coords4, n, ksize, offset_scale, nbr, counts, false, static_cast<hipStream_t>(stream));
+}
+
+int osn::kmap_build_self_impl(const uint64_t* table_keys, const int32_t* table_vals, int64_t cap, const int32_t* coords4, int64_t n,
+                              int ksize, int offset_scale, int32_t* nbr, int64_t* counts, bool prefilled, hipStream_t st) {
     OSN_REQUIRE(ksize >= 1 && ksize <= 7 && (ksize & 1) == 1, OSN_E_ARG, "osn_kmap_build_self: ksize=%d must be odd, <= 7", ksize);
     OSN_REQUIRE(cap >= 2 && (cap & (cap - 1)) == 0, OSN_E_ARG, "osn_kmap_build_self: cap must be a power of two");
     OSN_REQUIRE(n >= 0, OSN_E_ARG, "osn_kmap_build_self: n < 0");
     const int K = ksize * ksize * ksize;
-    if (counts) OSN_HIP(hipMemsetAsync(counts, 0, size_t(K) * 8, st));
+    if (counts && !prefilled) OSN_HIP(hipMemsetAsync(counts, 0, size_t(K) * 8, st));
     if (n == 0) return OSN_OK;
     OSN_REQUIRE(table_keys && table_vals && coords4 && nbr, OSN_E_ARG, "osn_kmap_build_self: null pointer");
     OSN_REQUIRE(aligned16(coords4), OSN_E_ARG, "osn_kmap_build_self: coords4 must be 16-byte aligned");
-    if (K > 1) OSN_HIP(hipMemsetAsync(nbr + int64_t(K / 2 + 1) * n, 0xFF, size_t(K / 2) * size_t(n) * 4, st));
+    if (K > 1 && !prefilled) OSN_HIP(hipMemsetAsync(nbr + int64_t(K / 2 + 1) * n, 0xFF, size_t(K / 2) * size_t(n) * 4, st));
     const int T = 256;
     hipLaunchKernelGGL(kmap_build_self_kernel, dim3(cdiv(n, T), K / 2 + 1), dim3(T), 0, st, table_keys, table_vals,
                        uint32_t(cap - 1), reinterpret_cast<const int4*>(coords4), n, ksize, offset_scale, nbr,
@@ -437,11 +549,14 @@ extern "C" int osn_kmap_build_self(const uint64_t* table_keys, const int32_t* ta
 
 extern "C" int osn_kmap_transpose(const int32_t* nbr, int64_t n_out, int K, int64_t n_in, int32_t* tbl,
                                   osn_stream_t stream) {
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    return kmap_transpose_impl(nbr, n_out, K, n_in, tbl, false, static_cast<hipStream_t>(stream));
+}
+
+int osn::kmap_transpose_impl(const int32_t* nbr, int64_t n_out, int K, int64_t n_in, int32_t* tbl, bool prefilled, hipStream_t st) {
     OSN_REQUIRE(K >= 1 && n_out >= 0 && n_in >= 0, OSN_E_ARG, "osn_kmap_transpose: bad sizes");
     if (n_in == 0) return OSN_OK;
     OSN_REQUIRE(tbl, OSN_E_ARG, "osn_kmap_transpose: null tbl");
-    OSN_HIP(hipMemsetAsync(tbl, 0xFF, size_t(K) * size_t(n_in) * 4, st));
+    if (!prefilled) OSN_HIP(hipMemsetAsync(tbl, 0xFF, size_t(K) * size_t(n_in) * 4, st));
     if (n_out == 0) return OSN_OK;
     OSN_REQUIRE(nbr, OSN_E_ARG, "osn_kmap_transpose: null nbr");
     const int T = 256;

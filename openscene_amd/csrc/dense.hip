@@ -16,6 +16,7 @@
 // (osn_weight_prep_tl with K = 1).
 #include "common.h"
 #include "split.h"
+#include "epilogue.h"
 
 namespace osn {
 
@@ -26,10 +27,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int DN_BM = 64;           // rows per workgroup
 
 // 4 waves; wave w owns output columns [128 cg + 32 w, + 32) of column group cg; KS k-steps of 32 input channels per chunk
-template <int KS>
+// EPI (inference): the stage's evaluation-mode batch norm in the epilogue (epilogue.h); a template flag so that the training instances
+// keep their register allocation
+template <int KS, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void dense_kernel(const float* __restrict__ in, const bf16x8* __restrict__ Wp,
                                                     float* __restrict__ out, int64_t n, int cin, int cout, int ns, int ncb,
-                                                    int64_t per_plane /* 1 KB blocks per weight plane */) {
+                                                    int64_t per_plane /* 1 KB blocks per weight plane */, const Epi epi) {
     constexpr int NT = 256;
     constexpr int CK = 32 * KS;
     constexpr int LDA = CK + 8;                     // bf16 row stride of a staged plane (16-byte aligned rows)
@@ -124,6 +127,14 @@ __global__ __launch_bounds__(256, 2) void dense_kernel(const float* __restrict__
         // ---- accumulators -> output rows.  The weight fragment is the MFMA's FIRST operand (the staged rows the second), so a
         // block comes out transposed: lane l holds columns 4 (l >> 4) .. + 3 of row l & 15 -- one 16-byte store per block
         if (wave_on) {
+            EpiCols ec[2];
+            if constexpr (EPI) {                 // the lane's two column quads: constants once for the four row blocks
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int col = cg * 128 + 32 * wave + 16 * nb + 4 * (lane >> 4);
+                    ec[nb] = epi_cols(epi, col < cout ? col : 0);
+                }
+            }
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) {
                 const int64_t row = r0 + 16 * rb + (lane & 15);
@@ -131,9 +142,11 @@ __global__ __launch_bounds__(256, 2) void dense_kernel(const float* __restrict__
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
                         const int col = cg * 128 + 32 * wave + 16 * nb + 4 * (lane >> 4);
-                        if (col < cout)          // (cout % 4 == 0: a quad is inside or outside as a whole)
-                            *reinterpret_cast<float4*>(out + row * cout + col) =
-                                make_float4(acc[rb][nb][0], acc[rb][nb][1], acc[rb][nb][2], acc[rb][nb][3]);
+                        if (col < cout) {        // (cout % 4 == 0: a quad is inside or outside as a whole)
+                            float4 v = make_float4(acc[rb][nb][0], acc[rb][nb][1], acc[rb][nb][2], acc[rb][nb][3]);
+                            if constexpr (EPI) v = epi_apply(epi, ec[nb], v, row, col, cout);  // evaluation-mode batch norm (epilogue.h)
+                            *reinterpret_cast<float4*>(out + row * cout + col) = v;
+                        }
                     }
                 }
             }
@@ -145,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void dense_kernel(const float* __restrict__
 
 using namespace osn;
 
-extern "C" int osn_dense_fwd(const float* in, const void* Wp, float* out, int64_t n, int cin, int cout, osn_stream_t stream) {
+int osn::dense_fwd_epi(const float* in, const void* Wp, float* out, int64_t n, int cin, int cout, const Epi& epi, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n >= 0 && n < (int64_t(1) << 31) && cin >= 4 && (cin & 3) == 0 && cout >= 4 && (cout & 3) == 0, OSN_E_ARG,
                 "osn_dense_fwd: needs cin %% 4 == 0 and cout %% 4 == 0 (n=%lld cin=%d cout=%d)", (long long)n, cin, cout);
@@ -158,11 +171,21 @@ extern "C" int osn_dense_fwd(const float* in, const void* Wp, float* out, int64_
     const dim3 grid(unsigned(cdiv(n, DN_BM)), unsigned(ns <= ks ? 1 : ncg));
     const bf16x8* wp = static_cast<const bf16x8*>(Wp);
     switch (ks) {
-        case 1: hipLaunchKernelGGL(dense_kernel<1>, grid, dim3(256), 0, st, in, wp, out, n, cin, cout, ns, ncb, per_plane); break;
-        case 2: hipLaunchKernelGGL(dense_kernel<2>, grid, dim3(256), 0, st, in, wp, out, n, cin, cout, ns, ncb, per_plane); break;
-        case 3: hipLaunchKernelGGL(dense_kernel<3>, grid, dim3(256), 0, st, in, wp, out, n, cin, cout, ns, ncb, per_plane); break;
-        default: hipLaunchKernelGGL(dense_kernel<4>, grid, dim3(256), 0, st, in, wp, out, n, cin, cout, ns, ncb, per_plane); break;
+#define OSN_DN(KS_)                                                                                                              \
+    do {                                                                                                                         \
+        if (epi.mean) hipLaunchKernelGGL((dense_kernel<KS_, true>), grid, dim3(256), 0, st, in, wp, out, n, cin, cout, ns, ncb, per_plane, epi); \
+        else hipLaunchKernelGGL((dense_kernel<KS_, false>), grid, dim3(256), 0, st, in, wp, out, n, cin, cout, ns, ncb, per_plane, epi);         \
+    } while (0)
+        case 1: OSN_DN(1); break;
+        case 2: OSN_DN(2); break;
+        case 3: OSN_DN(3); break;
+        default: OSN_DN(4); break;
     }
+#undef OSN_DN
     OSN_LAUNCH_CHECK();
     return OSN_OK;
+}
+
+extern "C" int osn_dense_fwd(const float* in, const void* Wp, float* out, int64_t n, int cin, int cout, osn_stream_t stream) {
+    return dense_fwd_epi(in, Wp, out, n, cin, cout, epi_none(), stream);
 }

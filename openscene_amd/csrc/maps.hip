@@ -10,6 +10,8 @@
 // bit for bit what the per-map calls produce.
 #include "common.h"
 #include "events.h"
+#include "coords_impl.h"
+#include <vector>
 
 using namespace osn;
 
@@ -22,6 +24,26 @@ extern "C" int osn_maps_build(const osn_map_level* levels, int n_levels, const o
     OSN_REQUIRE(n_streams == 1 || (events && events_count(events) >= n_streams + 1), OSN_E_ARG,
                 "osn_maps_build: %d streams need an event pool of at least %d events", n_streams, n_streams + 1);
     hipStream_t main = static_cast<hipStream_t>(streams[0]);
+    // Round 6: what the per-map entry points preset with one hipMemsetAsync each (pair counts: zero; the upper half of a self map's
+    // table and a transposed table: -1) is cleared for ALL jobs by one launch in front of the fork (~20 launches of 3 - 8 us per scene)
+    {
+        std::vector<FillJob> fills;
+        for (int j = 0; j < n_jobs; ++j) {
+            const osn_map_job& q = jobs[j];
+            if (q.lvl_in < 0 || q.lvl_in >= n_levels || q.lvl_out < 0 || q.lvl_out >= n_levels || q.ksize < 1 || q.ksize > 7 || !q.nbr_fwd) continue;
+            const int K = q.ksize * q.ksize * q.ksize;
+            const int64_t n_in = levels[q.lvl_in].rows, n_out = levels[q.lvl_out].rows;
+            if (q.counts) fills.push_back(FillJob{q.counts, uint64_t(K) * 8u, 0u, 0u});
+            if (q.self_map) {
+                if (K > 1 && n_in > 0) fills.push_back(FillJob{q.nbr_fwd + int64_t(K / 2 + 1) * n_in, uint64_t(K / 2) * uint64_t(n_in) * 4u, 0xFFFFFFFFu, 0u});
+            } else if (q.nbr_bwd && n_in > 0) {
+                fills.push_back(FillJob{q.nbr_bwd, uint64_t(K) * uint64_t(n_in) * 4u, 0xFFFFFFFFu, 0u});
+            }
+            (void)n_out;
+        }
+        const int rc = fill_batch(fills.data(), int(fills.size()), main);
+        if (rc) return rc;
+    }
     // fork: the side streams see the pyramid (coordinates + hash tables) the main stream has queued
     if (n_streams > 1) {
         hipEvent_t e0 = events_get(events, 0);
@@ -43,10 +65,12 @@ extern "C" int osn_maps_build(const osn_map_level* levels, int n_levels, const o
         int rc;
         if (q.self_map) {
             OSN_REQUIRE(q.lvl_in == q.lvl_out && (q.ksize & 1), OSN_E_ARG, "osn_maps_build: job %d: a self map needs one level and an odd kernel", j);
-            rc = osn_kmap_build_self(li.keys, li.vals, li.cap, li.coords4, li.rows, q.ksize, q.scale, q.nbr_fwd, q.counts, st);
+            rc = kmap_build_self_impl(li.keys, li.vals, li.cap, li.coords4, li.rows, q.ksize, q.scale, q.nbr_fwd, q.counts, true,
+                                      static_cast<hipStream_t>(st));
         } else {
-            rc = osn_kmap_build(li.keys, li.vals, li.cap, lo.coords4, lo.rows, q.ksize, q.scale, q.nbr_fwd, q.counts, st);
-            if (!rc && q.nbr_bwd) rc = osn_kmap_transpose(q.nbr_fwd, lo.rows, K, li.rows, q.nbr_bwd, st);
+            rc = kmap_build_impl(li.keys, li.vals, li.cap, lo.coords4, lo.rows, q.ksize, q.scale, q.nbr_fwd, q.counts, true,
+                                 static_cast<hipStream_t>(st));
+            if (!rc && q.nbr_bwd) rc = kmap_transpose_impl(q.nbr_fwd, lo.rows, K, li.rows, q.nbr_bwd, true, static_cast<hipStream_t>(st));
         }
         if (rc) return rc;
         // tile-ordered copies (rows sorted by offset-occupancy mask) of the forward / input-gradient tables

@@ -11,6 +11,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include "events.h"
+#include "epilogue.h"
 #include <vector>
 
 namespace osn {
@@ -291,29 +292,37 @@ static MapView view_of(const osn_net_map& m, bool transposed) {
 }
 
 // out[n_out, cout] = conv(in[n_in, cin]) over table side `fwd` of the view, with weight images `x6` / `tl`
+// epi (evaluation-mode forward pass only): the stage's batch norm applied by the kernel that stores the final rows (epilogue.h);
+// every kernel family but the first-generation one takes it (epi_fusable)
+static bool epi_fusable(int kernel) {
+    return kernel == OSN_NET_K_DENSE || kernel == OSN_NET_K_WS || kernel == OSN_NET_K_WS_DIRECT || kernel == OSN_NET_K_RG ||
+           kernel == OSN_NET_K_STEM || kernel == OSN_NET_K_TL;
+}
 static int run_conv(int kernel, const float* in, int64_t n_in, float* out, int64_t n_out, int K, int cin, int cout,
                     const float* W, const void* img_x6, const void* img_tl, const int32_t* nbr, const int32_t* t_rows,
                     const int32_t* t_tbl, const uint32_t* t_g, const void* tl, const int32_t* tl_rows, int tl_bm,
-                    const void* pl, int64_t pl_rows, int pl_swap, const osn_net_run* run, osn_stream_t stream, int op) {
+                    const void* pl, int64_t pl_rows, int pl_swap, const osn_net_run* run, osn_stream_t stream, int op,
+                    const Epi& epi = epi_none()) {
+    OSN_REQUIRE(!epi.mean || epi_fusable(kernel), OSN_E_ARG, "osn_net: op %d: kernel %d takes no epilogue", op, kernel);
     switch (kernel) {
         case OSN_NET_K_DENSE:
             OSN_REQUIRE(img_tl && K == 1 && n_in == n_out, OSN_E_ARG, "osn_net: op %d: the 1x1 kernel needs the fragment-order weight image", op);
-            return osn_dense_fwd(in, img_tl, out, n_out, cin, cout, stream);
+            return dense_fwd_epi(in, img_tl, out, n_out, cin, cout, epi, stream);
         case OSN_NET_K_WS:
         case OSN_NET_K_WS_DIRECT:
             OSN_REQUIRE(pl && img_tl && nbr, OSN_E_ARG, "osn_net: op %d: pair arrays / tile-list weight image / destination table missing", op);
-            return osn_spconv_fwd_ws(in, n_in, img_tl, pl, pl_rows, pl_swap, kernel == OSN_NET_K_WS_DIRECT ? 1 : 0, nbr, out, n_out, K,
-                                     cin, cout, run->ws, size_t(run->ws_bytes), stream);
+            return spconv_fwd_ws_epi(in, n_in, img_tl, pl, pl_rows, pl_swap, kernel == OSN_NET_K_WS_DIRECT ? 1 : 0, nbr, out, n_out, K,
+                                     cin, cout, run->ws, size_t(run->ws_bytes), epi, stream);
         case OSN_NET_K_RG:
             OSN_REQUIRE(img_tl && nbr, OSN_E_ARG, "osn_net: op %d: the register-gather kernel needs the tile-list weight image and the table", op);
-            return osn_spconv_fwd_rg(in, n_in, img_tl, t_tbl ? t_tbl : nbr, t_tbl ? t_rows : nullptr, out, n_out, K, cin, cout, stream);
+            return spconv_fwd_rg_epi(in, n_in, img_tl, t_tbl ? t_tbl : nbr, t_tbl ? t_rows : nullptr, out, n_out, K, cin, cout, epi, stream);
         case OSN_NET_K_STEM:
             OSN_REQUIRE(nbr && W, OSN_E_ARG, "osn_net: op %d: the stem kernel needs the plain table and the fp32 weight", op);
-            return osn_stem_conv_fwd(in, W, nbr, out, n_out, K, cin, cout, stream);
+            return stem_conv_fwd_epi(in, W, nbr, out, n_out, K, cin, cout, epi, stream);
         case OSN_NET_K_TL:
             OSN_REQUIRE(tl && img_tl && run->tl_counters, OSN_E_ARG, "osn_net: op %d: tile lists / tile-list weight image / counters missing", op);
-            return osn_spconv_fwd_tl_pc(in, n_in, img_tl, tl, tl_rows, out, nullptr, n_out, K, cin, cout, tl_bm, run->ws,
-                                        size_t(run->ws_bytes), run->tl_counters, stream);
+            return spconv_fwd_tl_epi(in, n_in, img_tl, tl, tl_rows, out, n_out, K, cin, cout, tl_bm, run->ws, size_t(run->ws_bytes),
+                                     run->tl_counters, epi, stream);
         case OSN_NET_K_X6: {
             OSN_REQUIRE(img_x6 && (K == 1 || nbr), OSN_E_ARG, "osn_net: op %d: split-bf16 weight image / table missing", op);
             const int32_t* tbl = K == 1 ? nullptr : (t_tbl ? t_tbl : nbr);
@@ -413,15 +422,44 @@ extern "C" int osn_net_forward(const osn_net_desc* net, const osn_net_run* run, 
             OSN_REQUIRE(run->maps[o.map].K == o.K, OSN_E_ARG, "osn_net_forward: op %d (K=%d) got a map with K=%d", i, o.K, run->maps[o.map].K);
             v = view_of(run->maps[o.map], o.transposed != 0);
         }
+        // Inference: the stage's batch norm (+ residual) (+ ReLU) (+ cat store) in the epilogue of the convolution's last kernel
+        // (epilogue.h: bitwise the separate launch): the convolution writes y, the x buffer and the osn_bn_apply2 launch are skipped
+        Epi epi = epi_none();
+        if (!run->training && o.bn >= 0 && !(run->flags & OSN_NET_RUN_NO_BN_EPILOGUE) && epi_fusable(L.fwd_k[i])) {
+            const osn_net_bn& bn = run->bns[o.bn];
+            OSN_REQUIRE(bn.running_mean && bn.running_var, OSN_E_ARG, "osn_net_forward: op %d: evaluation-mode batch norm without running statistics", i);
+            if (o.res >= 0 && forked) {                        // the residual is read by the convolution's kernel: join in front of it
+                const int p = L.producer[o.res];
+                if (p >= 0 && pending[p]) {
+                    OSN_HIP(hipStreamWaitEvent(st, evs->ev[net->n_ops + 1 + p], 0));
+                    pending[p] = 0;
+                }
+            }
+            epi.mean = bn.running_mean; epi.var = bn.running_var; epi.gamma = bn.gamma; epi.beta = bn.beta; epi.eps = bn.eps;
+            epi.res = o.res >= 0 ? reinterpret_cast<const float*>(A + L.y_off[o.res]) : nullptr;
+            epi.relu = o.relu;
+            if (o.copy_buf >= 0) {
+                epi.ld2 = net->bufs[o.copy_buf].channels;
+                epi.y2 = reinterpret_cast<float*>(A + L.y_off[o.copy_buf]) + o.copy_col;
+            }
+            x = reinterpret_cast<float*>(A + L.y_off[o.dst]);
+        }
         {
             Bracket br(run->prof, i, 0, on_side ? side : st);
             // pair arrays: those of the map's own (strided / self) direction; a transposed conv walks them the other way
             rc = run_conv(L.fwd_k[i], in, n_in, x, n_out, o.K, o.cin, o.cout, w.W, w.x6_fwd, w.tl_fwd, v.nbr_f, v.tf_rows, v.tf_tbl,
                           v.tf_g, v.tl_f, v.tl_f_rows, v.tl_f_bm, o.map >= 0 ? run->maps[o.map].pl_fwd : nullptr,
-                          o.transposed ? n_in : n_out, o.transposed ? 1 : 0, r, sstream, i);
+                          o.transposed ? n_in : n_out, o.transposed ? 1 : 0, r, sstream, i, epi);
         }
         if (rc) return rc;
         if (o.bn < 0) continue;
+        if (epi.mean) {                                        // the batch norm ran in the convolution's epilogue
+            if (on_side) {
+                OSN_HIP(hipEventRecord(evs->ev[net->n_ops + 1 + i], side));
+                pending[i] = 1;
+            }
+            continue;
+        }
         if (o.res >= 0 && forked) {                            // join: the residual may come from a side stage
             const int p = L.producer[o.res];
             if (p >= 0 && pending[p]) {

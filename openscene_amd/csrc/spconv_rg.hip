@@ -19,6 +19,7 @@
 // Arithmetic: "bf16x6" as everywhere (three bf16 pieces per operand, six MFMAs per product block, fp32 accumulate, smallest terms first).
 #include "common.h"
 #include "split.h"
+#include "epilogue.h"
 
 namespace osn {
 
@@ -34,11 +35,12 @@ constexpr int RG_RB = 4;                 // 16-row blocks per wave and half: 64 
 // BD: the weight fragments of the NEXT offset loaded one iteration ahead into a second register set.  Measured SLOWER (48 k rows
 // 32 -> 32: 24.8 against 22.0 us; 13 k rows 32 -> 64: 18.9 / 15.6): the extra registers cost a resident workgroup per CU, and resident
 // waves are what hides this kernel's per-offset latency chain.  Not instantiated.
-template <int KS, int NCB, int HALVES, int OCC, bool BD>
+// EPI (inference): the stage's evaluation-mode batch norm in the epilogue (epilogue.h)
+template <int KS, int NCB, int HALVES, int OCC, bool BD, bool EPI = false>
 __global__ __launch_bounds__(256, OCC) void spconv_rg_kernel(const float* __restrict__ in, const bf16x8* __restrict__ Wp,
                                                         const int32_t* __restrict__ nbr, const int32_t* __restrict__ out_rows,
                                                         float* __restrict__ out, int n_out, int K, int cin, int cout,
-                                                        unsigned in_bytes) {
+                                                        unsigned in_bytes, const Epi epi) {
     constexpr int ROWS = 64 * HALVES;
     constexpr int LDR = 32 + 4;                                   // fp32 row pitch of a partial tile in LDS (32 columns per pass)
     __shared__ __attribute__((aligned(16))) float red[4][64][LDR];
@@ -171,6 +173,8 @@ __global__ __launch_bounds__(256, OCC) void spconv_rg_kernel(const float* __rest
                 for (int c2 = 0; c2 < 2; ++c2)
                     *reinterpret_cast<f32x4*>(&red[wave][16 * rb + l15][16 * c2 + 4 * lg]) = acc[h][rb][2 * cp + c2];
             __syncthreads();
+            EpiCols ec;
+            if constexpr (EPI) ec = epi_cols(epi, 32 * cp + 4 * (tid & 7));       // (256 % 8 == 0: a thread keeps its column quad)
             for (int e = tid; e < 64 * 8; e += 256) {
                 const int j = e >> 3, c4 = e & 7;
                 const int r = row0 + 64 * h + j;
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(256, OCC) void spconv_rg_kernel(const float* __rest
                         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
                     }
                     const int64_t orow = out_rows ? out_rows[r] : r;
+                    if constexpr (EPI) s = epi_apply(epi, ec, s, orow, 32 * cp + 4 * c4, cout);
                     *reinterpret_cast<float4*>(out + orow * cout + 32 * cp + 4 * c4) = s;
                 }
             }
@@ -199,8 +204,8 @@ extern "C" int osn_spconv_fwd_rg_ok(int64_t n_in, int K, int cin, int cout) {
            uint64_t(n_in) * uint64_t(cin) * 4u < (uint64_t(1) << 31);
 }
 
-extern "C" int osn_spconv_fwd_rg(const float* in, int64_t n_in, const void* Wp, const int32_t* nbr, const int32_t* out_rows,
-                                 float* out, int64_t n_out, int K, int cin, int cout, osn_stream_t stream) {
+int osn::spconv_fwd_rg_epi(const float* in, int64_t n_in, const void* Wp, const int32_t* nbr, const int32_t* out_rows, float* out,
+                           int64_t n_out, int K, int cin, int cout, const Epi& epi, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_spconv_fwd_rg: n_out out of range");
     OSN_REQUIRE(osn_spconv_fwd_rg_ok(n_in > 0 ? n_in : 1, K, cin, cout), OSN_E_ARG,
@@ -214,8 +219,15 @@ extern "C" int osn_spconv_fwd_rg(const float* in, int64_t n_in, const void* Wp, 
     const int ks = cin / 32, ncb = cout / 16;
     // (two 64-row halves per workgroup -- each offset's fragments loaded once for both -- need 256 + registers: not instantiated)
     const dim3 grid(unsigned(cdiv(n_out, 64)));
-#define OSN_RG(KS_, NCB_, H_, OCC_, BD_) \
-    hipLaunchKernelGGL((spconv_rg_kernel<KS_, NCB_, H_, OCC_, BD_>), grid, dim3(256), 0, st, in, wp, nbr, out_rows, out, int(n_out), K, cin, cout, in_bytes)
+#define OSN_RG(KS_, NCB_, H_, OCC_, BD_)                                                                                                              \
+    do {                                                                                                                                              \
+        if (epi.mean)                                                                                                                                 \
+            hipLaunchKernelGGL((spconv_rg_kernel<KS_, NCB_, H_, OCC_, BD_, true>), grid, dim3(256), 0, st, in, wp, nbr, out_rows, out, int(n_out), K, \
+                               cin, cout, in_bytes, epi);                                                                                             \
+        else                                                                                                                                          \
+            hipLaunchKernelGGL((spconv_rg_kernel<KS_, NCB_, H_, OCC_, BD_, false>), grid, dim3(256), 0, st, in, wp, nbr, out_rows, out, int(n_out), K, \
+                               cin, cout, in_bytes, epi);                                                                                             \
+    } while (0)
     if (ks == 1 && ncb == 2) OSN_RG(1, 2, 1, 3, false);
     else if (ks == 1 && ncb == 4) OSN_RG(1, 4, 1, 2, false);
     else if (ks == 2 && ncb == 2) OSN_RG(2, 2, 1, 2, false);
@@ -223,4 +235,9 @@ extern "C" int osn_spconv_fwd_rg(const float* in, int64_t n_in, const void* Wp, 
 #undef OSN_RG
     OSN_LAUNCH_CHECK();
     return OSN_OK;
+}
+
+extern "C" int osn_spconv_fwd_rg(const float* in, int64_t n_in, const void* Wp, const int32_t* nbr, const int32_t* out_rows,
+                                 float* out, int64_t n_out, int K, int cin, int cout, osn_stream_t stream) {
+    return spconv_fwd_rg_epi(in, n_in, Wp, nbr, out_rows, out, n_out, K, cin, cout, epi_none(), stream);
 }

@@ -34,6 +34,7 @@
 #include <type_traits>
 #include "weight_prep.h"
 #include "split.h"
+#include "epilogue.h"
 
 namespace osn {
 
@@ -126,14 +127,17 @@ __global__ void weight_prep_tl_kernel(const float* __restrict__ W, int K, int ci
 // chunk's first channel in the scalar offset -- instead of a 64-bit multiply-add, two 64-bit adds and a channel clamp per quad (8 -> 2 VALU;
 // round 5's A/B: step 8.80 -> 8.73 / 8.76 ms, bit-identical results, profiles/r05_s1_knobs_ab.txt).  Ragged chunks and matrices of 2 GB
 // and more keep the 64-bit addresses.
-template <int NW, int KS, bool RAGGED, bool PROF = false, int OCC = 2, bool BUFG = false>
+// EPI (inference): the evaluation-mode batch norm of the stage in the epilogue (epilogue.h).  A template flag, not a run-time test: with
+// the test in the training instances the 96 -> 96 kernel's spills went from 26 to 45 SGPRs and from 52 to 92 bytes of scratch per lane.
+template <int NW, int KS, bool RAGGED, bool PROF = false, int OCC = 2, bool BUFG = false, bool EPI = false>
 __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __restrict__ in, const bf16x8* __restrict__ Wp,
                                                                const int32_t* __restrict__ cnt, const int2* __restrict__ lst,
                                                                const int32_t* __restrict__ out_rows, float* __restrict__ out,
                                                                double* __restrict__ bn_partial, int32_t* __restrict__ counter,
                                                                float* __restrict__ partial, int nz, int n_out, int K, int cin,
                                                                int cout, int bm, int n_tiles, int ns, int ncb,
-                                                               int self_reset, long long* __restrict__ prof, unsigned in_bytes) {
+                                                               int self_reset, long long* __restrict__ prof, unsigned in_bytes,
+                                                               const Epi epi) {
     static_assert(!(BUFG && RAGGED), "the buffer gather is for full channel chunks");
     constexpr int NT = 256;
     constexpr int CW = 32 * NW;               // output columns of the workgroup
@@ -507,6 +511,20 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
 
         // ---- epilogue: tile rows -> out[out_rows[row]] (16-byte stores), optional batch-norm partial sums
         constexpr int V = CW / 4;
+        if constexpr (EPI) {
+            // a thread keeps ONE column quad and walks the rows (NT / V rows per pass): the stage's per-column constants -- four loads and
+            // four reciprocal square roots -- once per tile and thread instead of once per stored quad
+            constexpr int RPP = NT / V;
+            const int c4 = tid % V, col = col0 + 4 * c4;
+            if (tid < RPP * V && col < cout) {
+                const EpiCols ec = epi_cols(epi, col);
+                for (int j = tid / V; j < rows; j += RPP) {
+                    const float4 v = *reinterpret_cast<const float4*>(&otile[j * S + 4 * c4]);
+                    const int64_t orow = park ? orow_s[j] : (out_rows ? out_rows[row0 + j] : row0 + j);
+                    *reinterpret_cast<float4*>(out + orow * cout + col) = epi_apply(epi, ec, v, orow, col, cout);
+                }
+            }
+        } else
         for (int idx = tid; idx < rows * V; idx += NT) {
             const int j = idx / V, c4 = idx - j * V;
             const int col = col0 + 4 * c4;
@@ -516,6 +534,7 @@ __global__ __launch_bounds__(256, OCC) void spconv_tl_kernel(const float* __rest
                     *reinterpret_cast<float4*>(partial + (int64_t(zpart) * n_out + row0 + j) * cout + col) = v;
                 } else {
                     const int64_t orow = park ? orow_s[j] : (out_rows ? out_rows[row0 + j] : row0 + j);
+                    // (inference: evaluation-mode batch norm + residual + ReLU on the finished row, epilogue.h)
                     *reinterpret_cast<float4*>(out + orow * cout + col) = v;
                 }
             }
@@ -642,8 +661,9 @@ extern "C" size_t osn_spconv_fwd_tl_ws_bytes(int64_t n_out, int K, int cout, int
 }
 
 // out[out_rows ? out_rows[r] : r] = partial[0][r] + partial[1][r] + ...  (fixed order)
+template <bool EPI>
 __global__ void tl_reduce_parts_kernel(const float4* __restrict__ partial, int S, int64_t n_out, int c4,
-                                       const int32_t* __restrict__ out_rows, float4* __restrict__ out) {
+                                       const int32_t* __restrict__ out_rows, float4* __restrict__ out, const Epi epi) {
     const int64_t total = n_out * c4;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
         float4 s = partial[e];
@@ -651,18 +671,16 @@ __global__ void tl_reduce_parts_kernel(const float4* __restrict__ partial, int S
             const float4 v = partial[int64_t(z) * total + e];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        if (out_rows) {
-            const int64_t r = e / c4, c = e - r * c4;
-            out[int64_t(out_rows[r]) * c4 + c] = s;
-        } else {
-            out[e] = s;
-        }
+        const int64_t r = e / c4, c = e - r * c4;
+        const int64_t orow = out_rows ? int64_t(out_rows[r]) : r;
+        if constexpr (EPI) s = epi_quad(epi, s, orow, int(4 * c), 4 * c4);     // evaluation-mode batch norm (epilogue.h)
+        out[orow * c4 + c] = s;
     }
 }
 
 static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,
                               float* out, double* bn_partial, int64_t n_out, int K, int cin, int cout, int bm, void* ws,
-                              size_t ws_bytes, int32_t* counters, long long* prof, osn_stream_t stream) {
+                              size_t ws_bytes, int32_t* counters, long long* prof, osn_stream_t stream, const Epi& epi = epi_none()) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_spconv_fwd_tl: n_out out of range");
     OSN_REQUIRE(K >= 1 && K <= TL_KMAX && cin >= 4 && (cin & 3) == 0 && cout >= 4 && (cout & 3) == 0, OSN_E_ARG,
@@ -727,10 +745,16 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
         gx = unsigned(units < TL_SLOTS / 2 * 3 ? units : TL_SLOTS / 2 * 3);
         grid = dim3(gx, unsigned(gy));
     }
+    const bool use_epi = epi.mean != nullptr && nz == 1;        // (split launches: the reduction of the parts applies it)
 #define OSN_TL4(NW_, KS_, RG_, PF_, OC_) OSN_TL5(NW_, KS_, RG_, PF_, OC_, false)
 #define OSN_TL5(NW_, KS_, RG_, PF_, OC_, BG_)                                                                              \
     do {                                                                                                                   \
-        auto kern = spconv_tl_kernel<NW_, KS_, RG_, PF_, OC_, BG_>;                                                        \
+        if (use_epi) OSN_TL6(NW_, KS_, RG_, PF_, OC_, BG_, true);                                                          \
+        else OSN_TL6(NW_, KS_, RG_, PF_, OC_, BG_, false);                                                                 \
+    } while (0)
+#define OSN_TL6(NW_, KS_, RG_, PF_, OC_, BG_, EP_)                                                                         \
+    do {                                                                                                                   \
+        auto kern = spconv_tl_kernel<NW_, KS_, RG_, PF_, OC_, BG_, EP_>;                                                   \
         /* dynamic LDS beyond the default limit needs the opt-in attribute: once per (instance, DEVICE), the largest tile any   \
            launch can ask for; relaxed atomics: a racing second thread (autograd's, the map prefetcher's) sets it again */       \
         static std::atomic<unsigned char> attr_set[TL_MAX_DEVICES];                                                        \
@@ -743,7 +767,8 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
             if (dev_slot_ok) attr_set[dev_slot].store(1, std::memory_order_relaxed);                                       \
         }                                                                                                                  \
         hipLaunchKernelGGL(kern, grid, dim3(256), tile_bytes, st, in, wp, cnt, lst, out_rows, out, bn_partial, counter, partial, nz, \
-                           int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof, in_bytes);               \
+                           int(n_out), K, cin, cout, bm, int(n_tiles), ns, ncb, self_reset, prof, in_bytes,                \
+                           use_epi ? epi : epi_none());                                                                    \
     } while (0)
 #define OSN_TL3(NW_, KS_, RG_, PF_) OSN_TL4(NW_, KS_, RG_, PF_, 2)
 #define OSN_TL2(NW_, KS_)                                                                                                  \
@@ -781,17 +806,25 @@ static int spconv_fwd_tl_impl(const float* in, int64_t n_in, const void* Wp, con
 #undef OSN_TL3
 #undef OSN_TL4
 #undef OSN_TL5
+#undef OSN_TL6
     OSN_REQUIRE(rc_attr == OSN_OK, OSN_E_HIP, "osn_spconv_fwd_tl: cannot reserve %zu bytes of LDS for the output tile", tile_bytes);
     OSN_LAUNCH_CHECK();
     if (nz > 1) {
         const int64_t total4 = n_out * (cout / 4);
         int g = int(cdiv(total4, 256));
         if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(tl_reduce_parts_kernel, dim3(g), dim3(256), 0, st, reinterpret_cast<const float4*>(partial), nz, n_out,
-                           cout / 4, out_rows, reinterpret_cast<float4*>(out));
+        hipLaunchKernelGGL(epi.mean ? tl_reduce_parts_kernel<true> : tl_reduce_parts_kernel<false>, dim3(g), dim3(256), 0, st,
+                           reinterpret_cast<const float4*>(partial), nz, n_out, cout / 4, out_rows, reinterpret_cast<float4*>(out), epi);
         OSN_LAUNCH_CHECK();
     }
     return OSN_OK;
+}
+
+int osn::spconv_fwd_tl_epi(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows, float* out,
+                           int64_t n_out, int K, int cin, int cout, int bm, void* ws, size_t ws_bytes, int32_t* counters, const Epi& epi,
+                           osn_stream_t stream) {
+    OSN_REQUIRE(counters, OSN_E_ARG, "spconv_fwd_tl_epi: null counters");
+    return spconv_fwd_tl_impl(in, n_in, Wp, tl, out_rows, out, nullptr, n_out, K, cin, cout, bm, ws, ws_bytes, counters, nullptr, stream, epi);
 }
 
 extern "C" int osn_spconv_fwd_tl(const float* in, int64_t n_in, const void* Wp, const void* tl, const int32_t* out_rows,

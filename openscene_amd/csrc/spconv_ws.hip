@@ -23,6 +23,7 @@
 #include "common.h"
 #include "split.h"
 #include "pairlist.h"
+#include "epilogue.h"
 
 namespace osn {
 
@@ -35,12 +36,13 @@ constexpr int WS_CH = 32 * WS_NG;   // pairs per workgroup at most
 
 // 4 waves; wave w < NW owns output columns [32 w, 32 w + 32) of the workgroup's column group (waves >= NW only gather
 // and stage); KS k-steps of 32 input channels per chunk (B fragments of a chunk: KS x 2 column blocks x 3 planes).
-template <int NW, int KS>
+// EPI (inference, direct launches): the stage's evaluation-mode batch norm in the epilogue (epilogue.h)
+template <int NW, int KS, bool EPI = false>
 __global__ __launch_bounds__(256) void spconv_ws_kernel(const float* __restrict__ in, const bf16x8* __restrict__ Wp,
                                                         const int32_t* __restrict__ gsrc, const int32_t* __restrict__ gdst,
                                                         const int32_t* __restrict__ poff, float* __restrict__ partial,
                                                         float* __restrict__ zeros, int n_dst, int K, int cin, int cout, int ns, int ncb, int chunk,
-                                                        int direct) {
+                                                        int direct, const Epi epi) {
     constexpr int NT = 256;
     constexpr int CK = 32 * KS;               // input channels per chunk
     constexpr int LDA = CK + 8;               // bf16 row stride of a staged plane (16-byte aligned rows)
@@ -161,6 +163,14 @@ __global__ __launch_bounds__(256) void spconv_ws_kernel(const float* __restrict_
         }
     }
     if (wave >= NW) return;
+    EpiCols ec[2];
+    if constexpr (EPI) {                         // (direct launches: the lane's two column quads, constants once)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int col = col0 + 32 * wave + 16 * nb + 4 * (lane >> 4);
+            ec[nb] = epi_cols(epi, col < cout ? col : 0);
+        }
+    }
     // ---- result rows -> partial[k][dst].  The weight fragment is the MFMA's FIRST operand (the staged rows the second), so a
     // block comes out transposed: lane l holds columns 4 (l >> 4) .. + 3 of pair l & 15 -- one 16-byte store per block
 #pragma unroll
@@ -175,9 +185,11 @@ __global__ __launch_bounds__(256) void spconv_ws_kernel(const float* __restrict_
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
                         const int col = col0 + 32 * wave + 16 * nb + 4 * (lane >> 4);
-                        if (col < cout)
-                            *reinterpret_cast<float4*>(row + col) =
-                                make_float4(acc[g][h][nb][0], acc[g][h][nb][1], acc[g][h][nb][2], acc[g][h][nb][3]);
+                        if (col < cout) {
+                            float4 v = make_float4(acc[g][h][nb][0], acc[g][h][nb][1], acc[g][h][nb][2], acc[g][h][nb][3]);
+                            if constexpr (EPI) v = epi_apply(epi, ec[nb], v, d, col, cout);
+                            *reinterpret_cast<float4*>(row + col) = v;
+                        }
                     }
                 }
             }
@@ -187,10 +199,10 @@ __global__ __launch_bounds__(256) void spconv_ws_kernel(const float* __restrict_
 
 // out[r] = sum over k ascending, nbr[k][r] >= 0, of partial[k][r]  (rows without any neighbour: zeros)
 // KT: offsets of the map when it is one of the two sizes the U-Net has (fully unrolled: all loads in flight), else 0.
-template <int KT>
+template <int KT, bool EPI = false>
 __global__ __launch_bounds__(256) void spconv_ws_reduce_kernel(const float* __restrict__ partial, const int32_t* __restrict__ nbr,
                                                                const float* __restrict__ zeros, float* __restrict__ out,
-                                                               int64_t n_dst, int K, int c4) {
+                                                               int64_t n_dst, int K, int c4, const Epi epi) {
     const int64_t total = n_dst * c4;
     const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (e >= total) return;
@@ -216,6 +228,7 @@ __global__ __launch_bounds__(256) void spconv_ws_reduce_kernel(const float* __re
             }
         }
     }
+    if constexpr (EPI) s = epi_quad(epi, s, r, 4 * c, 4 * c4);                 // evaluation-mode batch norm (epilogue.h)
     reinterpret_cast<float4*>(out)[e] = s;
 }
 
@@ -239,9 +252,9 @@ extern "C" size_t osn_spconv_fwd_ws_ws_bytes(int64_t n_dst, int K, int cout, int
     return 256 + (direct ? 0 : size_t(K) * size_t(n_dst > 0 ? n_dst : 0) * size_t(cout) * 4);
 }
 
-extern "C" int osn_spconv_fwd_ws(const float* in, int64_t n_in, const void* Wp, const void* pl, int64_t pl_rows,
-                                 int swap, int direct, const int32_t* nbr_dst, float* out, int64_t n_dst, int K, int cin, int cout,
-                                 void* ws, size_t ws_bytes, osn_stream_t stream) {
+int osn::spconv_fwd_ws_epi(const float* in, int64_t n_in, const void* Wp, const void* pl, int64_t pl_rows, int swap, int direct,
+                           const int32_t* nbr_dst, float* out, int64_t n_dst, int K, int cin, int cout, void* ws, size_t ws_bytes,
+                           const Epi& epi, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n_dst >= 0 && n_dst < (int64_t(1) << 31) && n_in >= 0 && n_in < (int64_t(1) << 31), OSN_E_ARG,
                 "osn_spconv_fwd_ws: row counts out of range");
@@ -271,8 +284,14 @@ extern "C" int osn_spconv_fwd_ws(const float* in, int64_t n_in, const void* Wp, 
     const dim3 grid(unsigned(cdiv(pmax, chunk)), unsigned(K), unsigned(gz));
     const bf16x8* wp = static_cast<const bf16x8*>(Wp);
 #define OSN_WS2(NW_, KS_)                                                                                              \
-    hipLaunchKernelGGL((spconv_ws_kernel<NW_, KS_>), grid, dim3(256), 0, st, in, wp, gsrc, gdst, v.poff, direct ? out : partial, zeros, \
-                       int(n_dst), K, cin, cout, ns, ncb, chunk, direct)
+    do {                                                                                                               \
+        if (direct && epi.mean)                                                                                        \
+            hipLaunchKernelGGL((spconv_ws_kernel<NW_, KS_, true>), grid, dim3(256), 0, st, in, wp, gsrc, gdst, v.poff, out, zeros, \
+                               int(n_dst), K, cin, cout, ns, ncb, chunk, direct, epi);                                 \
+        else                                                                                                           \
+            hipLaunchKernelGGL((spconv_ws_kernel<NW_, KS_, false>), grid, dim3(256), 0, st, in, wp, gsrc, gdst, v.poff,  \
+                               direct ? out : partial, zeros, int(n_dst), K, cin, cout, ns, ncb, chunk, direct, epi_none()); \
+    } while (0)
 #define OSN_WS(NW_)                                                                                                    \
     do {                                                                                                               \
         switch (ks) {                                                                                                  \
@@ -296,12 +315,21 @@ extern "C" int osn_spconv_fwd_ws(const float* in, int64_t n_in, const void* Wp, 
     }
     const int c4 = cout / 4;
     const dim3 rgrid(unsigned(cdiv(n_dst * c4, 256)));
-    if (K == 27)
-        hipLaunchKernelGGL(spconv_ws_reduce_kernel<27>, rgrid, dim3(256), 0, st, partial, nbr_dst, zeros, out, n_dst, K, c4);
-    else if (K == 8)
-        hipLaunchKernelGGL(spconv_ws_reduce_kernel<8>, rgrid, dim3(256), 0, st, partial, nbr_dst, zeros, out, n_dst, K, c4);
-    else
-        hipLaunchKernelGGL(spconv_ws_reduce_kernel<0>, rgrid, dim3(256), 0, st, partial, nbr_dst, zeros, out, n_dst, K, c4);
+#define OSN_WSR(KT_)                                                                                                                    \
+    do {                                                                                                                                \
+        if (epi.mean) hipLaunchKernelGGL((spconv_ws_reduce_kernel<KT_, true>), rgrid, dim3(256), 0, st, partial, nbr_dst, zeros, out, n_dst, K, c4, epi); \
+        else hipLaunchKernelGGL((spconv_ws_reduce_kernel<KT_, false>), rgrid, dim3(256), 0, st, partial, nbr_dst, zeros, out, n_dst, K, c4, epi);         \
+    } while (0)
+    if (K == 27) OSN_WSR(27);
+    else if (K == 8) OSN_WSR(8);
+    else OSN_WSR(0);
+#undef OSN_WSR
     OSN_LAUNCH_CHECK();
     return OSN_OK;
+}
+
+extern "C" int osn_spconv_fwd_ws(const float* in, int64_t n_in, const void* Wp, const void* pl, int64_t pl_rows,
+                                 int swap, int direct, const int32_t* nbr_dst, float* out, int64_t n_dst, int K, int cin, int cout,
+                                 void* ws, size_t ws_bytes, osn_stream_t stream) {
+    return spconv_fwd_ws_epi(in, n_in, Wp, pl, pl_rows, swap, direct, nbr_dst, out, n_dst, K, cin, cout, ws, ws_bytes, epi_none(), stream);
 }

@@ -12,6 +12,7 @@
 // the gathered input rows in LDS, and thread (4 offsets, channel n) runs a plain fmaf chain down the rows -- LDS-broadcast
 // operands, 12 accumulators, no cross-lane reduction; per-workgroup partial sums, summed in workgroup order.
 #include "common.h"
+#include "epilogue.h"
 
 namespace osn {
 
@@ -23,9 +24,10 @@ constexpr int STEM_COUT = 32;      // output channels handled per thread
 // 100 k-row table gives only 1.5 waves per SIMD, so the latency of the dependent table -> row -> FMA chain has to
 // be covered by instruction-level parallelism); W[k] is indexed by wave-uniform values only, so it is fetched
 // through the scalar cache (staging it in LDS per workgroup cost more than the whole convolution).
+template <bool EPI>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ in, const float* __restrict__ W,
                                                        const int32_t* __restrict__ nbr, float* __restrict__ out,
-                                                       int64_t n_out, int K, int cin) {
+                                                       int64_t n_out, int K, int cin, const Epi epi) {
     const int64_t o = int64_t(blockIdx.x) * 256 + threadIdx.x;
     const bool row_ok = o < n_out;
     const int64_t oc = row_ok ? o : 0;
@@ -58,7 +60,11 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     if (row_ok) {
         float4* dst = reinterpret_cast<float4*>(out + o * STEM_COUT);
 #pragma unroll
-        for (int c = 0; c < STEM_COUT / 4; ++c) dst[c] = make_float4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
+        for (int c = 0; c < STEM_COUT / 4; ++c) {
+            float4 v = make_float4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
+            if constexpr (EPI) v = epi_quad(epi, v, o, 4 * c, STEM_COUT);        // evaluation-mode batch norm (epilogue.h)
+            dst[c] = v;
+        }
     }
 }
 
@@ -67,9 +73,10 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 // of 125 dependent table -> row -> FMA steps; this gives 6 waves per SIMD and a chain of 32, and k stays wave-uniform, so
 // the weights still come through the scalar cache), the four partial rows meet in LDS and are added in a fixed tree
 // ((p0 + p1) + (p2 + p3)): deterministic, fp32 products exact.
+template <bool EPI>
 __global__ __launch_bounds__(256) void stem_fwd4_kernel(const float* __restrict__ in, const float* __restrict__ W,
                                                         const int32_t* __restrict__ nbr, float* __restrict__ out,
-                                                        int64_t n_out, int K, int cin) {
+                                                        int64_t n_out, int K, int cin, const Epi epi) {
     __shared__ float part[4][STEM_COUT][64 + 1];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -116,8 +123,13 @@ __global__ __launch_bounds__(256) void stem_fwd4_kernel(const float* __restrict_
             v[j] = (part[0][c][r] + part[1][c][r]) + (part[2][c][r] + part[3][c][r]);
         }
         float4* dst = reinterpret_cast<float4*>(out + orow * STEM_COUT + 8 * q);
-        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+        float4 v0 = make_float4(v[0], v[1], v[2], v[3]), v1 = make_float4(v[4], v[5], v[6], v[7]);
+        if constexpr (EPI) {                                                     // evaluation-mode batch norm (epilogue.h)
+            v0 = epi_quad(epi, v0, orow, 8 * q, STEM_COUT);
+            v1 = epi_quad(epi, v1, orow, 8 * q + 4, STEM_COUT);
+        }
+        dst[0] = v0;
+        dst[1] = v1;
     }
 }
 
@@ -243,8 +255,8 @@ extern "C" int osn_stem_conv_wgrad(const float* in, const float* gout, const int
     return OSN_OK;
 }
 
-extern "C" int osn_stem_conv_fwd(const float* in, const float* W, const int32_t* nbr, float* out, int64_t n_out, int K,
-                                 int cin, int cout, osn_stream_t stream) {
+int osn::stem_conv_fwd_epi(const float* in, const float* W, const int32_t* nbr, float* out, int64_t n_out, int K, int cin, int cout,
+                           const Epi& epi, osn_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     OSN_REQUIRE(n_out >= 0 && n_out < (int64_t(1) << 31), OSN_E_ARG, "osn_stem_conv_fwd: n_out out of range");
     OSN_REQUIRE(K >= 1 && K <= 125 && cin >= 1 && cin <= STEM_CMAX && cout == STEM_COUT, OSN_E_ARG,
@@ -253,9 +265,16 @@ extern "C" int osn_stem_conv_fwd(const float* in, const float* W, const int32_t*
     OSN_REQUIRE(in && W && nbr && out && aligned16(out), OSN_E_ARG, "osn_stem_conv_fwd: null or unaligned pointer");
     // four lanes per row from 4096 rows on (below that the single-lane kernel's launch is all there is)
     if (n_out >= 4096)
-        hipLaunchKernelGGL(stem_fwd4_kernel, dim3(unsigned(cdiv(n_out, 64))), dim3(256), 0, st, in, W, nbr, out, n_out, K, cin);
+        hipLaunchKernelGGL(epi.mean ? stem_fwd4_kernel<true> : stem_fwd4_kernel<false>, dim3(unsigned(cdiv(n_out, 64))), dim3(256), 0, st, in, W, nbr, out,
+                           n_out, K, cin, epi);
     else
-        hipLaunchKernelGGL(stem_fwd_kernel, dim3(unsigned(cdiv(n_out, 256))), dim3(256), 0, st, in, W, nbr, out, n_out, K, cin);
+        hipLaunchKernelGGL(epi.mean ? stem_fwd_kernel<true> : stem_fwd_kernel<false>, dim3(unsigned(cdiv(n_out, 256))), dim3(256), 0, st, in, W, nbr, out,
+                           n_out, K, cin, epi);
     OSN_LAUNCH_CHECK();
     return OSN_OK;
+}
+
+extern "C" int osn_stem_conv_fwd(const float* in, const float* W, const int32_t* nbr, float* out, int64_t n_out, int K,
+                                 int cin, int cout, osn_stream_t stream) {
+    return stem_conv_fwd_epi(in, W, nbr, out, n_out, K, cin, cout, epi_none(), stream);
 }

@@ -26,13 +26,15 @@ def is_unet(module):
 
 
 def _dispatcher(orig):
-    from . import executor
+    from . import executor, lazy_rows
     from . import functional as F_
 
     def forward(self, x):
         ex = executor.for_model(self)
         if ex is not None and ex.usable(x, self):
-            return ex.forward(self, x)
+            # (inference: the output's row gather stays lazy so that the reference's query lines -- run/evaluate.py:290-292 -- reach
+            #  the fused kernel unchanged; lazy_rows.py)
+            return lazy_rows.wrap_output(ex.forward(self, x))
         with F_.deferred_bn_counters():
             return orig(self, x)
 

@@ -81,6 +81,10 @@ class _Run(ctypes.Structure):
 
 
 RUN_NO_JOIN = 1                                 # include/openscene_amd.h: OSN_NET_RUN_NO_JOIN
+RUN_NO_BN_EPILOGUE = 2                          # include/openscene_amd.h: OSN_NET_RUN_NO_BN_EPILOGUE
+# Inference: every stage's batch norm (+ residual) (+ ReLU) (+ cat store) runs in the epilogue of the kernel that finishes the stage's
+# convolution (csrc/epilogue.h; bitwise the separate launch, 48 launches fewer per MinkUNet18A pass).  0: the separate launches (A/B, tests)
+BN_EPILOGUE = os.environ.get("OSN_BN_EPILOGUE", "1") != "0"
 
 
 def _ptr(a):
@@ -398,7 +402,8 @@ class UNetExecutor:
         side, ws2, events = self._side(lib, dev)
         run = _Run(_ptr(self._rows), _ptr(st.maps), _ptr(st.weights), _ptr(st.bns), feats.data_ptr(),
                    out.data_ptr() if out is not None else None, None, st.arena.data_ptr(), st.arena.numel(), None, 0,
-                   ws.data_ptr(), ws.numel(), ops.tl_counters(dev).data_ptr(), int(training), 0, end, 0, self.prof,
+                   ws.data_ptr(), ws.numel(), ops.tl_counters(dev).data_ptr(), int(training), 0, end,
+                   0 if (BN_EPILOGUE and not grad) else RUN_NO_BN_EPILOGUE, self.prof,      # (a pass with a backward pass keeps x)
                    side if events else None, ws2.data_ptr() if (events and ws2 is not None) else None,
                    ws2.numel() if (events and ws2 is not None) else 0, events, None, None, None, 0)
         with ops._Dev(dev):

@@ -228,24 +228,23 @@ def coords_pyramid(coords4, strides=(1, 2, 4, 8, 16)):
     lib = _prep(dev)
     coords4 = coords4.contiguous()
     L = len(strides)
-    counts = torch.zeros(L + 1, dtype=torch.int32, device=dev)        # [0 .. L-1] unique rows per level, [L] range error
+    counts = torch.empty(L + 1, dtype=torch.int32, device=dev)        # [0 .. L-1] unique rows per level, [L] range error (zeroed by the call)
     ws = _ws(_cached("osn_coords_unique_ws_bytes", n0), dev)
     st = _stream(dev)
-    bufs, prev, n_dev = [], coords4, None
+    bufs = []
+    for _ in strides:
+        bufs.append((torch.empty((n0, 4), dtype=torch.int32, device=dev), torch.empty(n0, dtype=torch.int32, device=dev),
+                     torch.empty(n0, dtype=torch.int32, device=dev), HashTable(n0, dev)))
+    arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
     with _Dev(dev):
-        for li, s in enumerate(strides):
-            table = HashTable(n0, dev)
-            out = torch.empty((n0, 4), dtype=torch.int32, device=dev)
-            inverse = torch.empty(n0, dtype=torch.int32, device=dev)
-            first = torch.empty(n0, dtype=torch.int32, device=dev)
-            check(lib.osn_coords_unique_async(_p(prev), n0, n_dev, int(s), _p(table.keys), _p(table.vals), table.cap, _p(out),
-                                              _p(inverse), _p(first), counts.data_ptr() + 4 * li, counts.data_ptr() + 4 * L,
-                                              _p(ws), ws.numel(), st), "osn_coords_unique_async")
-            bufs.append((out, inverse, first, table))
-            prev, n_dev = out, counts.data_ptr() + 4 * li
+        # one call, one preset launch for every table (round 6; was one osn_coords_unique_async per level)
+        check(lib.osn_coords_pyramid_async(_p(coords4), n0, (ctypes.c_int32 * L)(*[int(s) for s in strides]), L,
+                                           arr([b[3].keys for b in bufs]), arr([b[3].vals for b in bufs]), bufs[0][3].cap,
+                                           arr([b[0] for b in bufs]), arr([b[1] for b in bufs]), arr([b[2] for b in bufs]),
+                                           _p(counts), _p(ws), ws.numel(), st), "osn_coords_pyramid_async")
     host = counts.tolist()                                             # the one synchronisation
     if host[L]:
-        raise _lib.OpenSceneAmdError("osn_coords_unique_async: coordinate outside the packable range "
+        raise _lib.OpenSceneAmdError("osn_coords_pyramid_async: coordinate outside the packable range "
                                      "(|x|,|y|,|z| < 32767, 0 <= batch < 65535)")
     res, u_prev = [], n0
     for (out, inverse, first, table), u in zip(bufs, host[:L]):

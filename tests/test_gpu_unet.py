@@ -387,6 +387,36 @@ def test_executor_equals_the_module_path(monkeypatch):
     assert worst <= 2e-6, "worst parameter-gradient difference between the two host paths: %.3e" % worst
 
 
+@pytest.mark.parametrize("arch,n_pts,vox", [("MinkUNet18A", 30000, 0.03), ("MinkUNet34C", 120000, 0.02), ("MinkUNet14A", 3000, 0.05)])
+def test_inference_bn_epilogue_is_bitwise_the_separate_launches(arch, n_pts, vox, monkeypatch):
+    """Round 6: in an inference pass every stage's evaluation-mode batch norm (+ residual, ReLU, cat store) runs in the epilogue of the
+    kernel that finishes the stage's convolution (csrc/epilogue.h) -- tile-list (single and split launches), weight-stationary (reduce and
+    direct), register-gather, 1x1 and stem kernels.  Same expression, same order: outputs and feature taps bitwise equal to the pass with
+    the separate osn_bn_apply2 launches (OSN_NET_RUN_NO_BN_EPILOGUE), which test_executor_equals_the_module_path ties to the module path."""
+    from openscene_amd import executor
+    from openscene_amd.mink_unet import mink_unet
+    from openscene_amd.sparse import SparseTensor
+    d = dev()
+    coords = torch.from_numpy(scene_coords(61, n_pts, vox, batch=2 if n_pts < 100000 else 1)).to(d)
+    feats = torch.rand(coords.shape[0], 3, device=d)
+    torch.manual_seed(11)
+    model = mink_unet(3, 48, 3, arch).to(d).train()
+    with torch.no_grad():
+        for _ in range(2):
+            model(SparseTensor(feats, coords))              # running statistics away from (0, 1)
+    model.eval()
+    got = {}
+    for on in (False, True):
+        monkeypatch.setattr(executor, "BN_EPILOGUE", on)
+        with torch.no_grad():
+            out = model(SparseTensor(feats, coords)).clone()
+            ft = model.forward_features(SparseTensor(feats, coords))
+            ft = (ft[0] if isinstance(ft, tuple) else ft).clone()
+        got[on] = (out, ft)
+    assert torch.equal(got[True][0], got[False][0]) and torch.equal(got[True][1], got[False][1])
+    assert got[True][0].abs().max().item() > 0 and torch.isfinite(got[True][0]).all()
+
+
 def test_executor_with_frozen_and_eval_mode_gradients():
     """A frozen parameter gets no gradient; evaluation-mode BN (running statistics) inside a graph that needs gradients
     back-propagates through the executor like the module path does."""
@@ -599,5 +629,24 @@ def test_foreign_class_through_the_alias_runs_the_executor_on_the_gpu(monkeypatc
         step(theirs, ME.SparseTensor(feats, coords))
         optimizer.step()
         assert all(not torch.equal(p, q) for p, q in zip(theirs.parameters(), before))
+        # inference through the same class: run/evaluate.py:289-292 as written -- the row gather stays lazy and the matmul is the fused
+        # query kernel (openscene_amd/lazy_rows.py); training outputs (above) were plain tensors
+        from openscene_amd.lazy_rows import GatheredRows, NetworkOutput
+        from openscene_amd.query import query_distill
+        assert type(a_out) is torch.Tensor
+        theirs.eval()
+        inds_reverse = torch.randint(0, coords.shape[0], (70000,), device=d)
+        text_features = torch.nn.functional.normalize(torch.randn(20, 48, device=d), dim=1).half()
+        with torch.no_grad():
+            predictions = theirs(ME.SparseTensor(feats, coords))
+            assert type(predictions) is NetworkOutput
+            dense = predictions.clone()
+            predictions = predictions[inds_reverse, :]
+            assert type(predictions) is GatheredRows
+            pred = predictions.half() @ text_features.t()
+            logits_pred = torch.max(pred, 1)[1].cpu()
+            assert predictions._real is None and type(pred) is torch.Tensor
+            labels, scores = query_distill(dense, text_features, inds_reverse, return_scores=True)
+            assert torch.equal(pred, scores) and torch.equal(logits_pred, labels.cpu())
     finally:
         drop_in.remove_import_hook()
