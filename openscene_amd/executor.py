@@ -85,6 +85,11 @@ RUN_NO_BN_EPILOGUE = 2                          # include/openscene_amd.h: OSN_N
 # Inference: every stage's batch norm (+ residual) (+ ReLU) (+ cat store) runs in the epilogue of the kernel that finishes the stage's
 # convolution (csrc/epilogue.h; bitwise the separate launch, 48 launches fewer per MinkUNet18A pass).  0: the separate launches (A/B, tests)
 BN_EPILOGUE = os.environ.get("OSN_BN_EPILOGUE", "1") != "0"
+# Streams the map chains of an INFERENCE pass are dealt to (ops.maps_build; training keeps ops.MAPS_STREAMS = 1: its maps are built
+# beside the previous step on the prefetcher's stream, and more streams than hardware queues hurt there).  With the host-side
+# marshalling cached (round 6) the pass is no longer waiting on the host between the map build and the forward pass, so the
+# shorter map phase shows: maps_only 1.04 -> 0.79 ms (tools/maps_host_time.py)
+INFER_MAPS_STREAMS = int(os.environ.get("OSN_INFER_MAPS_STREAMS", "3"))
 
 
 def _ptr(a):
@@ -211,6 +216,12 @@ class UNetExecutor:
         self.grad_segments = 4
         self._cuts = None
         self._events = {}                 # device index -> osn_events_t* (fork / join of the backward pass)
+        # marshalling caches (round 6): the weight / batch-norm descriptor arrays of a pass are pure functions of the parameters'
+        # addresses and versions -- rebuilt only when the fingerprint of a pass differs from the last one's (see _fingerprint)
+        self._bn_mods = None
+        self._w_cache = None              # (key, array, keep-alive list)
+        self._bn_cache = None             # (key, array)
+        self._flips = None
         # gradient layout: one flat fp32 buffer, every parameter's slice starts on a 16-byte boundary
         self.grad_off, off = [], 0
         for prm in p.params:
@@ -233,13 +244,40 @@ class UNetExecutor:
         if f.requires_grad and torch.is_grad_enabled():
             return False                    # the node has no input-feature gradient (op 0 is planned without one): module path
         training = bool(model.training) if model is not None else None
-        for m in p.bns:
-            b = m.bn
+        dev = f.device
+        for m, b in zip(p.bns, self._bn_modules()):
             if training is not None and (bool(b.training) != training or bool(m.training) != training):
                 return False                # per-BN flags (frozen statistics): the executor applies ONE flag to every BN
-            if b.momentum is None or not b.affine or not b.track_running_stats or b.weight.device != f.device:
+            if b.momentum is None or not b.affine or not b.track_running_stats or b._parameters["weight"].device != dev:
                 return False
-        return all(c.kernel.device == f.device and c.kernel.dtype == torch.float32 for c in p.convs)
+        f32 = torch.float32
+        for w in p.params[:len(p.convs)]:
+            if w.device != dev or w.dtype != f32:
+                return False
+        return True
+
+    def _bn_modules(self):
+        """The torch BatchNorm1d inside every MinkowskiBatchNorm, looked up once (nn.Module.__getattr__ is the slow path of every
+        `m.bn` / `b.weight`: 480 calls per pass before round 6); a replaced sub-module is noticed by identity."""
+        mods = self._bn_mods
+        bns = self.program.bns
+        if mods is None or any(m._modules.get("bn") is not b for m, b in zip(bns, mods)):
+            mods = self._bn_mods = [m.bn for m in bns]
+        return mods
+
+    def _fingerprint(self):
+        """What the descriptor arrays depend on: the address of every parameter and running statistic, the version of every kernel (its
+        weight images), eps / momentum of every norm.  ~350 C-level reads (tens of microseconds) against rebuilding two numpy record
+        arrays through ~500 module attribute look-ups."""
+        p = self.program
+        nc = len(p.convs)
+        fp = [t.data_ptr() for t in p.params]
+        fp += [t._version for t in p.params[:nc]]
+        for b in self._bn_modules():
+            d = b._buffers
+            rm, rv = d["running_mean"], d["running_var"]
+            fp += (rm.data_ptr() if rm is not None else 0, rv.data_ptr() if rv is not None else 0, b.eps, b.momentum)
+        return tuple(fp)
 
     # -------------------------------------------------------------------------------------------- marshalling
     def _plan_query(self, lib, rows, training):
@@ -280,15 +318,23 @@ class UNetExecutor:
             keep.append((fwd, bwd, tf, tb, counts, lf, lb))
         return arr, keep
 
-    def _weights(self, cm, need_images):
+    def _weights(self, cm, need_images, fp=None, mutable=False):
+        """fp (a _fingerprint): reuse the last pass's array when nothing it depends on has changed (mutable: a private copy -- the
+        backward pass writes the gradient addresses into it)."""
         p = self.program
+        key = None
+        if fp is not None and ops.WEIGHT_CACHE:
+            key = (fp, need_images.tobytes(), cm.device)
+            hit = self._w_cache
+            if hit is not None and hit[0] == key:
+                return (hit[1].copy() if mutable else hit[1]), hit[2]
         arr = np.zeros(len(p.convs), dtype=_WEIGHT)
         keep = []
-        flips = {}
-        for i, (s_in, s_out, k, dil) in enumerate(p.map_keys):
-            flips[i] = bool(cm.kmap(s_in, s_out, k, dil)[2])
-        for i, conv in enumerate(p.convs):
-            w = conv.kernel
+        if self._flips is None:
+            # (static per map key: the map of an odd stride-1 kernel is its own mirror, sparse.CoordinateManager.kmap)
+            self._flips = {i: bool(cm.kmap(s_in, s_out, k, dil)[2]) for i, (s_in, s_out, k, dil) in enumerate(p.map_keys)}
+        flips = self._flips
+        for i, w in enumerate(p.params[:len(p.convs)]):
             a = arr[i]
             a["W"] = w.data_ptr()
             bits = int(need_images[i])
@@ -301,17 +347,26 @@ class UNetExecutor:
                 t = ops.weight_image(w, flip, True, ops.PREP_X6); a["x6_dgrad"] = t.data_ptr(); keep.append(t)
             if bits & IMG_TL_DGRAD:
                 t = ops.weight_image(w, flip, True, ops.PREP_TL); a["tl_dgrad"] = t.data_ptr(); keep.append(t)
+        if key is not None:
+            self._w_cache = (key, arr, keep)
+            return (arr.copy() if mutable else arr), keep
         return arr, keep
 
-    def _bns(self, training):
+    def _bns(self, training, fp=None, mutable=False):
         p = self.program
+        if fp is not None:
+            hit = self._bn_cache
+            if hit is not None and hit[0] == fp:
+                return hit[1].copy() if mutable else hit[1]
         arr = np.zeros(max(len(p.bns), 1), dtype=_BN)
-        for i, m in enumerate(p.bns):
-            b = m.bn
+        for i, b in enumerate(self._bn_modules()):
             a = arr[i]
             a["gamma"], a["beta"] = b.weight.data_ptr(), b.bias.data_ptr()
             a["running_mean"], a["running_var"] = b.running_mean.data_ptr(), b.running_var.data_ptr()
             a["eps"], a["momentum"] = b.eps, b.momentum
+        if fp is not None:
+            self._bn_cache = (fp, arr)
+            return arr.copy() if mutable else arr
         return arr
 
     # -------------------------------------------------------------------------------------------- passes
@@ -368,7 +423,8 @@ class UNetExecutor:
         dev = feats.device
         lib = ops._prep(dev)
         training = bool(model.training)
-        cm.prebuild(pairs=True if grad else "ws")
+        # (inference builds its maps inside the pass and nothing else is in flight: the map chains on INFER_MAPS_STREAMS streams)
+        cm.prebuild(pairs=True if grad else "ws", streams=None if grad else INFER_MAPS_STREAMS)
         rows = [cm.size(s) for s in p.STRIDES]
         if feats.shape[0] != rows[0]:
             raise ValueError("%d feature rows for %d voxels" % (feats.shape[0], rows[0]))
@@ -387,9 +443,14 @@ class UNetExecutor:
                 st.weights, keep_w = self._weights(cm, self._img)
             prep_done = torch.cuda.Event()
             prep_done.record(side_t)
-        else:
+            st.bns = self._bns(training)
+        elif grad:
             st.weights, keep_w = self._weights(cm, self._img)
-        st.bns = self._bns(training)
+            st.bns = self._bns(training)
+        else:
+            fp = self._fingerprint()                             # inference: both arrays from the last pass when nothing moved
+            st.weights, keep_w = self._weights(cm, self._img, fp)
+            st.bns = self._bns(training, fp)
         st.arena = torch.empty(int(self._plan.fwd_arena_bytes), dtype=torch.uint8, device=dev)
         st.plan_fwd_bytes = int(self._plan.fwd_arena_bytes)
         st.keep = (keep_m, keep_w)

@@ -338,7 +338,7 @@ def _addr(v):
     return 0 if v is None else (int(v) if isinstance(v, int) else v.data_ptr())
 
 
-def maps_build(levels, jobs, dev, sort_rows):
+def maps_build(levels, jobs, dev, sort_rows, streams=None):
     """levels: [(coords4, HashTable, rows)]; jobs: list of dicts with the fields of osn_map_job (tensors, device addresses
     or None for the pointers, `stream` = 0 .. MAPS_STREAMS - 1); sort_rows: rows of the largest table that gets tile-ordered (scratch
     size).  One C call; the maps of different levels run side by side on MAPS_STREAMS streams (fork / join inside)."""
@@ -351,7 +351,7 @@ def maps_build(levels, jobs, dev, sort_rows):
     ja = np.zeros(max(len(jobs), 1), dtype=jdt)
     for i, q in enumerate(jobs):
         ja[i] = tuple((_addr(q.get(n)) if jdt[n].kind == "u" else int(q.get(n, 0))) for n in jdt.names)
-    ns = max(1, min(MAPS_STREAMS, 4))
+    ns = max(1, min(int(streams) if streams else MAPS_STREAMS, 4))      # (streams: the caller's choice -- the executor's inference pass)
     idx = _idx(dev)
     main = _stream(dev)
     raws = [main]

@@ -113,7 +113,7 @@ class CoordinateManager:
                 self._kmaps[key] = ops.kmap_count(fwd) if fwd is not None else None
         return self._kmaps[key]
 
-    def prebuild(self, strides=(2, 4, 8, 16), kernel_sizes=(3,), stem_kernel=5, pairs=False):
+    def prebuild(self, strides=(2, 4, 8, 16), kernel_sizes=(3,), stem_kernel=5, pairs=False, streams=None):
         """Build every kernel map (and any level of the pyramid the constructor did not create) up front, before any
         heavy kernel is queued: the host then runs ahead of the GPU for the rest of the forward/backward pass instead of
         stopping at every first use of a map.  (The pyramid's levels 1 ... 16 were built by the constructor with one
@@ -125,7 +125,7 @@ class CoordinateManager:
             self.coords(s)
         levels = (1,) + tuple(strides)
         if self.device.type == "cuda" and all(self.size(s) > 0 for s in levels):
-            self._prebuild_fast(levels, kernel_sizes, stem_kernel, pairs)
+            self._prebuild_fast(levels, kernel_sizes, stem_kernel, pairs, streams)
         if stem_kernel:
             self.kmap(1, 1, stem_kernel)
             self.kmap_tiles(1, 1, stem_kernel)
@@ -146,7 +146,7 @@ class CoordinateManager:
         """kmap_tiles' rule: which tables get a tile-ordered copy."""
         return K <= 32 and rows >= self.SORT_MIN_ROWS and not (K <= 8 and rows < self.SORT_MIN_ROWS_K8)
 
-    def _prebuild_fast(self, levels, kernel_sizes, stem_kernel, pairs):
+    def _prebuild_fast(self, levels, kernel_sizes, stem_kernel, pairs, streams=None):
         """The maps prebuild() asks for, not cached yet, as jobs of one ops.maps_build call; results land in the caches
         kmap() / kmap_counts() / kmap_tiles() / kmap_lists() read -- the same tensors the per-map path would create.
         The GPU is idle when this runs (the pyramid's size read-back has just returned), so the launches go out first:
@@ -202,7 +202,7 @@ class CoordinateManager:
                 if f in e:
                     q[f] = base + e[f][0]
             jobs.append(q)
-        ops.maps_build([(self._coords[s], self._tables[s], self.size(s)) for s in levels], jobs, dev, sort_rows)
+        ops.maps_build([(self._coords[s], self._tables[s], self.size(s)) for s in levels], jobs, dev, sort_rows, streams)
 
         # ---- the launches are queued; now the views the rest of the library works with
         def view(e, f, dtype, shape):
