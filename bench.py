@@ -1077,7 +1077,10 @@ def main():
                 return model(SparseTensor(feats, coords0))
 
         def maps_only():
-            SparseTensor(feats, coords0).coordinate_manager.prebuild()
+            # what an inference pass builds, the way it builds it (executor._run_forward: pair arrays of the weight-stationary
+            # launches, map chains on INFER_MAPS_STREAMS streams)
+            from openscene_amd import executor as _exi
+            SparseTensor(feats, coords0).coordinate_manager.prebuild(pairs="ws", streams=_exi.INFER_MAPS_STREAMS)
 
         fwd_ms = timed(infer, 10)
         maps_ms = timed(maps_only, 10)
@@ -1113,7 +1116,8 @@ def main():
             stream_ms = timed(infer_stream, 20)
         extra = {"inference_fwd": {"ms": fwd_ms, "voxels_per_s": n_vox / (fwd_ms * 1e-3),
                                    "what": "configs[1]: maps + eval-mode forward, %d-d output" % out_dim},
-                 "maps_only": {"ms": maps_ms, "what": "coordinate pyramid + every kernel map + tile ordering of one scene"},
+                 "maps_only": {"ms": maps_ms, "what": "coordinate pyramid + every kernel map + tile ordering + the pair arrays an inference pass reads, "
+                                                      "of one scene, as the inference pass builds them (three streams)"},
                  "inference_plus_query": {"ms": unf_ms, "what": "maps + eval forward + 150 k-point / 20-label query (run/evaluate.py:283-292)"},
                  "inference_plus_query_fused_head": {"ms": fus_ms, "what": "the same with the final 1x1 conv folded into the text "
                                                      "matrix (SURVEY.md 8(f) row 2): no [N, %d] feature matrix" % out_dim},

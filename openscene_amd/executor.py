@@ -90,6 +90,7 @@ BN_EPILOGUE = os.environ.get("OSN_BN_EPILOGUE", "1") != "0"
 # marshalling cached (round 6) the pass is no longer waiting on the host between the map build and the forward pass, so the
 # shorter map phase shows: maps_only 1.04 -> 0.79 ms (tools/maps_host_time.py)
 INFER_MAPS_STREAMS = int(os.environ.get("OSN_INFER_MAPS_STREAMS", "3"))
+TRAIN_MAPS_STREAMS = os.environ.get("OSN_TRAIN_MAPS_STREAMS", "1") != "0"     # the same for the maps a training step builds inside itself
 
 
 def _ptr(a):
@@ -423,8 +424,10 @@ class UNetExecutor:
         dev = feats.device
         lib = ops._prep(dev)
         training = bool(model.training)
-        # (inference builds its maps inside the pass and nothing else is in flight: the map chains on INFER_MAPS_STREAMS streams)
-        cm.prebuild(pairs=True if grad else "ws", streams=None if grad else INFER_MAPS_STREAMS)
+        # (maps that are built HERE are built inside the pass -- inference, or a training step whose call site prefetches nothing,
+        #  run/distill.py:315-321 unchanged -- with nothing else of this pass in flight: the map chains on INFER_MAPS_STREAMS streams.
+        #  Prefetched maps are in the manager's caches already and nothing is built.)
+        cm.prebuild(pairs=True if grad else "ws", streams=INFER_MAPS_STREAMS if (not grad or TRAIN_MAPS_STREAMS) else None)
         rows = [cm.size(s) for s in p.STRIDES]
         if feats.shape[0] != rows[0]:
             raise ValueError("%d feature rows for %d voxels" % (feats.shape[0], rows[0]))

@@ -91,6 +91,22 @@ def side_stream(dev):
     return s
 
 
+_aux_streams = {}
+
+
+def aux_stream(dev):
+    """The THIRD stream of the process (per device, high priority, created on first use): the map prefetcher's stream, and the third
+    lane of an inference pass's map build.  The library never creates a fourth: the process is held to three hardware queues
+    (openscene_amd.configure_hw_queues), and a stream beyond them shares a queue with one that matters (round 6: two extra map
+    streams moved a LATER prefetcher onto the main stream's queue and the scene-stream inference went from 2.85 to 4.85 ms per scene)."""
+    i = _idx(dev)
+    s = _aux_streams.get(i)
+    if s is None:
+        _lo, hi = torch.cuda.Stream.priority_range()
+        s = _aux_streams[i] = torch.cuda.Stream(device=i, priority=hi)
+    return s
+
+
 # Scratch for the C-ABI calls: ONE growing buffer per (device, stream).  Every call's scratch is only
 # live while that call's kernels run, and calls on one stream execute in order (autograd's backward
 # thread launches on the same stream), so sharing is safe and saves a torch.empty per launch.
@@ -351,14 +367,14 @@ def maps_build(levels, jobs, dev, sort_rows, streams=None):
     ja = np.zeros(max(len(jobs), 1), dtype=jdt)
     for i, q in enumerate(jobs):
         ja[i] = tuple((_addr(q.get(n)) if jdt[n].kind == "u" else int(q.get(n, 0))) for n in jdt.names)
-    ns = max(1, min(int(streams) if streams else MAPS_STREAMS, 4))      # (streams: the caller's choice -- the executor's inference pass)
+    ns = max(1, min(int(streams) if streams else MAPS_STREAMS, 3))      # (streams: the caller's choice -- the executor's inference pass)
     idx = _idx(dev)
     main = _stream(dev)
     raws = [main]
     if ns > 1:
-        pool = _map_streams.get(idx)
-        if pool is None:
-            pool = _map_streams[idx] = [torch.cuda.Stream(device=idx) for _ in range(3)]
+        # lanes 1, 2: the two auxiliary streams the process has anyway (the executor's side stream, the prefetcher's) -- never new ones
+        pool = [s for s in (side_stream(dev), aux_stream(dev)) if s.cuda_stream != main]
+        ns = min(ns, 1 + len(pool))
         raws += [s.cuda_stream for s in pool[:ns - 1]]
         ev = _map_events.get(idx)
         if ev is None:

@@ -344,8 +344,7 @@ class MapPrefetcher:
         part of a step during which nothing else can run); the kernel maps are then built inside the step, from one C call
         (ops.maps_build), when the forward pass asks for them."""
         self.device = torch.device(device)
-        _lo, hi = torch.cuda.Stream.priority_range()
-        self.stream = torch.cuda.Stream(self.device, priority=hi)
+        self.stream = ops.aux_stream(self.device)     # the process's third stream (one per device, high priority; shared by every prefetcher)
         self.prebuild_args = prebuild_args
         self.pyramid_only = bool(pyramid_only)
         self.threaded = bool(threaded)
