@@ -325,7 +325,7 @@ class UNetExecutor:
         p = self.program
         key = None
         if fp is not None and ops.WEIGHT_CACHE:
-            key = (fp, need_images.tobytes(), cm.device)
+            key = (fp, need_images.tobytes(), cm.device, ops.WEIGHT_CACHE_GENERATION)
             hit = self._w_cache
             if hit is not None and hit[0] == key:
                 return (hit[1].copy() if mutable else hit[1]), hit[2]

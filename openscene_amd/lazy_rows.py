@@ -57,6 +57,12 @@ def _row_index(index, base):
 class NetworkOutput(torch.Tensor):
     """The [N_vox, D] output of an accelerated forward pass in inference: a tensor like any other, except that a row gather is lazy."""
 
+    def __reduce_ex__(self, proto):                      # pickles / torch.save as the plain tensor it is
+        return self.as_subclass(torch.Tensor).__reduce_ex__(proto)
+
+    def __deepcopy__(self, memo):
+        return self.as_subclass(torch.Tensor).__deepcopy__(memo)
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
@@ -82,6 +88,12 @@ class GatheredRows(torch.Tensor):
 
     def __init__(self, *a, **k):
         pass
+
+    def __reduce_ex__(self, proto):
+        return self.materialize().__reduce_ex__(proto)
+
+    def __deepcopy__(self, memo):
+        return self.materialize().clone()
 
     def materialize(self):
         """The rows, gathered by torch (cached): what the reference's expression holds at this point."""

@@ -572,7 +572,12 @@ class _WeightImages:
 _weight_images = {}
 
 
+WEIGHT_CACHE_GENERATION = 0          # moves when the cache is emptied (the executor's descriptor cache keys on it)
+
+
 def clear_weight_cache():
+    global WEIGHT_CACHE_GENERATION
+    WEIGHT_CACHE_GENERATION += 1
     _weight_images.clear()
 
 

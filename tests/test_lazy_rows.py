@@ -43,6 +43,19 @@ def test_reference_expressions_on_cpu_equal_plain_torch():
         assert (predictions.cpu().numpy() == rows.numpy()).all()
         assert predictions._real is not None                                 # gathered once, cached
         assert "tensor(" in repr(predictions)
+        # copies and serialisation see plain tensors (run/evaluate.py:330 saves features with np.save; a user may torch.save them)
+        import copy, io, pickle
+        o = wrap_output(out.clone())
+        lazy = o[inds]
+        for obj, ref_t in ((o, out), (lazy, out[inds])):
+            assert type(copy.deepcopy(obj)) is torch.Tensor and torch.equal(copy.deepcopy(obj), ref_t)
+            assert type(pickle.loads(pickle.dumps(obj))) is torch.Tensor
+            buf = io.BytesIO()
+            torch.save(obj, buf)
+            buf.seek(0)
+            back = torch.load(buf)
+            assert type(back) is torch.Tensor and torch.equal(back, ref_t)
+        assert torch.equal(lazy.to(torch.float16), out[inds].half()) and lazy.T.shape == (64, 1000) and lazy[0].shape == (64,)
 
 
 def test_only_plain_row_gathers_are_lazy_and_nothing_under_autograd():
