@@ -602,6 +602,8 @@ def headline(detail, detail_path=None):
                 line["query"][k] = {"ms": _num(q[k]["ms"]), "hbm_frac": _num(q[k]["hbm_frac"])}
         if "torch_call_site" in q:
             line["query"]["torch_call_site_ms"] = _num(q["torch_call_site"]["ms"])
+        if "call_site_unchanged" in q:        # run/evaluate.py:290-292 as written, on an accelerated model's output (lazy_rows.py)
+            line["query"]["call_site_unchanged_ms"] = _num(q["call_site_unchanged"]["ms"])
     if detail.get("voxelizer"):
         line["voxelizer_ms"] = _num(detail["voxelizer"]["ms"])
     ph = detail.get("phases")
