@@ -13,7 +13,6 @@
 // operands, 12 accumulators, no cross-lane reduction; per-workgroup partial sums, summed in workgroup order.
 #include "common.h"
 #include "epilogue.h"
-#include <atomic>
 
 namespace osn {
 
@@ -131,99 +130,6 @@ __global__ __launch_bounds__(256) void stem_fwd4_kernel(const float* __restrict_
         }
         dst[0] = v0;
         dst[1] = v1;
-    }
-}
-
-// Round 6: the same convolution with the WEIGHTS IN LDS and persistent workgroups.  stem_fwd4_kernel's waves fetch W[k] through the
-// scalar cache -- 96 scalar registers per offset, so every offset is a serialised s_load -> wait -> 96 FMAs, and the 48 KB weight
-// does not fit the 16 KB scalar cache the CU's waves share: ~2.5 us of exposed latency per offset and wave, 81 us per launch for 12 us
-// of instructions (this is the first kernel of every forward pass and nothing runs beside it).  Here a workgroup stages W once
-// (dynamic LDS, K x cin x 32 floats) and walks 64-row blocks; a wave reads the weights of an offset with wave-uniform ds_read_b128
-// (broadcast), table entries are loaded two trips ahead and input rows one trip ahead.  Same offsets per wave, same fmaf order,
-// same (p0 + p1) + (p2 + p3) tree as stem_fwd4_kernel: BITWISE the same output.
-template <bool EPI>
-__global__ __launch_bounds__(256, 2) void stem_fwd_lds_kernel(const float* __restrict__ in, const float* __restrict__ W,
-                                                              const int32_t* __restrict__ nbr, float* __restrict__ out,
-                                                              int64_t n_out, int K, int cin, const Epi epi) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];                 // [K][cin][32]
-    __shared__ float part[3][STEM_COUT][64 + 1];                               // waves 1 .. 3 (wave 0 keeps its sums in registers)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wfloats = K * cin * STEM_COUT;
-    for (int i = tid * 4; i < wfloats; i += 256 * 4) *reinterpret_cast<float4*>(wl + i) = *reinterpret_cast<const float4*>(W + i);
-    __syncthreads();
-    const int64_t n_blocks = (n_out + 63) / 64;
-    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const int64_t o = blk * 64 + lane;
-        const bool row_ok = o < n_out;
-        const int64_t oc = row_ok ? o : 0;
-        float acc[STEM_COUT];
-#pragma unroll
-        for (int c = 0; c < STEM_COUT; ++c) acc[c] = 0.f;
-        auto load_idx = [&](int k0, int (&idx)[4]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) idx[u] = (row_ok && k0 + 4 * u < K) ? nbr[int64_t(k0 + 4 * u) * n_out + oc] : -1;
-        };
-        auto gather = [&](const int (&idx)[4], float (&x)[4][STEM_CMAX]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int ci = 0; ci < STEM_CMAX; ++ci) x[u][ci] = (idx[u] >= 0 && ci < cin) ? in[int64_t(idx[u]) * cin + ci] : 0.f;
-        };
-        int idx_a[4], idx_b[4];
-        float xa[4][STEM_CMAX], xb[4][STEM_CMAX];
-        load_idx(wave, idx_a);
-        load_idx(wave + 16, idx_b);
-        gather(idx_a, xa);
-        auto trip = [&](int k0, float (&x)[4][STEM_CMAX], int (&idx_nxt)[4], float (&x_nxt)[4][STEM_CMAX], int (&idx_cur)[4]) {
-            gather(idx_nxt, x_nxt);                           // the next trip's rows (its entries arrived during the previous trip)
-            load_idx(k0 + 32, idx_cur);                       // the trip after that: its table entries
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (k0 + 4 * u < K) {
-                    const float* w = wl + (k0 + 4 * u) * cin * STEM_COUT;          // wave-uniform LDS address: broadcast reads
-#pragma unroll
-                    for (int ci = 0; ci < STEM_CMAX; ++ci)
-                        if (ci < cin) {
-#pragma unroll
-                            for (int c4 = 0; c4 < STEM_COUT / 4; ++c4) {
-                                const float4 wv = *reinterpret_cast<const float4*>(w + ci * STEM_COUT + 4 * c4);
-                                acc[4 * c4 + 0] = fmaf(x[u][ci], wv.x, acc[4 * c4 + 0]);
-                                acc[4 * c4 + 1] = fmaf(x[u][ci], wv.y, acc[4 * c4 + 1]);
-                                acc[4 * c4 + 2] = fmaf(x[u][ci], wv.z, acc[4 * c4 + 2]);
-                                acc[4 * c4 + 3] = fmaf(x[u][ci], wv.w, acc[4 * c4 + 3]);
-                            }
-                        }
-                }
-            }
-        };
-        for (int k0 = wave; k0 < K; k0 += 32) {               // two trips per iteration (register sets a / b alternate)
-            trip(k0, xa, idx_b, xb, idx_a);
-            if (k0 + 16 < K) trip(k0 + 16, xb, idx_a, xa, idx_b);
-        }
-        if (blk != blockIdx.x) __syncthreads();                // the previous block's partial rows have been read
-        if (wave > 0) {
-#pragma unroll
-            for (int c = 0; c < STEM_COUT; ++c) part[wave - 1][c][lane] = acc[c];
-        }
-        __syncthreads();
-        // wave 0's own sums stay in registers: lane = row, it adds the three other waves' rows in the kernel's fixed tree
-        // ((p0 + p1) + (p2 + p3)) and stores its row (8 quads)
-        if (wave == 0 && row_ok) {
-            float4* dst = reinterpret_cast<float4*>(out + o * STEM_COUT);
-#pragma unroll
-            for (int c4 = 0; c4 < STEM_COUT / 4; ++c4) {
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = 4 * c4 + j;
-                    v[j] = (acc[c] + part[0][c][lane]) + (part[1][c][lane] + part[2][c][lane]);
-                }
-                float4 q = make_float4(v[0], v[1], v[2], v[3]);
-                if constexpr (EPI) q = epi_quad(epi, q, o, 4 * c4, STEM_COUT);                 // evaluation-mode batch norm (epilogue.h)
-                dst[c4] = q;
-            }
-        }
     }
 }
 
@@ -357,31 +263,8 @@ int osn::stem_conv_fwd_epi(const float* in, const float* W, const int32_t* nbr, 
                 "osn_stem_conv_fwd: needs K <= 125, cin <= %d, cout == %d (K=%d cin=%d cout=%d)", STEM_CMAX, STEM_COUT, K, cin, cout);
     if (n_out == 0) return OSN_OK;
     OSN_REQUIRE(in && W && nbr && out && aligned16(out), OSN_E_ARG, "osn_stem_conv_fwd: null or unaligned pointer");
-    // four lanes per row from 4096 rows on (below that the single-lane kernel's launch is all there is); from 32 k rows on the
-    // persistent kernel with the weights in LDS (two workgroups per CU; needs the weight 16-byte aligned and a multiple of 4 floats)
-    const size_t wbytes = size_t(K) * cin * STEM_COUT * 4;
-    bool lds_ok = n_out >= 32768 && aligned16(W) && wbytes <= 64 * 1024;
-    auto kern = epi.mean ? stem_fwd_lds_kernel<true> : stem_fwd_lds_kernel<false>;
-    if (lds_ok) {
-        // static + dynamic LDS beyond 64 KB needs the opt-in attribute: once per (instance, device); refused => the scalar-cache kernel
-        static std::atomic<unsigned char> attr_set[2][64];
-        int dev_id = 0;
-        OSN_HIP(hipGetDevice(&dev_id));
-        const bool slot_ok = dev_id >= 0 && dev_id < 64;
-        if (!(slot_ok && attr_set[epi.mean ? 1 : 0][dev_id].load(std::memory_order_relaxed))) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) {
-                (void)hipGetLastError();
-                lds_ok = false;
-            } else if (slot_ok) {
-                attr_set[epi.mean ? 1 : 0][dev_id].store(1, std::memory_order_relaxed);
-            }
-        }
-    }
-    if (lds_ok) {
-        int64_t g = cdiv(n_out, 64);
-        if (g > 512) g = 512;
-        hipLaunchKernelGGL(kern, dim3(unsigned(g)), dim3(256), wbytes, st, in, W, nbr, out, n_out, K, cin, epi);
-    } else if (n_out >= 4096)
+    // four lanes per row from 4096 rows on (below that the single-lane kernel's launch is all there is)
+    if (n_out >= 4096)
         hipLaunchKernelGGL(epi.mean ? stem_fwd4_kernel<true> : stem_fwd4_kernel<false>, dim3(unsigned(cdiv(n_out, 64))), dim3(256), 0, st, in, W, nbr, out,
                            n_out, K, cin, epi);
     else

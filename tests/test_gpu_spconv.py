@@ -189,34 +189,6 @@ def test_register_gather_kernel_edge_cases(n_in, n_out, K, cin, cout):
     assert torch.equal(out, out_p), "the table's row order changed the result"
 
 
-@pytest.mark.parametrize("n_in,n_out,K,cin", [(50000, 40001, 125, 3), (33000, 32768, 27, 4), (70000, 70017, 125, 1)])
-def test_stem_kernel_with_the_weights_in_lds_is_bitwise_the_scalar_cache_kernel(n_in, n_out, K, cin):
-    """Round 6: from 32 768 output rows on the stem convolution (models/mink_unet.py:47-50: 5^3, 3 -> 32) runs on persistent workgroups
-    with the weights in LDS (stem_fwd_lds_kernel).  Same offsets per wave, same fmaf order, same final tree as the four-wave kernel below
-    that size: a launch on the first 20 000 columns of the same table (-> the scalar-cache kernel) is BITWISE the first 20 000 rows; the
-    whole output against a float64 product through the table (exact fp32 products: 3e-5 of the tensor max is the file's bound, observed
-    ~1e-6); ragged last block, rows without a neighbour, reproducibility."""
-    from openscene_amd import ops
-    d = dev()
-    g = torch.Generator().manual_seed(n_out + K)
-    nbr = torch.randint(0, n_in, (K, n_out), generator=g, dtype=torch.int32)
-    nbr[torch.rand(K, n_out, generator=g) < 0.88] = -1                # ~12 % occupancy, the 5^3 map's
-    nbr[:, 5] = -1
-    feats = torch.randn(n_in, cin, generator=g)
-    w = torch.randn(K, cin, 32, generator=g) / np.sqrt(cin * K * 0.12)
-    ref = torch.zeros(n_out, 32, dtype=torch.float64)
-    for k in range(K):
-        on = nbr[k] >= 0
-        ref[on] += feats[nbr[k][on].long()].double() @ w[k].double()
-    assert ops.stem_eligible(K, cin, 32)
-    out = ops.stem_conv_fwd(feats.to(d), w.to(d), nbr.to(d), n_out)
-    assert float((out.cpu().double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
-    assert float(out[5].abs().max()) == 0.0
-    assert torch.equal(out, ops.stem_conv_fwd(feats.to(d), w.to(d), nbr.to(d), n_out)), "not bitwise reproducible"
-    head = ops.stem_conv_fwd(feats.to(d), w.to(d), nbr[:, :20000].contiguous().to(d), 20000)      # 4096 <= rows < 32768: stem_fwd4_kernel
-    assert torch.equal(out[:20000], head), "the LDS kernel's rows differ from the scalar-cache kernel's"
-
-
 def test_out_rows_indirection_and_determinism():
     from openscene_amd import ops
     cm = cloud("mid")
