@@ -32,14 +32,13 @@ extern "C" int osn_maps_build(const osn_map_level* levels, int n_levels, const o
             const osn_map_job& q = jobs[j];
             if (q.lvl_in < 0 || q.lvl_in >= n_levels || q.lvl_out < 0 || q.lvl_out >= n_levels || q.ksize < 1 || q.ksize > 7 || !q.nbr_fwd) continue;
             const int K = q.ksize * q.ksize * q.ksize;
-            const int64_t n_in = levels[q.lvl_in].rows, n_out = levels[q.lvl_out].rows;
+            const int64_t n_in = levels[q.lvl_in].rows;
             if (q.counts) fills.push_back(FillJob{q.counts, uint64_t(K) * 8u, 0u, 0u});
             if (q.self_map) {
                 if (K > 1 && n_in > 0) fills.push_back(FillJob{q.nbr_fwd + int64_t(K / 2 + 1) * n_in, uint64_t(K / 2) * uint64_t(n_in) * 4u, 0xFFFFFFFFu, 0u});
             } else if (q.nbr_bwd && n_in > 0) {
                 fills.push_back(FillJob{q.nbr_bwd, uint64_t(K) * uint64_t(n_in) * 4u, 0xFFFFFFFFu, 0u});
             }
-            (void)n_out;
         }
         const int rc = fill_batch(fills.data(), int(fills.size()), main);
         if (rc) return rc;

@@ -329,7 +329,6 @@ def kmap_count(nbr):
 # ------------------------------------------------- every kernel map of a scene from one call, on several streams
 _MAP_LEVEL = None
 _MAP_JOB = None
-_map_streams = {}
 _map_events = {}
 # streams the jobs of one maps_build call are dealt to.  Measured on MI355X (profiles/r03_s5..s7): 2 - 4 streams do not
 # shorten the step (12.5 - 12.7 ms either way: the 5^3 stem map is the long pole and the first thing the forward pass
