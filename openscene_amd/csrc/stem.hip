@@ -13,10 +13,12 @@
 // operands, 12 accumulators, no cross-lane reduction; per-workgroup partial sums, summed in workgroup order.
 #include "common.h"
 #include "epilogue.h"
+#include "split.h"
 
 namespace osn {
 
 constexpr int STEM_CMAX = 4;       // input channels at most
+constexpr int64_t STEM_MFMA_MIN_ROWS = 32768;   // output rows from which the forward convolution runs on the matrix cores (stem_mfma_fwd_kernel)
 constexpr int STEM_COUT = 32;      // output channels handled per thread
 
 // out[o][0..31] = sum_k in[nbr[k][o]][0..cin) @ W[k]      (cout == 32)
@@ -130,6 +132,139 @@ __global__ __launch_bounds__(256) void stem_fwd4_kernel(const float* __restrict_
         }
         dst[0] = v0;
         dst[1] = v1;
+    }
+}
+
+// Round 6: the stem convolution of the LARGE maps on the matrix cores.  The plain-fp32 kernels above walk the table densely: 125 x 96
+// FMAs per row of which 89 % multiply the zero row of an absent neighbour, and a wave64 VALU instruction holds its 16-lane SIMD for four
+// cycles -- 81 us for 0.27 GFLOP of real work, alone on the device at the head of every forward pass.  As a matrix product the same walk
+// is cheap: the convolution is  out[o][0..32) = A[o][0..8 P) @ B[0..8 P)][0..32)  with P = ceil(K / 2) "offset pairs",
+//   A[o][8 v + 4 h + c] = in[nbr[2 v + h][o]][c]   (c < cin, zero otherwise / for an absent neighbour),   B[8 v + 4 h + c][n] = W[2 v + h][c][n],
+// i.e. EIGHT contraction elements per lane are two table entries and two gathered input rows: the register-gather kernel's scheme
+// (spconv_rg.hip) with the A operand assembled from two neighbours.  Four waves split the 32-deep k-steps (four offset pairs each) of a
+// 64-row workgroup, every wave splits its B fragments from the fp32 weight itself (no weight image: the stem's kernel changes every
+// step and is 48 KB), partial tiles are summed in wave order through LDS.  Arithmetic: "bf16x6" like every other convolution here
+// (three bf16 pieces per operand, six MFMAs per block, fp32 accumulate: fp32-class, not the exact fmaf chain of the kernels above --
+// the small maps keep those).
+typedef float stem_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 stem_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 stem_bf16x4 __attribute__((ext_vector_type(4)));
+
+template <bool EPI>
+__global__ __launch_bounds__(256, 2) void stem_mfma_fwd_kernel(const float* __restrict__ in, const float* __restrict__ W,
+                                                               const int32_t* __restrict__ nbr, float* __restrict__ out,
+                                                               int64_t n_out, int K, int cin, const Epi epi) {
+    constexpr int LDR = 32 + 4;
+    __shared__ __attribute__((aligned(16))) float red[4][64][LDR];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int64_t row0 = int64_t(blockIdx.x) * 64;
+    const int n_steps = ((K + 1) / 2 + 3) / 4;                        // 32-deep k-steps (four offset pairs each)
+    stem_f32x4 acc[4][2];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = stem_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int s = wave; s < n_steps; s += 4) {
+        const int k0 = 2 * (4 * s + lg), k1 = k0 + 1;               // this lane's two offsets
+        // ---- table entries and input rows of the four row blocks (absent neighbour / offset past the kernel: zeros)
+        int i0[4], i1[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const int64_t r = row0 + 16 * rb + l15;
+            const bool on = r < n_out;
+            i0[rb] = (on && k0 < K) ? nbr[int64_t(k0) * n_out + r] : -1;
+            i1[rb] = (on && k1 < K) ? nbr[int64_t(k1) * n_out + r] : -1;
+        }
+        // ---- B fragments of this k-step from the fp32 weight: element e of the lane = W[k0 + (e >> 2)][e & 3][16 cb + l15]
+        stem_bf16x8 B[2][3];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int n = 16 * cb + l15;
+            if (k0 < K) {
+                const float* p = W + int64_t(k0) * cin * STEM_COUT + n;
+                w0.x = p[0];
+                if (cin > 1) w0.y = p[STEM_COUT];
+                if (cin > 2) w0.z = p[2 * STEM_COUT];
+                if (cin > 3) w0.w = p[3 * STEM_COUT];
+            }
+            if (k1 < K) {
+                const float* p = W + int64_t(k1) * cin * STEM_COUT + n;
+                w1.x = p[0];
+                if (cin > 1) w1.y = p[STEM_COUT];
+                if (cin > 2) w1.z = p[2 * STEM_COUT];
+                if (cin > 3) w1.w = p[3 * STEM_COUT];
+            }
+            stem_bf16x4 a1, a2, a3, b1, b2, b3;
+            tl_split4(w0, a1, a2, a3);
+            tl_split4(w1, b1, b2, b3);
+            B[cb][0] = __builtin_shufflevector(a1, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            B[cb][1] = __builtin_shufflevector(a2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
+            B[cb][2] = __builtin_shufflevector(a3, b3, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        float4 x0[4], x1[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            x0[rb] = make_float4(0.f, 0.f, 0.f, 0.f);
+            x1[rb] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i0[rb] >= 0) {
+                const float* p = in + int64_t(i0[rb]) * cin;
+                x0[rb].x = p[0];
+                if (cin > 1) x0[rb].y = p[1];
+                if (cin > 2) x0[rb].z = p[2];
+                if (cin > 3) x0[rb].w = p[3];
+            }
+            if (i1[rb] >= 0) {
+                const float* p = in + int64_t(i1[rb]) * cin;
+                x1[rb].x = p[0];
+                if (cin > 1) x1[rb].y = p[1];
+                if (cin > 2) x1[rb].z = p[2];
+                if (cin > 3) x1[rb].w = p[3];
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            // (a row block none of whose 16 rows x 8 offsets has a neighbour: nothing to add -- wave-uniform)
+            if (__ballot(i0[rb] >= 0 || i1[rb] >= 0) == 0ull) continue;
+            stem_bf16x4 a1, a2, a3, b1, b2, b3;
+            tl_split4(x0[rb], a1, a2, a3);
+            tl_split4(x1[rb], b1, b2, b3);
+            const stem_bf16x8 A1 = __builtin_shufflevector(a1, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const stem_bf16x8 A2 = __builtin_shufflevector(a2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
+            const stem_bf16x8 A3 = __builtin_shufflevector(a3, b3, 0, 1, 2, 3, 4, 5, 6, 7);
+            // smallest terms first per accumulator; consecutive MFMAs on different accumulators
+#define STEM_MFMA(AP, BP)                                                                                      \
+    _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                           \
+        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[cb][BP], AP, acc[rb][cb], 0, 0, 0);
+            STEM_MFMA(A3, 0) STEM_MFMA(A2, 1) STEM_MFMA(A1, 2) STEM_MFMA(A2, 0) STEM_MFMA(A1, 1) STEM_MFMA(A1, 0)
+#undef STEM_MFMA
+        }
+    }
+    // ---- the four waves' partial tiles -> out, summed in wave order (64 rows x 32 columns through LDS)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+            *reinterpret_cast<stem_f32x4*>(&red[wave][16 * rb + l15][16 * cb + 4 * lg]) = acc[rb][cb];
+    __syncthreads();
+    EpiCols ec;
+    if constexpr (EPI) ec = epi_cols(epi, 4 * (tid & 7));
+    for (int e = tid; e < 64 * 8; e += 256) {
+        const int j = e >> 3, c4 = e & 7;
+        const int64_t r = row0 + j;
+        if (r < n_out) {
+            float4 sum = *reinterpret_cast<const float4*>(&red[0][j][4 * c4]);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 v = *reinterpret_cast<const float4*>(&red[w][j][4 * c4]);
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+            if constexpr (EPI) sum = epi_apply(epi, ec, sum, r, 4 * c4, STEM_COUT);      // evaluation-mode batch norm (epilogue.h)
+            *reinterpret_cast<float4*>(out + r * STEM_COUT + 4 * c4) = sum;
+        }
     }
 }
 
@@ -263,8 +398,12 @@ int osn::stem_conv_fwd_epi(const float* in, const float* W, const int32_t* nbr, 
                 "osn_stem_conv_fwd: needs K <= 125, cin <= %d, cout == %d (K=%d cin=%d cout=%d)", STEM_CMAX, STEM_COUT, K, cin, cout);
     if (n_out == 0) return OSN_OK;
     OSN_REQUIRE(in && W && nbr && out && aligned16(out), OSN_E_ARG, "osn_stem_conv_fwd: null or unaligned pointer");
-    // four lanes per row from 4096 rows on (below that the single-lane kernel's launch is all there is)
-    if (n_out >= 4096)
+    // four lanes per row from 4096 rows on (below that the single-lane kernel's launch is all there is); from STEM_MFMA_MIN_ROWS on
+    // the matrix-core kernel (split-bf16, fp32-class instead of exact fp32 products)
+    if (n_out >= STEM_MFMA_MIN_ROWS)
+        hipLaunchKernelGGL(epi.mean ? stem_mfma_fwd_kernel<true> : stem_mfma_fwd_kernel<false>, dim3(unsigned(cdiv(n_out, 64))), dim3(256), 0, st, in, W, nbr,
+                           out, n_out, K, cin, epi);
+    else if (n_out >= 4096)
         hipLaunchKernelGGL(epi.mean ? stem_fwd4_kernel<true> : stem_fwd4_kernel<false>, dim3(unsigned(cdiv(n_out, 64))), dim3(256), 0, st, in, W, nbr, out,
                            n_out, K, cin, epi);
     else

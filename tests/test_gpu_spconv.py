@@ -189,6 +189,37 @@ def test_register_gather_kernel_edge_cases(n_in, n_out, K, cin, cout):
     assert torch.equal(out, out_p), "the table's row order changed the result"
 
 
+@pytest.mark.parametrize("n_in,n_out,K,cin", [(50000, 40001, 125, 3), (33000, 32768, 27, 4), (70000, 70017, 125, 1), (40000, 33333, 8, 2)])
+def test_stem_convolution_on_the_matrix_cores(n_in, n_out, K, cin):
+    """Round 6: from 32 768 output rows on, the stem convolution (models/mink_unet.py:47-50: 5^3, 3 -> 32) is a matrix product on the MFMA
+    units (stem_mfma_fwd_kernel: eight contraction elements per lane = two table entries x four channels, B fragments split from the fp32
+    weight in the kernel, split-bf16 arithmetic like every other convolution here).  Against a float64 product through the same table,
+    3e-5 of the tensor max (the file's bound; observed ~1e-6); odd offset counts (the padded half of the last offset pair), 1 - 4 input
+    channels, a ragged last workgroup, rows without a neighbour (exact zeros), bitwise reproducibility, and agreement with the exact-fp32
+    kernel of the smaller maps on the first 20 000 rows of the same table."""
+    from openscene_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(n_out + K)
+    nbr = torch.randint(0, n_in, (K, n_out), generator=g, dtype=torch.int32)
+    nbr[torch.rand(K, n_out, generator=g) < 0.88] = -1                # ~12 % occupancy, the 5^3 map's
+    nbr[:, 5] = -1
+    feats = torch.randn(n_in, cin, generator=g)
+    w = torch.randn(K, cin, 32, generator=g) / np.sqrt(cin * K * 0.12)
+    ref = torch.zeros(n_out, 32, dtype=torch.float64)
+    for k in range(K):
+        on = nbr[k] >= 0
+        ref[on] += feats[nbr[k][on].long()].double() @ w[k].double()
+    assert ops.stem_eligible(K, cin, 32)
+    out = ops.stem_conv_fwd(feats.to(d), w.to(d), nbr.to(d), n_out)
+    scale = float(ref.abs().max())
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err <= 3e-5 * scale, "max |d| %.3e of %.3e" % (err, scale)
+    assert float(out[5].abs().max()) == 0.0
+    assert torch.equal(out, ops.stem_conv_fwd(feats.to(d), w.to(d), nbr.to(d), n_out)), "not bitwise reproducible"
+    head = ops.stem_conv_fwd(feats.to(d), w.to(d), nbr[:, :20000].contiguous().to(d), 20000)      # 4096 <= rows < 32768: exact fp32 products
+    assert float((out[:20000] - head).abs().max()) <= 3e-5 * scale
+
+
 def test_out_rows_indirection_and_determinism():
     from openscene_amd import ops
     cm = cloud("mid")
