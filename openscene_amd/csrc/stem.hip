@@ -341,6 +341,135 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     }
 }
 
+// Round 6: the weight gradient of the large maps on the matrix cores (the last kernel of every backward pass, alone on the device:
+// 100 us dense over the table).  gW[k][c][n] = sum over rows o of in[nbr[k][o]][c] * gout[o][n] is the product
+//   D_c[k][n] = sum_o A_c[k][o] G[o][n],   A_c[k][o] = in[nbr[k][o]][c]  (zero for an absent neighbour),   one product per input channel c,
+// contracted over the ROWS: an MFMA step takes 32 rows, lane (l & 15, l >> 4) of the first operand holds A_c[16 kb + (l & 15)][8 rows]
+// = eight consecutive entries of ONE table row (loaded once for all channels) and the gathered values, of the second
+// G[8 rows][16 nb + (l & 15)].  A workgroup = 4 waves x 2 blocks of 16 offsets (all 125 offsets x cin x 32 channels), walks the 32-row
+// steps blockIdx.x, + gridDim.x, ... in
+// ascending order and leaves ONE partial gradient; the partials are summed in workgroup order by stem_wgrad_reduce_kernel
+// (deterministic).  Split-bf16 arithmetic ("bf16x6"), fp32 accumulate.
+constexpr int SWM_PARTS = 512;     // workgroups (two per CU) = partial gradients of the matrix-core weight gradient
+
+__global__ __launch_bounds__(256, 2) void stem_mfma_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+                                                                 const int32_t* __restrict__ nbr, float* __restrict__ partial,
+                                                                 int64_t n_out, int K, int cin) {
+    // wave w owns the offsets 32 w .. 32 w + 31 as two blocks of 16 (lane & 15 = offset within the block), one accumulator set per
+    // input channel: a table entry is loaded ONCE and serves the (up to four) channels of its row
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    stem_f32x4 acc[2][STEM_CMAX][2];
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int c = 0; c < STEM_CMAX; ++c)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[ob][c][nb] = stem_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t n_steps = (n_out + 31) / 32;
+    const int kk[2] = {32 * wave + l15, 32 * wave + 16 + l15};               // this lane's offset in either block
+    for (int64_t rs = blockIdx.x; rs < n_steps; rs += gridDim.x) {            // ascending rows: fixed summation order
+        const int64_t o0 = rs * 32 + 8 * lg;                                  // this lane's eight rows
+        // ---- every load of the step first: table entries of both blocks, gradient rows; then the gathers
+        int idx[2][8];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) idx[ob][e] = (kk[ob] < K && o0 + e < n_out) ? nbr[int64_t(kk[ob]) * n_out + o0 + e] : -1;
+        float g[2][8];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[nb][e] = o0 + e < n_out ? gout[(o0 + e) * STEM_COUT + 16 * nb + l15] : 0.f;
+        float x[2][STEM_CMAX][8];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float* p = in + int64_t(idx[ob][e] >= 0 ? idx[ob][e] : 0) * cin;
+#pragma unroll
+                for (int c = 0; c < STEM_CMAX; ++c) x[ob][c][e] = (idx[ob][e] >= 0 && c < cin) ? p[c] : 0.f;
+            }
+        // ---- G fragments: element e of the lane = gout[o0 + e][16 nb + l15]
+        stem_bf16x8 G[2][3];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            stem_bf16x4 a1, a2, a3, b1, b2, b3;
+            tl_split4(make_float4(g[nb][0], g[nb][1], g[nb][2], g[nb][3]), a1, a2, a3);
+            tl_split4(make_float4(g[nb][4], g[nb][5], g[nb][6], g[nb][7]), b1, b2, b3);
+            G[nb][0] = __builtin_shufflevector(a1, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            G[nb][1] = __builtin_shufflevector(a2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
+            G[nb][2] = __builtin_shufflevector(a3, b3, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            bool any = false;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) any = any || idx[ob][e] >= 0;
+            if (__ballot(any) == 0ull) continue;                              // no pair in these 16 offsets x 32 rows (wave-uniform)
+#pragma unroll
+            for (int c = 0; c < STEM_CMAX; ++c) {
+                if (c < cin) {
+                    stem_bf16x4 a1, a2, a3, b1, b2, b3;
+                    tl_split4(make_float4(x[ob][c][0], x[ob][c][1], x[ob][c][2], x[ob][c][3]), a1, a2, a3);
+                    tl_split4(make_float4(x[ob][c][4], x[ob][c][5], x[ob][c][6], x[ob][c][7]), b1, b2, b3);
+                    const stem_bf16x8 A1 = __builtin_shufflevector(a1, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const stem_bf16x8 A2 = __builtin_shufflevector(a2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const stem_bf16x8 A3 = __builtin_shufflevector(a3, b3, 0, 1, 2, 3, 4, 5, 6, 7);
+#define STEM_WMFMA(AP, GP)                                                                                     \
+    _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                                           \
+        acc[ob][c][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AP, G[nb][GP], acc[ob][c][nb], 0, 0, 0);
+                    STEM_WMFMA(A3, 0) STEM_WMFMA(A2, 1) STEM_WMFMA(A1, 2) STEM_WMFMA(A2, 0) STEM_WMFMA(A1, 1) STEM_WMFMA(A1, 0)
+#undef STEM_WMFMA
+                }
+            }
+        }
+    }
+    // ---- partial[blockIdx.x][k][c][n]: C row = 4 (lane >> 4) + r (offset within the block), column = lane & 15 (output channel)
+    float* d = partial + int64_t(blockIdx.x) * K * cin * STEM_COUT;
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int c = 0; c < STEM_CMAX; ++c)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 32 * wave + 16 * ob + 4 * lg + r;
+                    if (k < K && c < cin) d[(k * cin + c) * STEM_COUT + 16 * nb + l15] = acc[ob][c][nb][r];
+                }
+}
+
+// gW[e] = sum of the partials in a FIXED two-level order: 16 thread rows each add a contiguous sixteenth of the partials (ascending),
+// thread row 0 adds the 16 sums (ascending).  (The one-level kernel below walks all 512 partials per thread with 47 workgroups: 20 us.)
+__global__ __launch_bounds__(1024) void stem_wgrad_reduce2_kernel(const float* __restrict__ partial, int parts, int total,
+                                                                  float* __restrict__ gW) {
+    __shared__ float sums[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx;
+    const int per = (parts + 15) / 16;
+    const int p0 = ty * per, p1 = min(parts, p0 + per);
+    float s = 0.f;
+    if (e < total) {
+        for (int p = p0; p < p1; p += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[int64_t(p + u < p1 ? p + u : p0) * total + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += p + u < p1 ? v[u] : 0.f;
+        }
+    }
+    sums[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && e < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sums[q][tx];
+        gW[e] = t;
+    }
+}
+
 // gW[e] = partial[0][e] + partial[1][e] + ...   (fixed order)
 __global__ void stem_wgrad_reduce_kernel(const float* __restrict__ partial, int parts, int total, float* __restrict__ gW) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -362,7 +491,7 @@ __global__ void stem_wgrad_reduce_kernel(const float* __restrict__ partial, int 
 using namespace osn;
 
 extern "C" size_t osn_stem_conv_wgrad_ws_bytes(int K, int cin) {
-    return size_t(SW_PARTS) * size_t(K > 0 ? K : 1) * size_t(cin > 0 ? cin : 1) * STEM_COUT * 4;
+    return size_t(SWM_PARTS > SW_PARTS ? SWM_PARTS : SW_PARTS) * size_t(K > 0 ? K : 1) * size_t(cin > 0 ? cin : 1) * STEM_COUT * 4;
 }
 
 extern "C" int osn_stem_conv_wgrad(const float* in, const float* gout, const int32_t* nbr, float* gW, int64_t n_out, int K,
@@ -380,11 +509,21 @@ extern "C" int osn_stem_conv_wgrad(const float* in, const float* gout, const int
     OSN_REQUIRE(in && gout && nbr && aligned16(gout), OSN_E_ARG, "osn_stem_conv_wgrad: null or unaligned pointer");
     OSN_REQUIRE(ws && ws_bytes >= osn_stem_conv_wgrad_ws_bytes(K, cin), OSN_E_WS, "osn_stem_conv_wgrad: workspace %zu < %zu",
                 ws_bytes, osn_stem_conv_wgrad_ws_bytes(K, cin));
-    const int64_t n_chunks = cdiv(n_out, SW_ROWS);
-    const int parts = int(n_chunks < SW_PARTS ? n_chunks : SW_PARTS);
     float* partial = static_cast<float*>(ws);
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(unsigned(parts), unsigned(cdiv(K, SW_KB))), dim3(256), 0, st, in, gout, nbr, partial,
-                       n_out, K, cin);
+    int parts;
+    if (n_out >= STEM_MFMA_MIN_ROWS) {                 // the large maps: matrix cores (stem_mfma_wgrad_kernel), split-bf16
+        const int64_t n_steps = cdiv(n_out, 32);
+        parts = int(n_steps < SWM_PARTS ? n_steps : SWM_PARTS);
+        hipLaunchKernelGGL(stem_mfma_wgrad_kernel, dim3(unsigned(parts)), dim3(256), 0, st, in, gout, nbr, partial, n_out, K, cin);
+        hipLaunchKernelGGL(stem_wgrad_reduce2_kernel, dim3(unsigned(cdiv(total, 64))), dim3(1024), 0, st, partial, parts, total, gW);
+        OSN_LAUNCH_CHECK();
+        return OSN_OK;
+    } else {
+        const int64_t n_chunks = cdiv(n_out, SW_ROWS);
+        parts = int(n_chunks < SW_PARTS ? n_chunks : SW_PARTS);
+        hipLaunchKernelGGL(stem_wgrad_kernel, dim3(unsigned(parts), unsigned(cdiv(K, SW_KB))), dim3(256), 0, st, in, gout, nbr, partial,
+                           n_out, K, cin);
+    }
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(unsigned(cdiv(total, 256))), dim3(256), 0, st, partial, parts, total, gW);
     OSN_LAUNCH_CHECK();
     return OSN_OK;

@@ -218,6 +218,17 @@ def test_stem_convolution_on_the_matrix_cores(n_in, n_out, K, cin):
     assert torch.equal(out, ops.stem_conv_fwd(feats.to(d), w.to(d), nbr.to(d), n_out)), "not bitwise reproducible"
     head = ops.stem_conv_fwd(feats.to(d), w.to(d), nbr[:, :20000].contiguous().to(d), 20000)      # 4096 <= rows < 32768: exact fp32 products
     assert float((out[:20000] - head).abs().max()) <= 3e-5 * scale
+    # the weight gradient of the same map (stem_mfma_wgrad_kernel: contraction over the rows, 256 partial gradients in workgroup order)
+    gout = torch.randn(n_out, 32, generator=g)
+    gw_ref = torch.zeros(K, cin, 32, dtype=torch.float64)
+    for k in range(K):
+        on = nbr[k] >= 0
+        gw_ref[k] = feats[nbr[k][on].long()].double().t() @ gout[on].double()
+    gw = ops.stem_conv_wgrad(feats.to(d), gout.to(d), nbr.to(d), K)
+    assert gw.shape == (K, cin, 32)
+    gerr = float((gw.cpu().double() - gw_ref).abs().max())
+    assert gerr <= 3e-5 * float(gw_ref.abs().max()), "weight gradient: max |d| %.3e of %.3e" % (gerr, float(gw_ref.abs().max()))
+    assert torch.equal(gw, ops.stem_conv_wgrad(feats.to(d), gout.to(d), nbr.to(d), K)), "weight gradient not bitwise reproducible"
 
 
 def test_out_rows_indirection_and_determinism():

@@ -151,6 +151,7 @@ def stem_main():
     print(json.dumps({"fwd_old_us": timed(lambda: ops.spconv_fwd(x, w, nbr, n), reps),
                       "fwd_stem_us": timed(lambda: ops.stem_conv_fwd(x, w, nbr, n), reps),
                       "wgrad_old_us": timed(lambda: ops.spconv_wgrad(x, g, nbr, 125, cnt), reps),
+                      "wgrad_stem_us": timed(lambda: ops.stem_conv_wgrad(x, g, nbr, 125), reps),
                       "fwd_diff": (a - b).abs().max().item() / a.abs().max().item(),
                       "kmap125_us": timed(lambda: ops.kmap_build(cm._tables[1], cm._coords[1], 5, 1, with_counts=True), reps),
                       "kmap27_us": timed(lambda: ops.kmap_build(cm._tables[1], cm._coords[1], 3, 1, with_counts=True), reps),
