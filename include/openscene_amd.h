@@ -325,13 +325,17 @@ int osn_spconv_fwd_ws(const float* in, int64_t n_in, const void* Wp, const void*
                       size_t ws_bytes, osn_stream_t stream);
 
 /* The 3-channel stem convolution (conv0p1s1: 5^3 kernel, 3 -> 32, models/mink_unet.py:47-50): same contract as
- * osn_spconv_fwd on the plain (unordered) table, exact fp32 FMA chain in ascending offset order, for cin <= 4
- * and cout == 32 (no contraction worth a matrix unit; the op streams the 125 x n_out table once).            */
+ * osn_spconv_fwd on the plain (unordered) table, for cin <= 4 and cout == 32.  Below 32 768 output rows: exact fp32 FMA
+ * chains in ascending offset order.  From 32 768 rows on (round 6): a matrix product on the MFMA units -- two table entries
+ * x four padded channels per lane, the library's split-bf16 arithmetic (fp32-class: three bf16 pieces per operand, six
+ * products, fp32 accumulate), partial tiles of four waves summed in wave order.  Bitwise reproducible either way.           */
 int osn_stem_conv_fwd(const float* in, const float* W, const int32_t* nbr, float* out, int64_t n_out, int K,
                       int cin, int cout, osn_stream_t stream);
 /* Its weight gradient gW[k][ci][n] = sum_o in[nbr[k][o]][ci] * gout[o][n] ([ME] MinkowskiConvolutionFunction backward for
- * the same layer): dense over the table (an absent neighbour is a zero row), fp32 fmaf chains down the rows in ascending
- * order, per-workgroup partial sums added in workgroup order -- bitwise reproducible.  ws: osn_stem_conv_wgrad_ws_bytes. */
+ * the same layer): dense over the table (an absent neighbour is a zero row), rows in ascending order, per-workgroup partial
+ * sums added in a fixed order -- bitwise reproducible.  Below 32 768 rows fp32 fmaf chains; from 32 768 rows on the
+ * contraction over the rows runs on the MFMA units (split-bf16, 32 rows per step, one accumulator set per input channel,
+ * 512 partial gradients).  ws: osn_stem_conv_wgrad_ws_bytes.                                                                */
 size_t osn_stem_conv_wgrad_ws_bytes(int K, int cin);
 int osn_stem_conv_wgrad(const float* in, const float* gout, const int32_t* nbr, float* gW, int64_t n_out, int K, int cin,
                         int cout, void* ws, size_t ws_bytes, osn_stream_t stream);
